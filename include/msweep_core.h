@@ -1,0 +1,157 @@
+/*
+ * msweep_core.h -- C ABI of the MI355X-native abundance-estimation core (libmsweep_core.so).
+ *
+ * This is the drop-in boundary for mSWEEP's estimation hot path.  Every entry point cites
+ * the reference interface (file:line under /root/reference) it replaces.  Plain pointers
+ * and sizes only; all pointers are HOST pointers unless a name ends in `_dev`.  Return
+ * value 0 = success, non-zero = error (text via msw_last_error); the C++ shim
+ * (msweep_amd/cpp/rcgpar_hip.hpp) turns non-zero into std::runtime_error so that
+ * mSWEEP's try/catch blocks (src/mSWEEP.cpp:400-406, 506-511) behave as with rcgpar.
+ *
+ * Threading: one caller thread per handle (the reference calls from its single main
+ * thread, src/mSWEEP.cpp:402,507).  A handle is bound to one HIP device.
+ */
+#ifndef MSWEEP_CORE_H
+#define MSWEEP_CORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msw_core *msw_handle;
+
+/* --algorithm (src/mSWEEP.cpp:127,192-204): rcggpu -> MSW_ALGO_RCG, emgpu -> MSW_ALGO_EM. */
+enum { MSW_ALGO_RCG = 0, MSW_ALGO_EM = 1 };
+/* --emprecision (src/mSWEEP.cpp:129,202) */
+enum { MSW_PREC_DOUBLE = 0, MSW_PREC_FLOAT = 1 };
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+int msw_core_create(int device, msw_handle *out);
+void msw_core_destroy(msw_handle h);
+/* last error text of the handle (or of the failed msw_core_create when h == NULL) */
+const char *msw_last_error(msw_handle h);
+/* library / device identification string ("msweep_core <ver> gfx950 ...") */
+const char *msw_core_version(void);
+
+/* ---- likelihood upload -------------------------------------------------------------
+ * Replaces the materialised `seamat::DenseMatrix<double> log_likelihoods`
+ * (include/Likelihood.hpp:85,176-185) that rcg_optl receives as `ll_mat`
+ * (src/mSWEEP.cpp:176,402,507).  The likelihood stays resident on the device across the
+ * 1 + --iters solves of one grouping (same `logl` object at :402 and :507).            */
+
+/* Dense G x E, rows = groups, element (g, j) at L[g*ld + j] -- the seamat layout read via
+ * operator()(row, col) (include/Likelihood.hpp:182,265); needed for --read-likelihood
+ * (include/Likelihood.hpp:224-253). */
+int msw_core_set_dense_logl(msw_handle h, const double *L, size_t n_groups, size_t n_ecs,
+                            size_t ld);
+
+/* CSR-of-ECs form of the same matrix: for EC j the cells k in [rowptr[j], rowptr[j+1])
+ * name group grp[k] hit cnt[k] >= 1 times; L(g, j) = lut[g*lut_ld + cnt] and every cell
+ * not listed is `logzi` (= lut[g*lut_ld + 0] for every g, include/Likelihood.hpp:98).
+ * `lut` is the precalc_lls table (include/Likelihood.hpp:92-107). */
+int msw_core_set_csr(msw_handle h, const uint64_t *rowptr, const uint32_t *grp,
+                     const uint32_t *cnt, const double *lut, size_t lut_ld, double logzi,
+                     size_t n_groups, size_t n_ecs);
+
+/* Builds the CSR-of-ECs likelihood on the device straight from the pseudoalignment:
+ * replaces LL_WOR21::fill_ll_mat + fill_ec_counts (include/Likelihood.hpp:109-195) and
+ * ConstructAdaptiveLikelihood (:333-380).
+ *   ec_tptr/ec_targets : for EC i the targets it aligned to (the set bits of
+ *                        Alignment::operator()(i, j), include/mSWEEP_alignment.hpp:223)
+ *   target_group[T]    : Alignment::get_groups() (include/mSWEEP_alignment.hpp:241)
+ *   group_sizes[G]     : Grouping::get_sizes()   (include/Grouping.hpp:35-50)
+ *   ec_counts[E]       : Alignment::reads_in_ec  (include/mSWEEP_alignment.hpp:220)
+ *   q, e               : -q / -e flags (bb_constants, include/Likelihood.hpp:212-214)
+ *   min_hits           : --min-hits mask (include/Likelihood.hpp:141-171)
+ * Outputs: *n_groups_out = groups kept, mask_out[G] = groups_considered() (:331),
+ * logc_out[E] = log_counts() (:328); either may be NULL. */
+int msw_core_build_likelihood(msw_handle h, const uint64_t *ec_tptr,
+                              const uint32_t *ec_targets, size_t n_ecs,
+                              const uint32_t *target_group, size_t n_targets,
+                              const uint64_t *group_sizes, size_t n_groups,
+                              const uint64_t *ec_counts, double q, double e,
+                              double zero_inflation, size_t min_hits,
+                              size_t *n_groups_out, uint8_t *mask_out, double *logc_out);
+
+/* Downloads the dense G' x E log-likelihood (rows = groups) of the resident likelihood --
+ * what Likelihood::log_mat() (include/Likelihood.hpp:325) would hold; used by
+ * --write-likelihood (include/Likelihood.hpp:255-273) and the parity tests. */
+int msw_core_get_dense_logl(msw_handle h, double *L_out, size_t ld);
+/* shape of the resident likelihood */
+int msw_core_shape(msw_handle h, size_t *n_groups, size_t *n_ecs, size_t *nnz);
+
+/* ---- solve --------------------------------------------------------------------------
+ * Replaces rcgpar::rcg_optl_torch / rcg_optl_omp / em_torch as called from rcg_optl()
+ * (src/mSWEEP.cpp:176-205) followed by rcgpar::mixture_components[_torch]
+ * (src/mSWEEP.cpp:419-423, 512-516):
+ *   logc[E]   = log_times_observed (natural log of EC counts; -inf allowed,
+ *               src/BootstrapSample.cpp:70)
+ *   alpha0[G] = prior_counts (src/mSWEEP.cpp:391-398)
+ *   tol, max_iters = --tol / --max-iters (src/mSWEEP.cpp:123-125)
+ * theta_out[G] receives mixture_components(gamma, logc).  iters_out / bound_out optional. */
+int msw_core_solve(msw_handle h, const double *logc, const double *alpha0, double tol,
+                   size_t max_iters, int algo, int prec, double *theta_out,
+                   size_t *iters_out, double *bound_out);
+
+/* The G x E log-responsibility matrix gamma of the last solve (the DenseMatrix rcg_optl
+ * returns, src/mSWEEP.cpp:195,199,203; consumed by Sample::store_probs / write_probs /
+ * mGEMS binning, src/mSWEEP.cpp:402,451,478-487).  Row-major, rows = groups, leading
+ * dimension ld >= E.  Materialised on demand from the structured state. */
+int msw_core_gamma(msw_handle h, double *gamma_out, size_t ld);
+
+/* Per-iteration diagnostics of the last solve (what rcgpar logs every 5th iteration to
+ * the verbose stream, src/mSWEEP.cpp:198): arrays of length n (<= max recorded, 4096);
+ * theta_trace is n x G or NULL.  Returns the number of iterations recorded via *n_out. */
+int msw_core_trace(msw_handle h, size_t n, double *bound, double *newnorm, double *beta,
+                   int32_t *didreset, double *theta_trace, size_t *n_out);
+/* how many leading iterations keep a theta snapshot (default 0) */
+int msw_core_set_trace_theta(msw_handle h, size_t n_iters);
+
+/* ---- bootstrap ----------------------------------------------------------------------
+ * Replaces BootstrapSample::init_bootstrap / construct / resample_counts
+ * (src/BootstrapSample.cpp:33-73) and the replicate loop (src/mSWEEP.cpp:496-518).
+ *   ec_counts[E]      Alignment::reads_in_ec as uint32 (src/BootstrapSample.cpp:38-42)
+ *   seed              --seed narrowed to int32 (include/Sample.hpp:169,172)
+ *   bootstrap_count   draws per replicate (src/BootstrapSample.cpp:56)
+ *   replicates [rep_begin, rep_end) of the ONE sequential mt19937_64 stream are solved
+ *   (a rank of an N-GPU job passes its own slice; the stream position of replicate b is
+ *   b * bootstrap_count draws).
+ * theta_out is (rep_end - rep_begin) x G, row b = abundances of replicate rep_begin+b,
+ * normalised by the resampled total as src/mSWEEP.cpp:513 does.  iters_out optional. */
+int msw_core_bootstrap(msw_handle h, const uint32_t *ec_counts, int32_t seed,
+                       size_t bootstrap_count, size_t rep_begin, size_t rep_end,
+                       const double *alpha0, double tol, size_t max_iters, int algo,
+                       int prec, double *theta_out, size_t *iters_out);
+
+/* Only the resampling step: counts_out is (rep_end-rep_begin) x E uint32, bit-exact with
+ * std::discrete_distribution<uint32_t> driven by std::mt19937_64(seed). */
+int msw_core_resample_counts(msw_handle h, const uint32_t *ec_counts, size_t n_ecs,
+                             int32_t seed, size_t bootstrap_count, size_t rep_begin,
+                             size_t rep_end, uint32_t *counts_out);
+
+/* ---- measurement hooks (used by bench.py; no effect on results) ---------------------- */
+/* Device time (ms, HIP events on the solve stream) and launch counts of the dominant
+ * kernels during the last solve: pass A (gradient norm sweep) and pass B (softmax /
+ * column-sum / ELBO sweep). */
+typedef struct msw_timing {
+  double solve_ms;       /* whole solve loop, events on the solve stream */
+  double passA_ms;       /* summed over launches (only when profiling is enabled) */
+  double passB_ms;
+  uint64_t passA_launches;
+  uint64_t passB_launches;
+  uint64_t iters;
+  uint64_t bytes_passA;  /* algorithmic bytes per launch */
+  uint64_t bytes_passB;
+} msw_timing;
+int msw_core_set_profiling(msw_handle h, int enabled);
+int msw_core_last_timing(msw_handle h, msw_timing *out);
+/* fixed-iteration mode for benchmarking: run exactly max_iters iterations (tol ignored) */
+int msw_core_set_fixed_iters(msw_handle h, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,242 @@
+"""ctypes binding of libmsweep_core.so (the C ABI in include/msweep_core.h).
+
+Fails loudly when the HIP extension is missing or no GPU is visible: there is no CPU
+fallback in the product path (the CPU oracle under oracle/ is test infrastructure and is
+never imported from here).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsweep_core.so")
+
+ALGO_RCG, ALGO_EM = 0, 1
+PREC_DOUBLE, PREC_FLOAT = 0, 1
+
+# every symbol include/msweep_core.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "msw_core_create", "msw_core_destroy", "msw_last_error", "msw_core_version",
+    "msw_core_set_dense_logl", "msw_core_set_csr", "msw_core_build_likelihood",
+    "msw_core_get_dense_logl", "msw_core_shape", "msw_core_solve", "msw_core_gamma",
+    "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
+    "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
+    "msw_core_set_fixed_iters",
+]
+
+
+class MswError(RuntimeError):
+    """Non-zero return from the C ABI (mirrors the std::runtime_error the C++ shim throws)."""
+
+
+class Timing(C.Structure):
+    _fields_ = [("solve_ms", C.c_double), ("passA_ms", C.c_double), ("passB_ms", C.c_double),
+                ("passA_launches", C.c_uint64), ("passB_launches", C.c_uint64), ("iters", C.c_uint64),
+                ("bytes_passA", C.c_uint64), ("bytes_passB", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree extension; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MswError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, sz, dp = C.c_void_p, C.c_size_t, C.c_double
+    L.msw_core_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.msw_core_destroy.argtypes = [vp]
+    L.msw_core_destroy.restype = None
+    L.msw_last_error.argtypes = [vp]
+    L.msw_last_error.restype = C.c_char_p
+    L.msw_core_version.restype = C.c_char_p
+    L.msw_core_set_dense_logl.argtypes = [vp, vp, sz, sz, sz]
+    L.msw_core_set_csr.argtypes = [vp, vp, vp, vp, vp, sz, dp, sz, sz]
+    L.msw_core_build_likelihood.argtypes = [vp, vp, vp, sz, vp, sz, vp, sz, vp, dp, dp, dp, sz,
+                                            C.POINTER(sz), vp, vp]
+    L.msw_core_get_dense_logl.argtypes = [vp, vp, sz]
+    L.msw_core_shape.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    L.msw_core_solve.argtypes = [vp, vp, vp, dp, sz, C.c_int, C.c_int, vp, C.POINTER(sz), C.POINTER(dp)]
+    L.msw_core_gamma.argtypes = [vp, vp, sz]
+    L.msw_core_trace.argtypes = [vp, sz, vp, vp, vp, vp, vp, C.POINTER(sz)]
+    L.msw_core_set_trace_theta.argtypes = [vp, sz]
+    L.msw_core_bootstrap.argtypes = [vp, vp, C.c_int32, sz, sz, sz, vp, dp, sz, C.c_int, C.c_int, vp, vp]
+    L.msw_core_resample_counts.argtypes = [vp, vp, sz, C.c_int32, sz, sz, sz, vp]
+    L.msw_core_set_profiling.argtypes = [vp, C.c_int]
+    L.msw_core_set_fixed_iters.argtypes = [vp, C.c_int]
+    L.msw_core_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _arr(x, dt):
+    return np.ascontiguousarray(x, dtype=dt)
+
+
+class Core:
+    """One handle = one GPU + one resident likelihood (the object rcg_optl() would receive)."""
+
+    def __init__(self, device=0):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        rc = self._L.msw_core_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise MswError(self._L.msw_last_error(None).decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.msw_core_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MswError(self._L.msw_last_error(self._h).decode())
+
+    # ---- likelihood -------------------------------------------------------------------
+    def set_dense_logl(self, logl):
+        """logl: G x E array, rows = groups (seamat layout of Likelihood::log_mat())."""
+        logl = np.asarray(logl, dtype=np.float64)
+        if logl.ndim != 2:
+            raise MswError("set_dense_logl: expected a 2-D G x E array")
+        if logl.strides[1] != 8 or logl.strides[0] % 8 or logl.strides[0] < 8 * logl.shape[1]:
+            logl = np.ascontiguousarray(logl)
+        G, E = logl.shape
+        self._check(self._L.msw_core_set_dense_logl(self._h, _ptr(logl), G, E, logl.strides[0] // 8 if G else E))
+
+    def set_csr(self, rowptr, grp, cnt, lut, logzi, n_groups):
+        rowptr = _arr(rowptr, np.uint64)
+        grp = _arr(grp, np.uint32)
+        cnt = _arr(cnt, np.uint32)
+        lut = _arr(lut, np.float64)
+        if lut.ndim != 2 or lut.shape[0] != n_groups:
+            raise MswError("set_csr: lut must be n_groups x lut_ld")
+        if len(grp) != len(cnt) or (len(rowptr) and int(rowptr[-1]) != len(grp)):
+            raise MswError("set_csr: rowptr / grp / cnt lengths disagree")
+        E = len(rowptr) - 1
+        self._check(self._L.msw_core_set_csr(self._h, _ptr(rowptr), _ptr(grp), _ptr(cnt), _ptr(lut),
+                                             lut.shape[1], float(logzi), int(n_groups), E))
+
+    def build_likelihood(self, ec_tptr, ec_targets, target_group, group_sizes, ec_counts, q=0.65, e=0.01,
+                         zero_inflation=0.01, min_hits=0):
+        """Device build from the pseudoalignment (replaces LL_WOR21::fill_ll_mat).
+        Returns (n_groups_kept, mask[G] bool, logc[E])."""
+        ec_tptr = _arr(ec_tptr, np.uint64)
+        ec_targets = _arr(ec_targets, np.uint32)
+        target_group = _arr(target_group, np.uint32)
+        group_sizes = _arr(group_sizes, np.uint64)
+        ec_counts = _arr(ec_counts, np.uint64)
+        E, G = len(ec_tptr) - 1, len(group_sizes)
+        if len(ec_counts) != E:
+            raise MswError("build_likelihood: ec_counts length != n_ecs")
+        n_out = C.c_size_t()
+        mask = np.zeros(G, np.uint8)
+        logc = np.empty(E, np.float64)
+        self._check(self._L.msw_core_build_likelihood(
+            self._h, _ptr(ec_tptr), _ptr(ec_targets), E, _ptr(target_group), len(target_group),
+            _ptr(group_sizes), G, _ptr(ec_counts), q, e, zero_inflation, int(min_hits), C.byref(n_out),
+            _ptr(mask), _ptr(logc)))
+        return n_out.value, mask.astype(bool), logc
+
+    def shape(self):
+        g, e, n = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._check(self._L.msw_core_shape(self._h, C.byref(g), C.byref(e), C.byref(n)))
+        return g.value, e.value, n.value
+
+    def get_dense_logl(self):
+        G, E, _ = self.shape()
+        out = np.empty((G, E))
+        self._check(self._L.msw_core_get_dense_logl(self._h, _ptr(out), E))
+        return out
+
+    # ---- solve --------------------------------------------------------------------------
+    def solve(self, logc, alpha0, tol=1e-6, max_iters=5000, algo=ALGO_RCG, prec=PREC_DOUBLE):
+        G, E, _ = self.shape()
+        logc = _arr(logc, np.float64)
+        alpha0 = _arr(alpha0, np.float64)
+        if len(logc) != E or len(alpha0) != G:
+            raise MswError(f"solve: expected logc[{E}] and alpha0[{G}], got {len(logc)} and {len(alpha0)}")
+        theta = np.empty(G)
+        it, b = C.c_size_t(), C.c_double()
+        self._check(self._L.msw_core_solve(self._h, _ptr(logc), _ptr(alpha0), float(tol), int(max_iters),
+                                           int(algo), int(prec), _ptr(theta), C.byref(it), C.byref(b)))
+        return dict(theta=theta, iters=it.value, bound=b.value)
+
+    def gamma(self):
+        G, E, _ = self.shape()
+        out = np.empty((G, E))
+        self._check(self._L.msw_core_gamma(self._h, _ptr(out), E))
+        return out
+
+    def set_trace_theta(self, n):
+        self._check(self._L.msw_core_set_trace_theta(self._h, int(n)))
+
+    def trace(self, n, with_theta=False):
+        G, _, _ = self.shape()
+        bound, nn, beta = np.full(n, np.nan), np.full(n, np.nan), np.full(n, np.nan)
+        rs = np.full(n, -1, np.int32)
+        th = np.full((n, G), np.nan) if with_theta else None
+        got = C.c_size_t()
+        self._check(self._L.msw_core_trace(self._h, n, _ptr(bound), _ptr(nn), _ptr(beta), _ptr(rs), _ptr(th),
+                                           C.byref(got)))
+        k = got.value
+        return dict(n=k, bound=bound[:k], newnorm=nn[:k], beta=beta[:k], didreset=rs[:k],
+                    theta=None if th is None else th[:k])
+
+    # ---- bootstrap ------------------------------------------------------------------------
+    def bootstrap(self, ec_counts, seed, bootstrap_count, rep_begin, rep_end, alpha0, tol=1e-6,
+                  max_iters=5000, algo=ALGO_RCG, prec=PREC_DOUBLE):
+        G, E, _ = self.shape()
+        ec_counts = _arr(ec_counts, np.uint32)
+        alpha0 = _arr(alpha0, np.float64)
+        if len(ec_counts) != E or len(alpha0) != G:
+            raise MswError("bootstrap: ec_counts / alpha0 length mismatch")
+        n = int(rep_end) - int(rep_begin)
+        theta = np.empty((max(n, 0), G))
+        iters = np.zeros(max(n, 0), np.uint64)
+        self._check(self._L.msw_core_bootstrap(self._h, _ptr(ec_counts), int(seed), int(bootstrap_count),
+                                               int(rep_begin), int(rep_end), _ptr(alpha0), float(tol),
+                                               int(max_iters), int(algo), int(prec), _ptr(theta), _ptr(iters)))
+        return theta, iters
+
+    def resample_counts(self, ec_counts, seed, bootstrap_count, rep_begin, rep_end):
+        ec_counts = _arr(ec_counts, np.uint32)
+        n = int(rep_end) - int(rep_begin)
+        out = np.empty((max(n, 0), len(ec_counts)), np.uint32)
+        self._check(self._L.msw_core_resample_counts(self._h, _ptr(ec_counts), len(ec_counts), int(seed),
+                                                     int(bootstrap_count), int(rep_begin), int(rep_end),
+                                                     _ptr(out)))
+        return out
+
+    # ---- measurement ------------------------------------------------------------------------
+    def set_profiling(self, on):
+        self._check(self._L.msw_core_set_profiling(self._h, int(bool(on))))
+
+    def set_fixed_iters(self, on):
+        self._check(self._L.msw_core_set_fixed_iters(self._h, int(bool(on))))
+
+    def last_timing(self):
+        t = Timing()
+        self._check(self._L.msw_core_last_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timing._fields_}

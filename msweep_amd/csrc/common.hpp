@@ -1,0 +1,79 @@
+// common.hpp -- shared host/device declarations of libmsweep_core (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace msw {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kPassThreads = 1024; // one persistent workgroup per CU for the CSR sweeps
+constexpr int kMaxTrace = 4096;
+
+struct HipError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define MSW_HIP(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      char _b[512];                                                                        \
+      snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+               __FILE__, __LINE__);                                                        \
+      throw ::msw::HipError(_b);                                                           \
+    }                                                                                      \
+  } while (0)
+
+// Simple owning device buffer.
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    if (count <= n && p) return;
+    release();
+    if (count == 0) count = 1;
+    MSW_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+    n = count;
+  }
+  void upload(const T *src, size_t count, hipStream_t s) {
+    alloc(count);
+    if (count) MSW_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void zero(hipStream_t s) {
+    if (p) MSW_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+  }
+};
+
+// Scalar state of one solve; lives in device memory, mirrored to pinned host memory when
+// the host polls.  Kept POD.
+struct Scalars {
+  // gamma = a*L + u - lse ; oldstep = (os_a, os_u) ; step = (step_a, step_u)
+  double a, os_a, step_a;
+  double oldnorm, newnorm, beta;
+  double bound, oldbound, bound_const;
+  double tol, csum;
+  // per-pass shared quantities
+  double M, U, p0, V1c, V2c, W;
+  double logzi;
+  int32_t didreset, reset_pending, done, iter;
+  int32_t max_iters, fixed_iters, trace_theta, flavor;  // flavor: 0 csr, 1 dense
+  int32_t n_flagged;  // rows whose background term cancelled badly (diagnostic)
+  int32_t pad;
+};
+
+}  // namespace msw

@@ -1,0 +1,539 @@
+// msweep_core.hip -- host side of libmsweep_core.so: the C ABI declared in
+// include/msweep_core.h over the gfx950 kernels in kernels.hpp.
+//
+// No CPU fallback exists in this library: every numeric step of the hot path (likelihood
+// expansion, RCG / EM sweeps, column reductions, ELBO, bootstrap resampling) is a HIP
+// kernel; the host only validates shapes, lays out buffers and enqueues launches.
+#include "../../include/msweep_core.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.hpp"
+#include "likelihood_kernels.hpp"
+#include "bootstrap_kernels.hpp"
+#include "em_kernels.hpp"
+
+using namespace msw;
+
+namespace {
+thread_local std::string g_create_error;
+constexpr size_t kLdsMax = 160 * 1024;
+constexpr int kIterBatch = 8;
+constexpr double kInitBound = -100000.0;  // rcgpar: `long double bound = -100000.0`
+}  // namespace
+
+struct msw_core {
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ---- resident likelihood -----------------------------------------------------------
+  int flavor = -1;  // -1 none, 0 CSR-of-ECs, 1 dense
+  uint32_t G = 0, E = 0, n_lut = 0, ntiles = 0;
+  uint64_t nnz = 0;
+  bool wide = false, glds = true, tlds = true;
+  double logzi = 0.0;
+  DevBuf<uint32_t> rowptr, rec, tile_row;
+  DevBuf<double> lut, Lt;
+  int nblk = 0;      // persistent workgroups of the CSR sweeps
+  int nblk_dense = 0;
+  int nreg = 0;
+
+  // ---- solve state ---------------------------------------------------------------------
+  DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, wc, e, N, Nc, Acc, tabA, tabB;
+  DevBuf<double> partA, partS, partAcc, partC;
+  DevBuf<Scalars> sc;
+  Scalars *sc_host = nullptr;  // pinned
+  DevBuf<double> tr_bound, tr_newnorm, tr_beta, tr_theta;
+  DevBuf<int32_t> tr_reset;
+  size_t trace_theta = 0;
+  bool have_solution = false;
+  int last_algo = MSW_ALGO_RCG;
+  // EM state
+  DevBuf<double> logth;
+
+  // ---- bootstrap -------------------------------------------------------------------------
+  DevBuf<double> cp;
+  DevBuf<uint64_t> mtwords;
+  DevBuf<uint32_t> bcounts;
+
+  // ---- measurement ---------------------------------------------------------------------------
+  bool profiling = false, fixed_iters = false;
+  msw_timing timing = {};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evA, evB;
+  size_t evA_used = 0, evB_used = 0;
+
+  ~msw_core() {
+    if (sc_host) (void)hipHostFree(sc_host);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    for (auto &p : evA) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : evB) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+struct Fail : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+template <class F>
+int guarded(msw_handle h, F &&f) {
+  if (!h) return 1;
+  try {
+    MSW_HIP(hipSetDevice(h->device));
+    f();
+    return 0;
+  } catch (const std::exception &ex) {
+    h->err = ex.what();
+    (void)hipGetLastError();
+    return 1;
+  }
+}
+
+std::pair<hipEvent_t, hipEvent_t> &next_pair(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v,
+                                             size_t &used) {
+  if (used == v.size()) {
+    hipEvent_t a, b;
+    MSW_HIP(hipEventCreate(&a));
+    MSW_HIP(hipEventCreate(&b));
+    v.emplace_back(a, b);
+  }
+  return v[used++];
+}
+
+CsrDev csr_view(msw_core *h) {
+  CsrDev S;
+  S.rowptr = h->rowptr.p;
+  S.rec = h->rec.p;
+  S.tile_row = h->tile_row.p;
+  S.cvec = h->cvec.p;
+  S.ntiles = h->ntiles;
+  S.n_ecs = h->E;
+  S.n_groups = h->G;
+  S.n_lut = h->n_lut;
+  return S;
+}
+
+void choose_lds_mode(msw_core *h) {
+  const bool opts[4][2] = {{true, true}, {true, false}, {false, true}, {false, false}};
+  for (auto &o : opts) {
+    const size_t a = pass_lds_bytes(h->wide, o[0], o[1], h->G, h->n_lut, 3);
+    const size_t b = pass_lds_bytes(h->wide, o[0], o[1], h->G, h->n_lut, 2);
+    if (std::max(a, b) <= kLdsMax) {
+      h->glds = o[0];
+      h->tlds = o[1];
+      return;
+    }
+  }
+  throw Fail("internal: no LDS configuration fits");
+}
+
+void alloc_solve_state(msw_core *h) {
+  const uint32_t G = h->G, E = h->E;
+  for (DevBuf<double> *b : {&h->alpha0, &h->u, &h->os_u, &h->step_u, &h->w, &h->wc, &h->e, &h->N,
+                            &h->Nc, &h->Acc, &h->logth})
+    b->alloc(G);
+  h->cvec.alloc(E);
+  h->logc_d.alloc(E);
+  h->tabA.alloc(3 * (size_t)std::max<uint32_t>(h->n_lut, 1));
+  h->tabB.alloc(2 * (size_t)std::max<uint32_t>(h->n_lut, 1));
+  const int nb = std::max(h->nblk, h->nblk_dense);
+  h->partA.alloc(std::max(nb, 1024));
+  h->partS.alloc(4 * (size_t)std::max(nb, 1024));
+  h->partAcc.alloc((size_t)std::max(nb, 1) * G);
+  h->partC.alloc(1024);
+  h->sc.alloc(1);
+  h->tr_bound.alloc(kMaxTrace);
+  h->tr_newnorm.alloc(kMaxTrace);
+  h->tr_beta.alloc(kMaxTrace);
+  h->tr_reset.alloc(kMaxTrace);
+  if (!h->sc_host) MSW_HIP(hipHostMalloc((void **)&h->sc_host, sizeof(Scalars)));
+  if (!h->ev0) {
+    MSW_HIP(hipEventCreate(&h->ev0));
+    MSW_HIP(hipEventCreate(&h->ev1));
+  }
+}
+
+// ---- launch helpers for the templated sweeps ----------------------------------------------
+template <bool W, bool GL, bool TL>
+void launch_passA_t(msw_core *h) {
+  const size_t lds = pass_lds_bytes(W, GL, TL, h->G, h->n_lut, 3);
+  auto k = k_passA<W, GL, TL>;
+  MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, csr_view(h),
+                     h->e.p, h->wc.p, h->tabA.p, h->partA.p);
+}
+template <bool W, bool GL, bool TL>
+void launch_passB_t(msw_core *h, int cond) {
+  const size_t lds = pass_lds_bytes(W, GL, TL, h->G, h->n_lut, 2);
+  auto k = k_passB<W, GL, TL>;
+  MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, cond,
+                     csr_view(h), h->e.p, h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p);
+}
+
+#define MSW_DISPATCH3(fn, ...)                                                       \
+  do {                                                                               \
+    const int key = (h->wide ? 4 : 0) | (h->glds ? 2 : 0) | (h->tlds ? 1 : 0);       \
+    switch (key) {                                                                   \
+      case 0: fn<false, false, false>(__VA_ARGS__); break;                           \
+      case 1: fn<false, false, true>(__VA_ARGS__); break;                            \
+      case 2: fn<false, true, false>(__VA_ARGS__); break;                            \
+      case 3: fn<false, true, true>(__VA_ARGS__); break;                             \
+      case 4: fn<true, false, false>(__VA_ARGS__); break;                            \
+      case 5: fn<true, false, true>(__VA_ARGS__); break;                             \
+      case 6: fn<true, true, false>(__VA_ARGS__); break;                             \
+      default: fn<true, true, true>(__VA_ARGS__); break;                             \
+    }                                                                                \
+  } while (0)
+
+template <int NREG>
+void launch_dense_A(msw_core *h) {
+  hipLaunchKernelGGL(k_dense_passA<NREG>, dim3(h->nblk_dense), dim3(256), 0, h->stream, h->sc.p,
+                     h->Lt.p, (int)h->G, h->E, h->u.p, h->w.p, h->partA.p);
+}
+template <int NREG>
+void launch_dense_B(msw_core *h, int cond) {
+  const size_t lds = (32 + 4 * (size_t)h->G) * sizeof(double);
+  hipLaunchKernelGGL(k_dense_passB<NREG>, dim3(h->nblk_dense), dim3(256), lds, h->stream, h->sc.p,
+                     cond, h->Lt.p, (int)h->G, h->E, h->cvec.p, h->u.p, h->partAcc.p, h->partS.p);
+}
+#define MSW_DISPATCH_NREG(fn, ...)                       \
+  do {                                                   \
+    switch (h->nreg) {                                   \
+      case 1: fn<1>(__VA_ARGS__); break;                 \
+      case 2: fn<2>(__VA_ARGS__); break;                 \
+      case 4: fn<4>(__VA_ARGS__); break;                 \
+      case 8: fn<8>(__VA_ARGS__); break;                 \
+      default: fn<16>(__VA_ARGS__); break;               \
+    }                                                    \
+  } while (0)
+
+void launch_passA(msw_core *h) {
+  std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+  if (h->profiling) {
+    ev = &next_pair(h->evA, h->evA_used);
+    MSW_HIP(hipEventRecord(ev->first, h->stream));
+  }
+  if (h->flavor == 0) MSW_DISPATCH3(launch_passA_t, h);
+  else MSW_DISPATCH_NREG(launch_dense_A, h);
+  MSW_HIP(hipGetLastError());
+  if (ev) MSW_HIP(hipEventRecord(ev->second, h->stream));
+  h->timing.passA_launches++;
+}
+
+void launch_passB(msw_core *h, int cond) {
+  std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+  if (h->profiling && !cond) {
+    ev = &next_pair(h->evB, h->evB_used);
+    MSW_HIP(hipEventRecord(ev->first, h->stream));
+  }
+  if (h->flavor == 0) {
+    if (!h->glds) MSW_HIP(hipMemsetAsync(h->Acc.p, 0, h->G * sizeof(double), h->stream));
+    MSW_DISPATCH3(launch_passB_t, h, cond);
+  } else {
+    MSW_DISPATCH_NREG(launch_dense_B, h, cond);
+  }
+  MSW_HIP(hipGetLastError());
+  if (ev) MSW_HIP(hipEventRecord(ev->second, h->stream));
+  if (!cond) h->timing.passB_launches++;
+  // column sums across workgroups
+  const bool need_red = (h->flavor == 1) || h->glds;
+  if (need_red) {
+    const int nb = h->flavor == 0 ? h->nblk : h->nblk_dense;
+    hipLaunchKernelGGL(k_redB, dim3((h->G + 255) / 256), dim3(256), 0, h->stream, h->sc.p, cond,
+                       (int)h->G, nb, h->partAcc.p, h->Acc.p);
+  }
+}
+
+void launch_finB(msw_core *h, int mode) {
+  TraceDev tr{h->tr_bound.p, h->tr_newnorm.p, h->tr_beta.p, h->tr_theta.p, h->tr_reset.p};
+  const int nb = h->flavor == 0 ? h->nblk : h->nblk_dense;
+  hipLaunchKernelGGL(k_finB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G,
+                     (int)h->n_lut, nb, h->partS.p, h->Acc.p, h->alpha0.p, h->u.p, h->os_u.p,
+                     h->step_u.p, h->lut.p, h->e.p, h->tabB.p, h->Nc.p, h->N.p, tr);
+}
+
+void poll(msw_core *h) {
+  MSW_HIP(hipMemcpyAsync(h->sc_host, h->sc.p, sizeof(Scalars), hipMemcpyDeviceToHost, h->stream));
+  MSW_HIP(hipStreamSynchronize(h->stream));
+}
+
+// cvec / csum / initial state.  counts_dev != null: bootstrap replicate counts (uint32).
+void begin_solve(msw_core *h, const double *logc_host, const uint32_t *counts_dev,
+                 const double *alpha0_host, double tol, size_t max_iters) {
+  if (h->flavor < 0) throw Fail("no likelihood resident: call msw_core_set_csr / set_dense_logl first");
+  if (max_iters == 0 || max_iters > (size_t)std::numeric_limits<int32_t>::max())
+    throw Fail("max_iters out of range");
+  const uint32_t E = h->E, G = h->G;
+  const int nb = 512;
+  if (counts_dev) {
+    hipLaunchKernelGGL(k_cvec_from_counts, dim3(nb), dim3(256), 0, h->stream, counts_dev, E,
+                       h->cvec.p, h->partC.p);
+  } else {
+    MSW_HIP(hipMemcpyAsync(h->logc_d.p, logc_host, E * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_cvec_from_logc, dim3(nb), dim3(256), 0, h->stream, h->logc_d.p, E,
+                       h->cvec.p, h->partC.p);
+  }
+  if (alpha0_host)
+    MSW_HIP(hipMemcpyAsync(h->alpha0.p, alpha0_host, G * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->trace_theta) h->tr_theta.alloc(h->trace_theta * G);
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1024), 0, h->stream, h->sc.p, (int)G, nb,
+                     h->partC.p, h->alpha0.p, h->u.p, h->os_u.p, h->step_u.p, tol, (int)max_iters,
+                     h->fixed_iters ? 1 : 0, (int)h->trace_theta, h->flavor, h->logzi, kInitBound);
+  MSW_HIP(hipGetLastError());
+}
+
+void run_rcg(msw_core *h, size_t max_iters) {
+  const int G = (int)h->G, n_lut = (int)h->n_lut;
+  // initial update_N_k on gamma = log(1/G)
+  hipLaunchKernelGGL(k_prepB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->u.p, h->lut.p,
+                     h->e.p, h->tabB.p);
+  launch_passB(h, 0);
+  h->timing.passB_launches--;  // the initial evaluation is not an iteration
+  if (h->profiling && h->evB_used) h->evB_used--;
+  launch_finB(h, 2);
+  size_t enq = 0;
+  const int nbA = h->flavor == 0 ? h->nblk : h->nblk_dense;
+  while (enq < max_iters) {
+    const size_t batch = std::min<size_t>(kIterBatch, max_iters - enq);
+    for (size_t b = 0; b < batch; ++b) {
+      hipLaunchKernelGGL(k_prepA, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->N.p,
+                         h->u.p, h->lut.p, h->w.p, h->e.p, h->wc.p, h->tabA.p);
+      launch_passA(h);
+      hipLaunchKernelGGL(k_step, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, nbA,
+                         h->partA.p, h->w.p, h->u.p, h->os_u.p, h->step_u.p, h->lut.p, h->e.p,
+                         h->tabB.p);
+      launch_passB(h, 0);
+      launch_finB(h, 0);
+      launch_passB(h, 1);
+      launch_finB(h, 1);
+    }
+    MSW_HIP(hipGetLastError());
+    enq += batch;
+    poll(h);
+    if (h->sc_host->done) break;
+  }
+}
+
+void finish_solve(msw_core *h, double *theta_out, size_t *iters_out, double *bound_out) {
+  poll(h);
+  const uint32_t G = h->G;
+  std::vector<double> nc(G);
+  MSW_HIP(hipMemcpy(nc.data(), h->Nc.p, G * sizeof(double), hipMemcpyDeviceToHost));
+  const double csum = h->sc_host->csum;
+  if (theta_out)
+    for (uint32_t g = 0; g < G; ++g) theta_out[g] = nc[g] / csum;
+  if (iters_out) *iters_out = (size_t)h->sc_host->iter;
+  if (bound_out) *bound_out = h->sc_host->bound;
+  h->have_solution = true;
+}
+
+void collect_timing(msw_core *h) {
+  float ms = 0.f;
+  MSW_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->timing.solve_ms = ms;
+  h->timing.passA_ms = h->timing.passB_ms = 0.0;
+  if (h->profiling) {
+    // launches enqueued after `done` was set return immediately; they are still counted
+    for (size_t i = 0; i < h->evA_used; ++i) {
+      MSW_HIP(hipEventElapsedTime(&ms, h->evA[i].first, h->evA[i].second));
+      h->timing.passA_ms += ms;
+    }
+    for (size_t i = 0; i < h->evB_used; ++i) {
+      MSW_HIP(hipEventElapsedTime(&ms, h->evB[i].first, h->evB[i].second));
+      h->timing.passB_ms += ms;
+    }
+  }
+  h->timing.iters = (uint64_t)h->sc_host->iter;
+  const uint64_t recsz = h->wide ? 8 : 4;
+  if (h->flavor == 0) {
+    h->timing.bytes_passA = h->nnz * recsz + 4ull * (h->E + 1);
+    h->timing.bytes_passB = h->nnz * recsz + 4ull * (h->E + 1) + 8ull * h->E;
+  } else {
+    h->timing.bytes_passA = 8ull * h->E * h->G;
+    h->timing.bytes_passB = 8ull * h->E * h->G + 8ull * h->E;
+  }
+}
+
+void run_em(msw_core *h, size_t max_iters, int prec);
+
+void solve_impl(msw_core *h, const double *logc, const uint32_t *counts_dev, const double *alpha0,
+                double tol, size_t max_iters, int algo, int prec, double *theta_out,
+                size_t *iters_out, double *bound_out) {
+  if (algo != MSW_ALGO_RCG && algo != MSW_ALGO_EM) throw Fail("unknown algorithm id");
+  if (prec != MSW_PREC_DOUBLE && prec != MSW_PREC_FLOAT) throw Fail("unknown precision id");
+  h->timing = {};
+  h->evA_used = h->evB_used = 0;
+  begin_solve(h, logc, counts_dev, alpha0, tol, max_iters);
+  MSW_HIP(hipEventRecord(h->ev0, h->stream));
+  if (algo == MSW_ALGO_RCG) run_rcg(h, max_iters);
+  else run_em(h, max_iters, prec);
+  MSW_HIP(hipEventRecord(h->ev1, h->stream));
+  h->last_algo = algo;
+  finish_solve(h, theta_out, iters_out, bound_out);
+  collect_timing(h);
+}
+
+}  // namespace
+
+#include "host_likelihood.inc"
+#include "host_bootstrap.inc"
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char *msw_core_version(void) { return "msweep_core 0.1 gfx950 (HIP, wave64)"; }
+
+const char *msw_last_error(msw_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int msw_core_create(int device, msw_handle *out) {
+  if (!out) return 1;
+  *out = nullptr;
+  try {
+    int n = 0;
+    MSW_HIP(hipGetDeviceCount(&n));
+    if (n <= 0) throw Fail("no HIP device visible: libmsweep_core has no CPU fallback");
+    if (device < 0 || device >= n) throw Fail("device index out of range");
+    MSW_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MSW_HIP(hipGetDeviceProperties(&prop, device));
+    std::unique_ptr<msw_core> h(new msw_core);
+    h->device = device;
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    MSW_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    *out = h.release();
+    return 0;
+  } catch (const std::exception &ex) {
+    g_create_error = ex.what();
+    (void)hipGetLastError();
+    return 1;
+  }
+}
+
+void msw_core_destroy(msw_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  delete h;
+}
+
+int msw_core_shape(msw_handle h, size_t *n_groups, size_t *n_ecs, size_t *nnz) {
+  return guarded(h, [&] {
+    if (h->flavor < 0) throw Fail("no likelihood resident");
+    if (n_groups) *n_groups = h->G;
+    if (n_ecs) *n_ecs = h->E;
+    if (nnz) *nnz = h->flavor == 0 ? h->nnz : (size_t)h->G * h->E;
+  });
+}
+
+int msw_core_set_dense_logl(msw_handle h, const double *L, size_t n_groups, size_t n_ecs, size_t ld) {
+  return guarded(h, [&] { set_dense_impl(h, L, n_groups, n_ecs, ld); });
+}
+
+int msw_core_set_csr(msw_handle h, const uint64_t *rowptr, const uint32_t *grp, const uint32_t *cnt,
+                     const double *lut, size_t lut_ld, double logzi, size_t n_groups, size_t n_ecs) {
+  return guarded(h, [&] { set_csr_impl(h, rowptr, grp, cnt, lut, lut_ld, logzi, n_groups, n_ecs); });
+}
+
+int msw_core_build_likelihood(msw_handle h, const uint64_t *ec_tptr, const uint32_t *ec_targets,
+                              size_t n_ecs, const uint32_t *target_group, size_t n_targets,
+                              const uint64_t *group_sizes, size_t n_groups, const uint64_t *ec_counts,
+                              double q, double e, double zero_inflation, size_t min_hits,
+                              size_t *n_groups_out, uint8_t *mask_out, double *logc_out) {
+  return guarded(h, [&] {
+    build_likelihood_impl(h, ec_tptr, ec_targets, n_ecs, target_group, n_targets, group_sizes,
+                          n_groups, ec_counts, q, e, zero_inflation, min_hits, n_groups_out, mask_out,
+                          logc_out);
+  });
+}
+
+int msw_core_get_dense_logl(msw_handle h, double *L_out, size_t ld) {
+  return guarded(h, [&] { materialise_impl(h, L_out, ld, /*gamma=*/false); });
+}
+
+int msw_core_gamma(msw_handle h, double *gamma_out, size_t ld) {
+  return guarded(h, [&] {
+    if (!h->have_solution) throw Fail("msw_core_gamma: no solve has run on this handle");
+    materialise_impl(h, gamma_out, ld, /*gamma=*/true);
+  });
+}
+
+int msw_core_solve(msw_handle h, const double *logc, const double *alpha0, double tol, size_t max_iters,
+                   int algo, int prec, double *theta_out, size_t *iters_out, double *bound_out) {
+  return guarded(h, [&] {
+    if (!logc || !alpha0) throw Fail("msw_core_solve: null logc / alpha0");
+    solve_impl(h, logc, nullptr, alpha0, tol, max_iters, algo, prec, theta_out, iters_out, bound_out);
+  });
+}
+
+int msw_core_set_trace_theta(msw_handle h, size_t n_iters) {
+  return guarded(h, [&] {
+    if (n_iters > (size_t)kMaxTrace) throw Fail("trace_theta: at most 4096 iterations");
+    h->trace_theta = n_iters;
+  });
+}
+
+int msw_core_trace(msw_handle h, size_t n, double *bound, double *newnorm, double *beta,
+                   int32_t *didreset, double *theta_trace, size_t *n_out) {
+  return guarded(h, [&] {
+    if (!h->have_solution) throw Fail("msw_core_trace: no solve has run on this handle");
+    size_t have = std::min<size_t>((size_t)h->sc_host->iter, kMaxTrace);
+    n = std::min(n, have);
+    if (bound) MSW_HIP(hipMemcpy(bound, h->tr_bound.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (newnorm) MSW_HIP(hipMemcpy(newnorm, h->tr_newnorm.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (beta) MSW_HIP(hipMemcpy(beta, h->tr_beta.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (didreset) MSW_HIP(hipMemcpy(didreset, h->tr_reset.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (theta_trace) {
+      const size_t nt = std::min(n, h->trace_theta);
+      if (nt) MSW_HIP(hipMemcpy(theta_trace, h->tr_theta.p, nt * h->G * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (n_out) *n_out = n;
+  });
+}
+
+int msw_core_bootstrap(msw_handle h, const uint32_t *ec_counts, int32_t seed, size_t bootstrap_count,
+                       size_t rep_begin, size_t rep_end, const double *alpha0, double tol,
+                       size_t max_iters, int algo, int prec, double *theta_out, size_t *iters_out) {
+  return guarded(h, [&] {
+    bootstrap_impl(h, ec_counts, seed, bootstrap_count, rep_begin, rep_end, alpha0, tol, max_iters,
+                   algo, prec, theta_out, iters_out);
+  });
+}
+
+int msw_core_resample_counts(msw_handle h, const uint32_t *ec_counts, size_t n_ecs, int32_t seed,
+                             size_t bootstrap_count, size_t rep_begin, size_t rep_end,
+                             uint32_t *counts_out) {
+  return guarded(h, [&] {
+    resample_impl(h, ec_counts, n_ecs, seed, bootstrap_count, rep_begin, rep_end, counts_out);
+  });
+}
+
+int msw_core_set_profiling(msw_handle h, int enabled) {
+  return guarded(h, [&] { h->profiling = enabled != 0; });
+}
+int msw_core_set_fixed_iters(msw_handle h, int enabled) {
+  return guarded(h, [&] { h->fixed_iters = enabled != 0; });
+}
+int msw_core_last_timing(msw_handle h, msw_timing *out) {
+  return guarded(h, [&] {
+    if (!out) throw Fail("null out");
+    *out = h->timing;
+  });
+}
+
+}  // extern "C"

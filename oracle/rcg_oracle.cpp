@@ -1,0 +1,609 @@
+// rcg_oracle.cpp -- CPU ORACLE (test infrastructure, see msweep_oracle.h header note).
+//
+// Restates the optimiser behind mSWEEP's `--algorithm` (reference call sites
+// src/mSWEEP.cpp:176-205, 419-423, 496-518).  The loops themselves live in rcgpar v1.2.1
+// (CMakeLists.txt:274-311), which is NOT in /root/reference: "parity unpinned" for this
+// file.  The restatement follows rcgpar's published src/rcg.cpp structure
+// (mixt_negnatgrad / logsumexp / update_N_k / ELBO_rcg_mat / revert_step).
+#include "msweep_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+extern "C" {
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+void orc_default_opts(orc_rcg_opts *o) {
+  o->init_bound = -100000.0;
+  o->weight_newnorm = 0;
+  o->max_trace = 0;
+}
+
+// src/Sample.cpp:87-97 (rcgpar carries the same series)
+double orc_digamma(double x) {
+  double result = 0, xx, xx2, xx4;
+  for (; x < 7; ++x) result -= 1 / x;
+  x -= 1.0 / 2.0;
+  xx = 1.0 / x;
+  xx2 = xx * xx;
+  xx4 = xx2 * xx2;
+  result += std::log(x) + (1. / 24.) * xx2 - (7.0 / 960.0) * xx4 +
+            (31.0 / 8064.0) * xx4 * xx2 - (127.0 / 30720.0) * xx4 * xx4;
+  return result;
+}
+
+}  // extern "C"
+
+namespace {
+
+inline double bound_const_of(const double *logc, size_t E, const double *alpha0, size_t G) {
+  // rcgpar calc_bound_const: lgamma(sum alpha0) - lgamma(sum alpha0 + sum counts) - sum lgamma(alpha0)
+  double counts_sum = 0.0;
+  for (size_t j = 0; j < E; ++j) counts_sum += std::exp(logc[j]);
+  double a_sum = 0.0, lg_sum = 0.0;
+  for (size_t g = 0; g < G; ++g) {
+    a_sum += alpha0[g];
+    lg_sum += std::lgamma(alpha0[g]);
+  }
+  return std::lgamma(a_sum) - std::lgamma(a_sum + counts_sum) - lg_sum;
+}
+
+// ---- dense-state pieces, rows = groups ---------------------------------------------
+struct Dense {
+  size_t G, E;
+  const double *L;
+  const double *logc;
+  const double *alpha0;
+
+  // rcgpar logsumexp(gamma_Z, m): m_j = logsumexp over groups; gamma -= m
+  void logsumexp(double *gamma, double *m) const {
+#pragma omp parallel for schedule(static)
+    for (size_t j = 0; j < E; ++j) {
+      double mx = -std::numeric_limits<double>::infinity();
+      for (size_t g = 0; g < G; ++g) mx = std::max(mx, gamma[g * E + j]);
+      double s = 0.0;
+      for (size_t g = 0; g < G; ++g) s += std::exp(gamma[g * E + j] - mx);
+      m[j] = mx + std::log(s);
+    }
+    for (size_t g = 0; g < G; ++g) {
+#pragma omp parallel for schedule(static)
+      for (size_t j = 0; j < E; ++j) gamma[g * E + j] -= m[j];
+    }
+  }
+
+  // rcgpar mixt_negnatgrad: fills step (dL_dphi) and returns newnorm
+  double negnatgrad(const double *gamma, const double *N, double *step, int weighted) const {
+    std::vector<double> colsums(E, 0.0);
+    for (size_t g = 0; g < G; ++g) {
+      const double dg = orc_digamma(N[g]) - 1.0;
+#pragma omp parallel for schedule(static)
+      for (size_t j = 0; j < E; ++j) {
+        double s = L[g * E + j];
+        s += dg - gamma[g * E + j];
+        step[g * E + j] = s;
+        colsums[j] += s * std::exp(gamma[g * E + j]);
+      }
+    }
+    double newnorm = 0.0;
+    for (size_t g = 0; g < G; ++g) {
+#pragma omp parallel for schedule(static) reduction(+ : newnorm)
+      for (size_t j = 0; j < E; ++j) {
+        double t = std::exp(gamma[g * E + j]) * (step[g * E + j] - colsums[j]) * step[g * E + j];
+        if (weighted) t *= std::exp(logc[j]);
+        newnorm += t;
+      }
+    }
+    return newnorm;
+  }
+
+  void update_N(const double *gamma, double *N) const {
+    for (size_t g = 0; g < G; ++g) {
+      double acc = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+      for (size_t j = 0; j < E; ++j) acc += std::exp(gamma[g * E + j] + logc[j]);
+      N[g] = acc + alpha0[g];
+    }
+  }
+
+  long double elbo(const double *gamma, const double *N, long double bound_const) const {
+    long double bound = bound_const;
+    for (size_t g = 0; g < G; ++g) {
+      long double acc = 0.0L;
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+      for (size_t j = 0; j < E; ++j) {
+        const double gz = gamma[g * E + j];
+        const double w = std::exp(gz + logc[j]);
+        // 0 * (finite) = 0 for zero-count ECs (logc = -inf in bootstrap replicates)
+        acc += (w == 0.0) ? 0.0 : w * (L[g * E + j] - gz);
+      }
+      bound += acc;
+      bound += std::lgamma(N[g]);
+    }
+    return bound;
+  }
+};
+
+inline void record(orc_rcg_trace *tr, const orc_rcg_opts *o, size_t k, double bound,
+                   double newnorm, double beta, bool didreset, const double *N,
+                   const double *alpha0, size_t G, double csum) {
+  if (!tr || !o || (int)k >= o->max_trace) return;
+  if (tr->bound) tr->bound[k] = bound;
+  if (tr->newnorm) tr->newnorm[k] = newnorm;
+  if (tr->beta) tr->beta[k] = beta;
+  if (tr->didreset) tr->didreset[k] = didreset ? 1 : 0;
+  if (tr->theta)
+    for (size_t g = 0; g < G; ++g) tr->theta[k * G + g] = (N[g] - alpha0[g]) / csum;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t orc_rcg_optl_dense(const double *logl, size_t G, size_t E, const double *logc,
+                          const double *alpha0, double tol, size_t max_iters,
+                          const orc_rcg_opts *opts_in, double *gamma, double *bound_out,
+                          orc_rcg_trace *trace) {
+  orc_rcg_opts opts;
+  if (opts_in) opts = *opts_in; else orc_default_opts(&opts);
+  Dense D{G, E, logl, logc, alpha0};
+  const size_t n = G * E;
+  // rcg_optl_omp: gamma_Z(n_groups, n_obs, log(1/n_groups))
+  const double init = std::log(1.0 / (double)G);
+  for (size_t i = 0; i < n; ++i) gamma[i] = init;
+  std::vector<double> step(n, 0.0), oldstep(n, 0.0), oldm(E, 0.0), N(G, 0.0);
+  const long double bound_const = bound_const_of(logc, E, alpha0, G);
+  double csum = 0.0;
+  for (size_t j = 0; j < E; ++j) csum += std::exp(logc[j]);
+
+  double oldnorm = 1.0;
+  long double bound = opts.init_bound;
+  bool didreset = false;
+  D.update_N(gamma, N.data());
+
+  size_t k = 0;
+  for (; k < max_iters; ++k) {
+    const double newnorm = D.negnatgrad(gamma, N.data(), step.data(), opts.weight_newnorm);
+    const double beta_FR = newnorm / oldnorm;
+    oldnorm = newnorm;
+
+    if (didreset) {
+#pragma omp parallel for schedule(static)
+      for (size_t i = 0; i < n; ++i) oldstep[i] *= 0.0;
+    } else if (beta_FR > 0) {
+#pragma omp parallel for schedule(static)
+      for (size_t i = 0; i < n; ++i) {
+        oldstep[i] *= beta_FR;
+        step[i] += oldstep[i];
+      }
+    }
+    didreset = false;
+
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) gamma[i] += step[i];
+    D.logsumexp(gamma, oldm.data());
+    D.update_N(gamma, N.data());
+
+    const long double oldbound = bound;
+    bound = D.elbo(gamma, N.data(), bound_const);
+
+    if (bound < oldbound) {
+      didreset = true;
+      // revert_step: undo the normalisation, then drop the conjugate part
+      for (size_t g = 0; g < G; ++g) {
+#pragma omp parallel for schedule(static)
+        for (size_t j = 0; j < E; ++j) gamma[g * E + j] += oldm[j];
+      }
+      if (beta_FR > 0) {
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n; ++i) gamma[i] -= oldstep[i];
+      }
+      D.logsumexp(gamma, oldm.data());
+      D.update_N(gamma, N.data());
+      bound = D.elbo(gamma, N.data(), bound_const);
+    } else {
+      std::memcpy(oldstep.data(), step.data(), n * sizeof(double));
+    }
+    record(trace, &opts, k, (double)bound, newnorm, beta_FR, didreset, N.data(), alpha0, G, csum);
+    if (bound - oldbound < tol && !didreset) {
+      D.logsumexp(gamma, oldm.data());
+      ++k;
+      break;
+    }
+  }
+  if (bound_out) *bound_out = (double)bound;
+  return k;
+}
+
+void orc_mixture_components(const double *gamma, size_t G, size_t E, const double *logc,
+                            double *theta) {
+  double total = 0.0;
+  for (size_t j = 0; j < E; ++j) total += std::exp(logc[j]);
+  for (size_t g = 0; g < G; ++g) {
+    double acc = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+    for (size_t j = 0; j < E; ++j) acc += std::exp(gamma[g * E + j] + logc[j]);
+    theta[g] = acc / total;
+  }
+}
+
+}  // extern "C"
+
+// =====================================================================================
+// Structured restatement: gamma_gj = a*L_gj + u_g - lse_j  (SURVEY.md 7.3).
+// The per-EC shift v_j of step/oldstep never influences gamma after renormalisation nor
+// newnorm (a per-column variance), so the state is (a,u) for gamma and (a,u) for oldstep.
+// This is the formulation the HIP kernels implement; kept element-for-element the same.
+// =====================================================================================
+namespace {
+
+struct StructState {
+  double a = 0.0;
+  std::vector<double> u;
+};
+
+// Abstract "L" access for the two structured variants.
+struct PassOut {
+  double newnorm = 0.0;          // A pass
+  long double bound_terms = 0.0; // B pass: sum_j c_j*log Z_j + (1-a) sum_j r_j H_j
+  double W = 0.0;                // B pass: sum_j r_j
+};
+
+struct CsrL {
+  const uint64_t *rowptr;
+  const uint32_t *grp;
+  const uint32_t *lutidx;
+  const double *lut;
+  size_t n_lut;
+  double logzi;
+  size_t G, E;
+};
+
+// B pass on CSR: returns Nc_g (without alpha) and the bound's data terms.
+void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double *Nc,
+                long double *bound_data, double *lse_out /*E or null*/) {
+  const size_t G = S.G, E = S.E;
+  double M = -std::numeric_limits<double>::infinity();
+  for (size_t g = 0; g < G; ++g) M = std::max(M, st.u[g]);
+  std::vector<double> e(G);
+  double U = 0.0;
+  for (size_t g = 0; g < G; ++g) { e[g] = std::exp(st.u[g] - M); U += e[g]; }
+  const double a = st.a;
+  const double p0 = std::exp(a * S.logzi);
+  std::vector<double> xm(S.n_lut), xTm(S.n_lut);
+  for (size_t i = 0; i < S.n_lut; ++i) {
+    const double x = std::exp(a * S.lut[i]);
+    xm[i] = x - p0;
+    xTm[i] = x * S.lut[i] - p0 * S.logzi;
+  }
+  std::vector<double> A(G, 0.0);
+  long double sum_clogZ = 0.0L, sum_rH = 0.0L;
+  double W = 0.0;
+  const double zbase = p0 * U, hbase = p0 * S.logzi * U;
+  for (size_t j = 0; j < E; ++j) {
+    double zs = 0.0, hs = 0.0;
+    for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
+      const double eg = e[S.grp[k]];
+      zs += eg * xm[S.lutidx[k]];
+      hs += eg * xTm[S.lutidx[k]];
+    }
+    const double Z = zbase + zs;
+    const double H = hbase + hs;
+    const double c = cvec[j];
+    const double r = c / Z;
+    if (lse_out) lse_out[j] = M + std::log(Z);
+    if (c != 0.0) {
+      sum_clogZ += (long double)c * std::log(Z);
+      sum_rH += (long double)r * H;
+    }
+    W += r;
+    for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) A[S.grp[k]] += r * xm[S.lutidx[k]];
+  }
+  long double mu = 0.0L;
+  for (size_t g = 0; g < G; ++g) {
+    Nc[g] = e[g] * (p0 * W + A[g]);
+    mu += (long double)(M - st.u[g]) * Nc[g];
+  }
+  *bound_data = sum_clogZ + (long double)(1.0 - a) * sum_rH + mu;
+}
+
+double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
+  const size_t G = S.G, E = S.E;
+  double M = -std::numeric_limits<double>::infinity();
+  for (size_t g = 0; g < G; ++g) M = std::max(M, st.u[g]);
+  const double a = st.a, oma = 1.0 - a;
+  const double p0 = std::exp(a * S.logzi);
+  std::vector<double> e(G), s0(G);
+  double U = 0.0, V1 = 0.0;
+  for (size_t g = 0; g < G; ++g) {
+    e[g] = std::exp(st.u[g] - M);
+    s0[g] = oma * S.logzi + w[g];
+    U += e[g];
+    V1 += e[g] * s0[g];
+  }
+  // centre the step values (a per-column shift leaves the variance unchanged)
+  const double kappa = V1 / U;
+  double V1c = 0.0, V2c = 0.0;
+  std::vector<double> wc(G);
+  for (size_t g = 0; g < G; ++g) {
+    wc[g] = w[g] - kappa;           // s = oma*T + wc_g ; s0c = oma*logzi + wc_g
+    const double s0c = oma * S.logzi + wc[g];
+    V1c += e[g] * s0c;
+    V2c += e[g] * s0c * s0c;
+  }
+  std::vector<double> xm(S.n_lut), A1(S.n_lut), A2(S.n_lut);
+  for (size_t i = 0; i < S.n_lut; ++i) {
+    const double T = S.lut[i];
+    const double x = std::exp(a * T);
+    xm[i] = x - p0;
+    A1[i] = oma * (x * T - p0 * S.logzi);
+    A2[i] = oma * oma * (x * T * T - p0 * S.logzi * S.logzi);
+  }
+  const double zbase = p0 * U, b1 = p0 * V1c, b2 = p0 * V2c;
+  long double newnorm = 0.0L;
+  for (size_t j = 0; j < E; ++j) {
+    double zs = 0.0, t1 = 0.0, t2 = 0.0;
+    for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
+      const uint32_t g = S.grp[k], i = S.lutidx[k];
+      const double eg = e[g], wg = wc[g];
+      const double wx = wg * xm[i];
+      zs += eg * xm[i];
+      t1 += eg * (A1[i] + wx);
+      t2 += eg * (A2[i] + wg * (2.0 * A1[i] + wx));
+    }
+    const double iZ = 1.0 / (zbase + zs);
+    const double S1 = (b1 + t1) * iZ;
+    const double S2 = (b2 + t2) * iZ;
+    newnorm += (long double)(S2 - S1 * S1);
+  }
+  return (double)newnorm;
+}
+
+// dense-L structured passes (rows = groups, G x E)
+void dense_pass_B(const double *L, size_t G, size_t E, const StructState &st,
+                  const double *cvec, double *Nc, long double *bound_data) {
+  std::vector<double> Acc(G, 0.0);
+  long double bd = 0.0L;
+  std::vector<double> y(G), p(G);
+  for (size_t j = 0; j < E; ++j) {
+    double m = -std::numeric_limits<double>::infinity();
+    for (size_t g = 0; g < G; ++g) { y[g] = st.a * L[g * E + j] + st.u[g]; m = std::max(m, y[g]); }
+    double Z = 0.0, hs = 0.0;
+    for (size_t g = 0; g < G; ++g) {
+      p[g] = std::exp(y[g] - m);
+      Z += p[g];
+      hs += p[g] * (L[g * E + j] - (y[g] - m));
+    }
+    const double c = cvec[j];
+    const double r = c / Z;
+    if (c != 0.0) bd += (long double)c * std::log(Z) + (long double)r * hs;
+    for (size_t g = 0; g < G; ++g) Acc[g] += r * p[g];
+  }
+  for (size_t g = 0; g < G; ++g) Nc[g] = Acc[g];
+  *bound_data = bd;
+}
+
+double dense_pass_A(const double *L, size_t G, size_t E, const StructState &st, const double *w) {
+  long double nn = 0.0L;
+  const double oma = 1.0 - st.a;
+  std::vector<double> p(G), s(G);
+  for (size_t j = 0; j < E; ++j) {
+    double m = -std::numeric_limits<double>::infinity();
+    for (size_t g = 0; g < G; ++g) { p[g] = st.a * L[g * E + j] + st.u[g]; m = std::max(m, p[g]); }
+    double Z = 0.0, S1 = 0.0;
+    for (size_t g = 0; g < G; ++g) {
+      p[g] = std::exp(p[g] - m);
+      s[g] = oma * L[g * E + j] + w[g];
+      Z += p[g];
+      S1 += p[g] * s[g];
+    }
+    const double iZ = 1.0 / Z;
+    const double sbar = S1 * iZ;
+    double v = 0.0;
+    for (size_t g = 0; g < G; ++g) { const double d = s[g] - sbar; v += p[g] * d * d; }
+    nn += (long double)(v * iZ);
+  }
+  return (double)nn;
+}
+
+template <class PassA, class PassB>
+size_t structured_loop(size_t G, size_t E, const double *logc, const double *alpha0, double tol,
+                       size_t max_iters, const orc_rcg_opts &opts, PassA passA, PassB passB,
+                       StructState &st, double *theta_out, double *bound_out,
+                       orc_rcg_trace *trace) {
+  std::vector<double> cvec(E);
+  double csum = 0.0;
+  for (size_t j = 0; j < E; ++j) { cvec[j] = std::exp(logc[j]); csum += cvec[j]; }
+  const long double bound_const = bound_const_of(logc, E, alpha0, G);
+
+  st.a = 0.0;
+  st.u.assign(G, 0.0);
+  StructState os;  // oldstep
+  os.a = 0.0;
+  os.u.assign(G, 0.0);
+  std::vector<double> Nc(G), N(G), w(G), step_u(G);
+  double oldnorm = 1.0;
+  long double bound = opts.init_bound;
+  bool didreset = false;
+
+  auto evalB = [&](long double *b) {
+    long double bd;
+    passB(st, cvec.data(), Nc.data(), &bd);
+    long double lg = 0.0L;
+    for (size_t g = 0; g < G; ++g) { N[g] = alpha0[g] + Nc[g]; lg += std::lgamma(N[g]); }
+    if (b) *b = bound_const + bd + lg;
+  };
+  evalB(nullptr);  // update_N_k on the initial gamma
+
+  size_t k = 0;
+  for (; k < max_iters; ++k) {
+    for (size_t g = 0; g < G; ++g) w[g] = (orc_digamma(N[g]) - 1.0) - st.u[g];
+    double step_a = 1.0 - st.a;
+    const double newnorm = passA(st, w.data());
+    const double beta_FR = newnorm / oldnorm;
+    oldnorm = newnorm;
+    for (size_t g = 0; g < G; ++g) step_u[g] = w[g];
+    if (didreset) {
+      os.a *= 0.0;
+      for (size_t g = 0; g < G; ++g) os.u[g] *= 0.0;
+    } else if (beta_FR > 0) {
+      os.a *= beta_FR;
+      step_a += os.a;
+      for (size_t g = 0; g < G; ++g) { os.u[g] *= beta_FR; step_u[g] += os.u[g]; }
+    }
+    didreset = false;
+    st.a += step_a;
+    for (size_t g = 0; g < G; ++g) st.u[g] += step_u[g];
+
+    const long double oldbound = bound;
+    evalB(&bound);
+    if (bound < oldbound) {
+      didreset = true;
+      if (beta_FR > 0) {
+        st.a -= os.a;
+        for (size_t g = 0; g < G; ++g) st.u[g] -= os.u[g];
+      }
+      evalB(&bound);
+    } else {
+      os.a = step_a;
+      os.u = step_u;
+    }
+    record(trace, &opts, k, (double)bound, newnorm, beta_FR, didreset, N.data(), alpha0, G, csum);
+    if (bound - oldbound < tol && !didreset) { ++k; break; }
+  }
+  if (theta_out) for (size_t g = 0; g < G; ++g) theta_out[g] = Nc[g] / csum;
+  if (bound_out) *bound_out = (double)bound;
+  return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t orc_rcg_optl_csr(const uint64_t *rowptr, const uint32_t *grp, const uint32_t *lutidx,
+                        const double *lut, size_t n_lut, double logzi, size_t G, size_t E,
+                        const double *logc, const double *alpha0, double tol,
+                        size_t max_iters, const orc_rcg_opts *opts_in, double *theta_out,
+                        double *gamma_out, double *bound_out, orc_rcg_trace *trace) {
+  orc_rcg_opts opts;
+  if (opts_in) opts = *opts_in; else orc_default_opts(&opts);
+  CsrL S{rowptr, grp, lutidx, lut, n_lut, logzi, G, E};
+  StructState st;
+  auto pA = [&](const StructState &s, const double *w) { return csr_pass_A(S, s, w); };
+  auto pB = [&](const StructState &s, const double *c, double *Nc, long double *bd) {
+    csr_pass_B(S, s, c, Nc, bd, nullptr);
+  };
+  size_t it = structured_loop(G, E, logc, alpha0, tol, max_iters, opts, pA, pB, st, theta_out,
+                              bound_out, trace);
+  if (gamma_out) {
+    std::vector<double> lse(E), cvec(E), Nc(G);
+    for (size_t j = 0; j < E; ++j) cvec[j] = std::exp(logc[j]);
+    long double bd;
+    csr_pass_B(S, st, cvec.data(), Nc.data(), &bd, lse.data());
+    for (size_t g = 0; g < G; ++g)
+      for (size_t j = 0; j < E; ++j) gamma_out[g * E + j] = st.a * logzi + st.u[g] - lse[j];
+    for (size_t j = 0; j < E; ++j)
+      for (uint64_t k = rowptr[j]; k < rowptr[j + 1]; ++k)
+        gamma_out[(size_t)grp[k] * E + j] = st.a * lut[lutidx[k]] + st.u[grp[k]] - lse[j];
+  }
+  return it;
+}
+
+size_t orc_rcg_optl_dense_structured(const double *logl, size_t G, size_t E,
+                                     const double *logc, const double *alpha0, double tol,
+                                     size_t max_iters, const orc_rcg_opts *opts_in,
+                                     double *theta_out, double *gamma_out,
+                                     double *bound_out, orc_rcg_trace *trace) {
+  orc_rcg_opts opts;
+  if (opts_in) opts = *opts_in; else orc_default_opts(&opts);
+  StructState st;
+  auto pA = [&](const StructState &s, const double *w) { return dense_pass_A(logl, G, E, s, w); };
+  auto pB = [&](const StructState &s, const double *c, double *Nc, long double *bd) {
+    dense_pass_B(logl, G, E, s, c, Nc, bd);
+  };
+  size_t it = structured_loop(G, E, logc, alpha0, tol, max_iters, opts, pA, pB, st, theta_out,
+                              bound_out, trace);
+  if (gamma_out) {
+    for (size_t j = 0; j < E; ++j) {
+      double m = -std::numeric_limits<double>::infinity();
+      for (size_t g = 0; g < G; ++g) m = std::max(m, st.a * logl[g * E + j] + st.u[g]);
+      double Z = 0.0;
+      for (size_t g = 0; g < G; ++g) Z += std::exp(st.a * logl[g * E + j] + st.u[g] - m);
+      const double lse = m + std::log(Z);
+      for (size_t g = 0; g < G; ++g) gamma_out[g * E + j] = st.a * logl[g * E + j] + st.u[g] - lse;
+    }
+  }
+  return it;
+}
+
+// rcgpar::em_torch restated [UPSTREAM-UNVERIFIED]: plain EM for the mixture weights with
+// the Dirichlet(alpha0) prior folded in as pseudo-counts (MAP; alpha0 = 1 gives ML).
+//   E: gamma_gj = log theta_g + L_gj - logsumexp_g(.)
+//   M: theta_g  = (sum_j c_j exp(gamma_gj) + alpha0_g - 1) / (sum_j c_j + sum_g (alpha0_g - 1))
+//   stop when the weighted log-likelihood gain drops below tol.
+size_t orc_em_dense(const double *L, size_t G, size_t E, const double *logc,
+                    const double *alpha0, double tol, size_t max_iters, double *gamma_out,
+                    double *theta_out, double *bound_out) {
+  std::vector<double> theta(G, 1.0 / (double)G), logth(G), acc(G), c(E);
+  double csum = 0.0, asum = 0.0;
+  for (size_t j = 0; j < E; ++j) { c[j] = std::exp(logc[j]); csum += c[j]; }
+  for (size_t g = 0; g < G; ++g) asum += alpha0[g] - 1.0;
+  long double ll = -std::numeric_limits<double>::infinity();
+  size_t k = 0;
+  std::vector<double> y(G);
+  for (; k < max_iters; ++k) {
+    for (size_t g = 0; g < G; ++g) { logth[g] = std::log(theta[g]); acc[g] = 0.0; }
+    long double newll = 0.0L;
+    for (size_t j = 0; j < E; ++j) {
+      double m = -std::numeric_limits<double>::infinity();
+      for (size_t g = 0; g < G; ++g) { y[g] = logth[g] + L[g * E + j]; m = std::max(m, y[g]); }
+      double Z = 0.0;
+      for (size_t g = 0; g < G; ++g) { y[g] = std::exp(y[g] - m); Z += y[g]; }
+      if (c[j] != 0.0) newll += (long double)c[j] * (m + std::log(Z));
+      const double r = c[j] / Z;
+      for (size_t g = 0; g < G; ++g) acc[g] += r * y[g];
+    }
+    for (size_t g = 0; g < G; ++g) {
+      double t = (acc[g] + alpha0[g] - 1.0) / (csum + asum);
+      theta[g] = t > 0.0 ? t : 0.0;
+    }
+    const long double gain = newll - ll;
+    ll = newll;
+    if (k > 0 && gain < tol) { ++k; break; }
+  }
+  if (theta_out) for (size_t g = 0; g < G; ++g) theta_out[g] = theta[g];
+  if (bound_out) *bound_out = (double)ll;
+  if (gamma_out) {
+    for (size_t j = 0; j < E; ++j) {
+      double m = -std::numeric_limits<double>::infinity();
+      for (size_t g = 0; g < G; ++g) m = std::max(m, std::log(theta[g]) + L[g * E + j]);
+      double Z = 0.0;
+      for (size_t g = 0; g < G; ++g) Z += std::exp(std::log(theta[g]) + L[g * E + j] - m);
+      const double lse = m + std::log(Z);
+      for (size_t g = 0; g < G; ++g) gamma_out[g * E + j] = std::log(theta[g]) + L[g * E + j] - lse;
+    }
+  }
+  return k;
+}
+
+}  // extern "C"
