@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the abundance-estimation hot path (BASELINE.json).
+
+Workload (config.workload "cfg3"): synthetic 10M reads x 5k groups collapsed to a CSR-of-ECs
+likelihood (seeded generator msweep_amd/synth.py, seed 2), resident in HBM before the timed
+region.  A "step" = ONE RCG iteration of the hot path over the whole likelihood: pass A
+(natural-gradient norm sweep) + pass B (per-EC softmax, column sums N_g, ELBO sweep) + the O(G)
+digamma / Fletcher-Reeves / bound kernels.  `value` = cells of the EC x group likelihood matrix
+the reference would hold (E * G) processed per second, summed over all ranks.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): the path shards over bootstrap
+replicates (src/mSWEEP.cpp:496-518, independent solves on the same likelihood): rank r runs K
+iterations on replicate r's resampled EC counts -- no data-path collective; the per-replicate
+abundances are exchanged with one RCCL all-gather at the end (inside the timed region).
+Scaling is "weak" (per-GPU work fixed).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--groups", type=int, default=5000)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-ecs", type=int, default=50000)
+    ap.add_argument("--cpu-iters", type=int, default=6)
+    return ap.parse_args()
+
+
+def cpu_baseline(prob, lut, n_ecs, iters):
+    """Oracle leg (test infrastructure, the ONLY place bench.py touches oracle/): the dense-state
+    RCG exactly as the reference structures it (rcgpar::rcg_optl_omp restated), timed on the host
+    cores over the first `n_ecs` ECs of the same workload expanded to a dense G x E matrix."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    from oracle import Oracle
+    O = Oracle()
+    G = len(prob["group_sizes"])
+    rp = prob["rowptr"].astype(np.int64)
+    E = min(n_ecs, len(rp) - 1)
+    nz = rp[E]
+    L = np.full((G, E), np.log(0.01))
+    rows = np.repeat(np.arange(E), np.diff(rp[:E + 1]))
+    L[prob["grp"][:nz], rows] = lut[prob["grp"][:nz], prob["cnt"][:nz]]
+    logc = np.log(prob["ec_counts"][:E].astype(float))
+    cores = min(O.num_threads(), os.cpu_count() or 1)
+    O.set_num_threads(cores)
+    O.rcg_optl_dense(L, logc, np.ones(G), tol=0.0, max_iters=1)  # touch pages / warm up
+    t0 = time.perf_counter()
+    r = O.rcg_optl_dense(L, logc, np.ones(G), tol=-1.0, max_iters=iters)
+    dt = time.perf_counter() - t0
+    return {"value": E * G * r["iters"] / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": f"first {E} ECs of the cfg3 workload x {G} groups as a dense fp64 matrix, "
+                      f"{r['iters']} RCG iterations of the dense-state restatement (4 G x E matrices), "
+                      f"{dt:.1f} s; iters/s on the sample = {r['iters'] / dt:.3f}"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if a.gpus != world and world > 1 and rank == 0:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    n_gpus = world
+
+    import numpy as np
+    from msweep_amd import synth
+    from msweep_amd.core import Core
+    from msweep_amd.likelihood import from_grouped_counts, precalc_lls
+
+    t0 = time.time()
+    prob = synth.make_csr_problem(a.reads, a.groups, seed=a.seed)
+    G = a.groups
+    E = len(prob["rowptr"]) - 1
+    nnz = len(prob["grp"])
+    t_gen = time.time() - t0
+
+    core = Core(local_rank)
+    lik = from_grouped_counts(core, prob["rowptr"], prob["grp"], prob["cnt"], prob["ec_counts"],
+                              prob["group_sizes"])
+    alpha0 = np.ones(G)
+    if world > 1:
+        # replicate `rank` of the bootstrap: multinomial resample of the EC counts.  (Synthetic
+        # bench input; the parity-exact mt19937_64 stream is msw_core_resample_counts.)
+        rng = np.random.Generator(np.random.PCG64(1000 + rank))
+        c = prob["ec_counts"].astype(np.float64)
+        counts = rng.multinomial(int(c.sum()), c / c.sum()).astype(np.float64)
+        with np.errstate(divide="ignore"):
+            logc = np.log(counts)
+    else:
+        logc = lik.log_counts()
+    core.set_fixed_iters(True)
+    core.prepare(logc, alpha0)               # inputs resident in HBM before the timed region
+    core.run(max_iters=max(a.warmup, 1))     # W untimed warm-up steps
+    core.set_profiling(True)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        # core.run() returns only after the solve stream has drained (it downloads theta)
+
+    sync()
+    t0 = time.perf_counter()
+    res = core.run(max_iters=a.steps)         # exactly K steps
+    if dist is not None:
+        import torch
+        th = torch.from_numpy(res["theta"]).cuda()
+        out = [torch.empty_like(th) for _ in range(world)]
+        dist.all_gather(out, th)
+        torch.cuda.synchronize()
+    sync()
+    dt = time.perf_counter() - t0
+    tm = core.last_timing()
+    assert tm["iters"] == a.steps, (tm["iters"], a.steps)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64).cuda()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        cells = float(E) * G * a.steps * n_gpus
+        msA = tm["passA_ms"] / max(tm["passA_launches"], 1)
+        msB = tm["passB_ms"] / max(tm["passB_launches"], 1)
+        dom, ms_dom, b_dom = ("k_passB", msB, tm["bytes_passB"]) if msB >= msA else ("k_passA", msA, tm["bytes_passA"])
+        achieved = b_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+        line = {
+            "metric": "EM iters/sec + reads×groups cells/sec, 10M reads × 5k groups",
+            "value": cells / dt, "unit": "cells/s",
+            "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg3: synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB "
+                                   "(--algorithm rcggpu), fixed iteration count",
+                       "reads": a.reads, "groups": G, "ecs": E, "nnz": nnz, "seed": a.seed,
+                       "sharding": "single solve" if n_gpus == 1 else f"bootstrap replicates, 1 per GPU x {n_gpus}"},
+            "iters_per_sec": a.steps * n_gpus / dt,
+            "reads_x_groups_cells_per_sec": float(a.reads) * G * a.steps * n_gpus / dt,
+            "device_ms_per_step": tm["solve_ms"] / a.steps,
+            "kernels": {"k_passA_ms": msA, "k_passB_ms": msB, "passA_launches": tm["passA_launches"],
+                        "passB_launches": tm["passB_launches"]},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_dom, "avg_launch_ms": ms_dom},
+            "setup_s": {"generate": t_gen},
+        }
+        if not a.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(prob, precalc_lls(prob["group_sizes"]), a.cpu_sample_ecs,
+                                                    a.cpu_iters)
+            except Exception as ex:  # the baseline is reporting only
+                line["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {ex}"}
+        print(json.dumps(line), flush=True)
+    core.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,14 @@ int msw_core_solve(msw_handle h, const double *logc, const double *alpha0, doubl
                    size_t max_iters, int algo, int prec, double *theta_out,
                    size_t *iters_out, double *bound_out);
 
+/* The same call split in two for callers that keep the inputs resident (bench.py's timed
+ * region, the bootstrap driver): msw_core_prepare uploads logc / alpha0 and forms the EC
+ * multiplicities on the device; msw_core_run executes the optimiser on the prepared inputs.
+ * msw_core_solve == msw_core_prepare + msw_core_run. */
+int msw_core_prepare(msw_handle h, const double *logc, const double *alpha0);
+int msw_core_run(msw_handle h, double tol, size_t max_iters, int algo, int prec,
+                 double *theta_out, size_t *iters_out, double *bound_out);
+
 /* The G x E log-responsibility matrix gamma of the last solve (the DenseMatrix rcg_optl
  * returns, src/mSWEEP.cpp:195,199,203; consumed by Sample::store_probs / write_probs /
  * mGEMS binning, src/mSWEEP.cpp:402,451,478-487).  Row-major, rows = groups, leading

@@ -19,7 +19,8 @@ PREC_DOUBLE, PREC_FLOAT = 0, 1
 EXPORTS = [
     "msw_core_create", "msw_core_destroy", "msw_last_error", "msw_core_version",
     "msw_core_set_dense_logl", "msw_core_set_csr", "msw_core_build_likelihood",
-    "msw_core_get_dense_logl", "msw_core_shape", "msw_core_solve", "msw_core_gamma",
+    "msw_core_get_dense_logl", "msw_core_shape", "msw_core_solve", "msw_core_prepare", "msw_core_run",
+    "msw_core_gamma",
     "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
     "msw_core_set_fixed_iters",
@@ -62,6 +63,8 @@ def load_library():
     L.msw_core_get_dense_logl.argtypes = [vp, vp, sz]
     L.msw_core_shape.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.msw_core_solve.argtypes = [vp, vp, vp, dp, sz, C.c_int, C.c_int, vp, C.POINTER(sz), C.POINTER(dp)]
+    L.msw_core_prepare.argtypes = [vp, vp, vp]
+    L.msw_core_run.argtypes = [vp, dp, sz, C.c_int, C.c_int, vp, C.POINTER(sz), C.POINTER(dp)]
     L.msw_core_gamma.argtypes = [vp, vp, sz]
     L.msw_core_trace.argtypes = [vp, sz, vp, vp, vp, vp, vp, C.POINTER(sz)]
     L.msw_core_set_trace_theta.argtypes = [vp, sz]
@@ -181,6 +184,22 @@ class Core:
         it, b = C.c_size_t(), C.c_double()
         self._check(self._L.msw_core_solve(self._h, _ptr(logc), _ptr(alpha0), float(tol), int(max_iters),
                                            int(algo), int(prec), _ptr(theta), C.byref(it), C.byref(b)))
+        return dict(theta=theta, iters=it.value, bound=b.value)
+
+    def prepare(self, logc, alpha0):
+        G, E, _ = self.shape()
+        logc = _arr(logc, np.float64)
+        alpha0 = _arr(alpha0, np.float64)
+        if len(logc) != E or len(alpha0) != G:
+            raise MswError(f"prepare: expected logc[{E}] and alpha0[{G}], got {len(logc)} and {len(alpha0)}")
+        self._check(self._L.msw_core_prepare(self._h, _ptr(logc), _ptr(alpha0)))
+
+    def run(self, tol=1e-6, max_iters=5000, algo=ALGO_RCG, prec=PREC_DOUBLE):
+        G, _, _ = self.shape()
+        theta = np.empty(G)
+        it, b = C.c_size_t(), C.c_double()
+        self._check(self._L.msw_core_run(self._h, float(tol), int(max_iters), int(algo), int(prec), _ptr(theta),
+                                         C.byref(it), C.byref(b)))
         return dict(theta=theta, iters=it.value, bound=b.value)
 
     def gamma(self):

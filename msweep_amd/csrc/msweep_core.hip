@@ -56,6 +56,7 @@ struct msw_core {
   DevBuf<int32_t> tr_reset;
   size_t trace_theta = 0;
   bool have_solution = false;
+  bool prepared = false;
   int last_algo = MSW_ALGO_RCG;
   // EM state
   DevBuf<double> logth;
@@ -271,26 +272,36 @@ void poll(msw_core *h) {
   MSW_HIP(hipStreamSynchronize(h->stream));
 }
 
-// cvec / csum / initial state.  counts_dev != null: bootstrap replicate counts (uint32).
-void begin_solve(msw_core *h, const double *logc_host, const uint32_t *counts_dev,
-                 const double *alpha0_host, double tol, size_t max_iters) {
+// Inputs of one solve: c_j (from log counts or from bootstrap counts already on the device) and
+// the prior.  Leaves per-block partial sums of c in partC for k_init_state.
+constexpr int kCvecBlocks = 512;
+void prepare_inputs(msw_core *h, const double *logc_host, const uint32_t *counts_dev,
+                    const double *alpha0_host) {
   if (h->flavor < 0) throw Fail("no likelihood resident: call msw_core_set_csr / set_dense_logl first");
-  if (max_iters == 0 || max_iters > (size_t)std::numeric_limits<int32_t>::max())
-    throw Fail("max_iters out of range");
   const uint32_t E = h->E, G = h->G;
-  const int nb = 512;
   if (counts_dev) {
-    hipLaunchKernelGGL(k_cvec_from_counts, dim3(nb), dim3(256), 0, h->stream, counts_dev, E,
+    hipLaunchKernelGGL(k_cvec_from_counts, dim3(kCvecBlocks), dim3(256), 0, h->stream, counts_dev, E,
                        h->cvec.p, h->partC.p);
   } else {
     MSW_HIP(hipMemcpyAsync(h->logc_d.p, logc_host, E * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_cvec_from_logc, dim3(nb), dim3(256), 0, h->stream, h->logc_d.p, E,
+    hipLaunchKernelGGL(k_cvec_from_logc, dim3(kCvecBlocks), dim3(256), 0, h->stream, h->logc_d.p, E,
                        h->cvec.p, h->partC.p);
   }
   if (alpha0_host)
     MSW_HIP(hipMemcpyAsync(h->alpha0.p, alpha0_host, G * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  MSW_HIP(hipGetLastError());
+  // logc_host / alpha0_host may be pageable caller memory: finish the copies before returning
+  MSW_HIP(hipStreamSynchronize(h->stream));
+  h->prepared = true;
+}
+
+void begin_solve(msw_core *h, double tol, size_t max_iters) {
+  if (!h->prepared) throw Fail("msw_core_run: inputs not prepared (call msw_core_prepare)");
+  if (max_iters == 0 || max_iters > (size_t)std::numeric_limits<int32_t>::max())
+    throw Fail("max_iters out of range");
+  const uint32_t G = h->G;
   if (h->trace_theta) h->tr_theta.alloc(h->trace_theta * G);
-  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1024), 0, h->stream, h->sc.p, (int)G, nb,
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1024), 0, h->stream, h->sc.p, (int)G, kCvecBlocks,
                      h->partC.p, h->alpha0.p, h->u.p, h->os_u.p, h->step_u.p, tol, (int)max_iters,
                      h->fixed_iters ? 1 : 0, (int)h->trace_theta, h->flavor, h->logzi, kInitBound);
   MSW_HIP(hipGetLastError());
@@ -370,14 +381,13 @@ void collect_timing(msw_core *h) {
 
 void run_em(msw_core *h, size_t max_iters, int prec);
 
-void solve_impl(msw_core *h, const double *logc, const uint32_t *counts_dev, const double *alpha0,
-                double tol, size_t max_iters, int algo, int prec, double *theta_out,
-                size_t *iters_out, double *bound_out) {
+void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, double *theta_out,
+              size_t *iters_out, double *bound_out) {
   if (algo != MSW_ALGO_RCG && algo != MSW_ALGO_EM) throw Fail("unknown algorithm id");
   if (prec != MSW_PREC_DOUBLE && prec != MSW_PREC_FLOAT) throw Fail("unknown precision id");
   h->timing = {};
   h->evA_used = h->evB_used = 0;
-  begin_solve(h, logc, counts_dev, alpha0, tol, max_iters);
+  begin_solve(h, tol, max_iters);
   MSW_HIP(hipEventRecord(h->ev0, h->stream));
   if (algo == MSW_ALGO_RCG) run_rcg(h, max_iters);
   else run_em(h, max_iters, prec);
@@ -477,8 +487,21 @@ int msw_core_solve(msw_handle h, const double *logc, const double *alpha0, doubl
                    int algo, int prec, double *theta_out, size_t *iters_out, double *bound_out) {
   return guarded(h, [&] {
     if (!logc || !alpha0) throw Fail("msw_core_solve: null logc / alpha0");
-    solve_impl(h, logc, nullptr, alpha0, tol, max_iters, algo, prec, theta_out, iters_out, bound_out);
+    prepare_inputs(h, logc, nullptr, alpha0);
+    run_impl(h, tol, max_iters, algo, prec, theta_out, iters_out, bound_out);
   });
+}
+
+int msw_core_prepare(msw_handle h, const double *logc, const double *alpha0) {
+  return guarded(h, [&] {
+    if (!logc || !alpha0) throw Fail("msw_core_prepare: null logc / alpha0");
+    prepare_inputs(h, logc, nullptr, alpha0);
+  });
+}
+
+int msw_core_run(msw_handle h, double tol, size_t max_iters, int algo, int prec, double *theta_out,
+                 size_t *iters_out, double *bound_out) {
+  return guarded(h, [&] { run_impl(h, tol, max_iters, algo, prec, theta_out, iters_out, bound_out); });
 }
 
 int msw_core_set_trace_theta(msw_handle h, size_t n_iters) {

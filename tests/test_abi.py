@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library loads and exports every symbol include/msweep_core.h declares; without a
+GPU it fails loudly instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from msweep_amd import core
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "msweep_core.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(msw_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    lib = core.load_library()
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/msweep_core.h but not exported"
+    assert sorted(core.EXPORTS) == names
+
+
+def test_version_string():
+    lib = core.load_library()
+    assert b"gfx950" in lib.msw_core_version()
+
+
+def test_no_silent_cpu_fallback():
+    """On a box without a GPU creating a core must fail with a message; on a GPU box it succeeds."""
+    lib = core.load_library()
+    h = ctypes.c_void_p()
+    rc = lib.msw_core_create(0, ctypes.byref(h))
+    if rc != 0:
+        msg = lib.msw_last_error(None).decode()
+        assert msg, "error text must be set"
+        with pytest.raises(core.MswError):
+            core.Core(0)
+    else:
+        lib.msw_core_destroy(h)
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not import, link or load the oracle (test infrastructure)."""
+    pk = os.path.join(ROOT, "msweep_amd")
+    bad = re.compile(r"import\s+oracle|from\s+oracle|libmsweep_oracle|msweep_oracle\.h|orc_[a-z_]+\s*\(")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".inc", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not bad.search(txt), (f, bad.search(txt).group(0))

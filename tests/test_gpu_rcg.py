@@ -1,0 +1,270 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and through size-independent properties.
+
+Protocol: (i) lock-step gate -- same formulation, theta / bound / |g| after
+k <= 20 iterations at rel 1e-9 and identical reset decisions; (ii) convergence gate at --tol 1e-6
+-- theta rel <= 1e-6 for weights >= 1e-4 and abs <= 1e-8 below (the north-star tolerance);
+(iii) dense-state reference-shaped oracle as cross-check.
+"""
+import numpy as np
+import pytest
+
+from conftest import dense_from_csr, load_golden, lutidx_of
+from msweep_amd import synth
+from msweep_amd.core import ALGO_RCG, Core, MswError
+from msweep_amd.likelihood import from_dense, from_grouped_counts, precalc_lls
+
+pytestmark = pytest.mark.gpu
+
+REL, FLOOR, ABS = 1e-6, 1e-4, 1e-8  # north-star tolerance on the mixture weights
+
+
+def assert_theta(got, ref, rel=REL, floor=FLOOR, abs_=ABS):
+    got, ref = np.asarray(got), np.asarray(ref)
+    big = ref >= floor
+    worst_rel = np.max(np.abs(got - ref)[big] / ref[big], initial=0.0)
+    worst_abs = np.max(np.abs(got - ref)[~big], initial=0.0)
+    assert worst_rel <= rel, f"worst rel err {worst_rel:.3e} on weights >= {floor}"
+    assert worst_abs <= abs_, f"worst abs err {worst_abs:.3e} on weights < {floor}"
+
+
+def lockstep(tr, rt, k, rel=1e-9):
+    k = min(k, tr["n"], int(np.sum(rt["didreset"] >= 0)))
+    assert k > 0
+    assert tr["didreset"][:k].tolist() == rt["didreset"][:k].tolist()
+    np.testing.assert_allclose(tr["bound"][:k], rt["bound"][:k], rtol=rel)
+    np.testing.assert_allclose(tr["newnorm"][:k], rt["newnorm"][:k], rtol=1e-7, atol=1e-300)
+    np.testing.assert_allclose(tr["theta"][:k], rt["theta"][:k], rtol=rel, atol=1e-15)
+
+
+def solve_csr(core, p, alpha0=None, logc=None, trace=20, **kw):
+    G = len(p["group_sizes"])
+    alpha0 = np.ones(G) if alpha0 is None else alpha0
+    lik = from_grouped_counts(core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    logc = lik.log_counts() if logc is None else logc
+    core.set_trace_theta(trace)
+    res = core.solve(logc, alpha0, **kw)
+    return res, core.trace(trace, with_theta=True), logc, alpha0
+
+
+@pytest.mark.parametrize("R,G,seed,mo", [(3000, 60, 5, 6), (50000, 300, 6, 6), (200000, 1000, 7, 15)])
+def test_csr_lockstep_and_convergence_vs_structured_oracle(gpu_core, oracle, R, G, seed, mo):
+    p = synth.make_csr_problem(R, G, seed=seed, max_other=mo)
+    res, tr, logc, alpha0 = solve_csr(gpu_core, p)
+    lut = precalc_lls(p["group_sizes"])
+    ref = oracle.rcg_optl_csr(p["rowptr"], p["grp"], lutidx_of(p, lut), lut, np.log(0.01), G, logc, alpha0, trace=20)
+    lockstep(tr, ref["trace"], 20)
+    assert res["iters"] == ref["iters"]
+    assert res["bound"] == pytest.approx(ref["bound"], rel=1e-11)
+    assert_theta(res["theta"], ref["theta"])
+    assert res["theta"].sum() == pytest.approx(1.0, abs=1e-12)
+
+
+def test_csr_vs_dense_state_reference_shaped_oracle(gpu_core, oracle):
+    """The HIP CSR path against rcgpar's dense-state algorithm as the reference structures it."""
+    p = synth.make_csr_problem(20000, 120, seed=8, max_other=8)
+    res, tr, logc, alpha0 = solve_csr(gpu_core, p)
+    lut = precalc_lls(p["group_sizes"])
+    L = dense_from_csr(p, lut)
+    d = oracle.rcg_optl_dense(L, logc, alpha0, trace=20)
+    lockstep(tr, d["trace"], 20, rel=1e-8)
+    assert abs(res["iters"] - d["iters"]) <= 5  # the reference itself varies by 10 with -t (docs/gpubenchmarks.md:15-17)
+    assert_theta(res["theta"], oracle.mixture_components(d["gamma"], logc))
+    # gamma materialisation (K6) against the oracle's dense gamma, as probabilities
+    g = gpu_core.gamma()
+    assert g.shape == L.shape
+    np.testing.assert_allclose(np.exp(g).sum(0), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(np.exp(g), np.exp(d["gamma"]), atol=1e-6)
+    # the resident likelihood expands to exactly the reference's dense matrix
+    np.testing.assert_array_equal(gpu_core.get_dense_logl(), L)
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_golden_fixture_dense_path(gpu_core, idx):
+    """HIP dense-L path against the committed golden trajectories (tests/golden/rcg_golden.json)."""
+    c = load_golden("rcg_golden.json")["cases"][idx]
+    L = np.array(c["logl"])
+    logc = np.array([-np.inf if x is None else x for x in c["logc"]])
+    alpha0 = np.array(c["alpha0"])
+    from_dense(gpu_core, L, logc)
+    gpu_core.set_trace_theta(20)
+    res = gpu_core.solve(logc, alpha0, c["tol"], c["max_iters"])
+    e = c["expect"]
+    assert res["iters"] == e["iters"], c["name"]
+    tr = gpu_core.trace(20, with_theta=True)
+    k = min(10, e["iters"])
+    np.testing.assert_allclose(tr["bound"][:k], e["trace"]["bound"][:k], rtol=1e-11)
+    assert tr["didreset"][:k].tolist() == e["trace"]["didreset"][:k]
+    np.testing.assert_allclose(tr["theta"][:k], np.array(e["trace"]["theta"])[:k], rtol=1e-8)
+    assert_theta(res["theta"], e["theta"])
+
+
+@pytest.mark.parametrize("E,G,seed", [(2000, 40, 3), (20000, 500, 4), (3000, 1000, 5), (513, 65, 6)])
+def test_dense_path_vs_dense_state_oracle(gpu_core, oracle, E, G, seed):
+    p = synth.make_dense_problem(E, G, seed=seed)
+    alpha0 = np.ones(G)
+    from_dense(gpu_core, p["logl"], p["logc"])
+    gpu_core.set_trace_theta(20)
+    res = gpu_core.solve(p["logc"], alpha0)
+    tr = gpu_core.trace(20, with_theta=True)
+    ref = oracle.rcg_optl_dense(p["logl"], p["logc"], alpha0, trace=20)
+    lockstep(tr, ref["trace"], 15, rel=1e-8)
+    assert abs(res["iters"] - ref["iters"]) <= 5
+    assert_theta(res["theta"], oracle.mixture_components(ref["gamma"], p["logc"]))
+    s = oracle.rcg_optl_dense_structured(p["logl"], p["logc"], alpha0, trace=20)
+    lockstep(tr, s["trace"], 20)
+    np.testing.assert_array_equal(gpu_core.get_dense_logl(), p["logl"])
+
+
+def test_dense_strided_input_and_gamma(gpu_core, oracle):
+    p = synth.make_dense_problem(700, 33, seed=9)
+    big = np.zeros((33, 1000))
+    big[:, :700] = p["logl"]
+    from_dense(gpu_core, big[:, :700], p["logc"])          # ld = 1000 > E
+    res = gpu_core.solve(p["logc"], np.ones(33))
+    ref = oracle.rcg_optl_dense(p["logl"], p["logc"], np.ones(33))
+    assert_theta(res["theta"], oracle.mixture_components(ref["gamma"], p["logc"]))
+    np.testing.assert_allclose(np.exp(gpu_core.gamma()), np.exp(ref["gamma"]), atol=1e-6)
+
+
+def test_edge_cases_csr(gpu_core, oracle):
+    lut = precalc_lls(np.array([3, 2, 5, 1], np.uint64))
+    lz = np.log(0.01)
+    # (a) ECs without any hit (all-background rows), a single-cell row, zero-count ECs (-inf)
+    rowptr = np.array([0, 0, 2, 3, 3, 6], np.uint64)
+    grp = np.array([0, 2, 1, 3, 0, 2], np.uint32)
+    cnt = np.array([3, 1, 2, 1, 1, 5], np.uint32)
+    gpu_core.set_csr(rowptr, grp, cnt, lut, lz, 4)
+    with np.errstate(divide="ignore"):
+        logc = np.log(np.array([4.0, 7.0, 0.0, 2.0, 9.0]))
+    alpha0 = np.array([1.0, 0.5, 2.0, 1.0])
+    res = gpu_core.solve(logc, alpha0)
+    lutidx = (grp * lut.shape[1] + cnt).astype(np.uint32)
+    ref = oracle.rcg_optl_csr(rowptr, grp, lutidx, lut, lz, 4, logc, alpha0)
+    assert res["iters"] == ref["iters"]
+    np.testing.assert_allclose(res["theta"], ref["theta"], rtol=1e-9)
+    # (b) one group
+    gpu_core.set_csr(np.array([0, 1, 1], np.uint64), np.array([0], np.uint32), np.array([2], np.uint32),
+                     lut[:1], lz, 1)
+    r1 = gpu_core.solve(np.log([3.0, 5.0]), np.ones(1))
+    assert r1["theta"][0] == pytest.approx(1.0, rel=1e-14)
+    # (c) a single EC
+    gpu_core.set_csr(np.array([0, 2], np.uint64), np.array([1, 3], np.uint32), np.array([1, 1], np.uint32), lut, lz, 4)
+    r2 = gpu_core.solve(np.log([10.0]), np.ones(4))
+    o2 = oracle.rcg_optl_csr(np.array([0, 2], np.uint64), [1, 3], (np.array([1, 3]) * lut.shape[1] + 1), lut, lz, 4,
+                             np.log([10.0]), np.ones(4))
+    np.testing.assert_allclose(r2["theta"], o2["theta"], rtol=1e-9)
+    # (d) max_iters cap is honoured
+    p = synth.make_csr_problem(5000, 40, seed=3, max_other=5)
+    res3, _, _, _ = solve_csr(gpu_core, p, max_iters=3)
+    assert res3["iters"] == 3
+
+
+def test_long_rows_and_global_vector_mode(gpu_core, oracle):
+    """G > LDS capacity (group vectors in HBM, global atomics) and an EC longer than a tile
+    (workgroup-cooperative path)."""
+    rng = np.random.default_rng(12)
+    G = 9000
+    sizes = (1 + rng.poisson(3, G)).astype(np.uint64)
+    lut = precalc_lls(sizes)
+    rows, cols, cnts = [], [], []
+    for j in range(400):
+        n = G if j in (7, 200) else int(rng.integers(1, 12))   # two ECs hit every group
+        g = np.sort(rng.choice(G, n, replace=False))
+        rows.append(n); cols.append(g); cnts.append(rng.integers(1, sizes[g] + 1))
+    rowptr = np.concatenate([[0], np.cumsum(rows)]).astype(np.uint64)
+    grp = np.concatenate(cols).astype(np.uint32)
+    cnt = np.concatenate(cnts).astype(np.uint32)
+    logc = np.log(rng.integers(1, 50, 400).astype(float))
+    alpha0 = np.ones(G)
+    gpu_core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
+    gpu_core.set_trace_theta(10)
+    res = gpu_core.solve(logc, alpha0)
+    tr = gpu_core.trace(10, with_theta=True)
+    lutidx = (grp * lut.shape[1] + cnt).astype(np.uint32)
+    ref = oracle.rcg_optl_csr(rowptr, grp, lutidx, lut, np.log(0.01), G, logc, alpha0, trace=10)
+    lockstep(tr, ref["trace"], 10)
+    assert_theta(res["theta"], ref["theta"])
+
+
+def test_wide_records_large_lut(gpu_core, oracle):
+    """More than 65536 LUT slots -> 64-bit records and the table read from HBM/L2."""
+    rng = np.random.default_rng(13)
+    G = 400
+    sizes = rng.permutation(np.arange(100, 100 + G)).astype(np.uint64)   # all sizes distinct: 400 x 500 slots
+    lut = precalc_lls(sizes)
+    assert lut.size > 65536
+    E = 3000
+    n = rng.integers(1, 9, E)
+    rowptr = np.concatenate([[0], np.cumsum(n)]).astype(np.uint64)
+    grp = np.concatenate([np.sort(rng.choice(G, k, replace=False)) for k in n]).astype(np.uint32)
+    cnt = rng.integers(1, sizes[grp] + 1).astype(np.uint32)
+    logc = np.log(rng.integers(1, 30, E).astype(float))
+    gpu_core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
+    gpu_core.set_trace_theta(10)
+    res = gpu_core.solve(logc, np.ones(G))
+    tr = gpu_core.trace(10, with_theta=True)
+    lutidx = (grp * lut.shape[1] + cnt).astype(np.uint32)
+    ref = oracle.rcg_optl_csr(rowptr, grp, lutidx, lut, np.log(0.01), G, logc, np.ones(G), trace=10)
+    lockstep(tr, ref["trace"], 10)
+    assert_theta(res["theta"], ref["theta"])
+
+
+def test_properties_at_scale(gpu_core):
+    """Size-independent properties on a problem too large for the dense oracle: sum theta = 1,
+    sum N = sum alpha + sum c, EC-splitting invariance, group-permutation equivariance, bound
+    monotone over accepted steps, and the fixed-point condition of the RCG-VB optimum."""
+    p = synth.make_csr_problem(2_000_000, 5000, seed=2)
+    G = 5000
+    res, tr, logc, alpha0 = solve_csr(gpu_core, p, trace=0)
+    assert res["theta"].sum() == pytest.approx(1.0, abs=1e-11)
+    t = gpu_core.trace(4096)
+    b = t["bound"]
+    ok = t["didreset"] == 0
+    assert np.all(np.diff(b)[ok[1:]] > -1e-6)
+    # EC splitting: one EC with count c == two identical ECs with counts c1 + c2
+    rp = p["rowptr"].astype(np.int64)
+    E = len(rp) - 1
+    big = np.nonzero(p["ec_counts"] >= 2)[0][:50000]
+    lens = np.diff(rp)
+    extra_idx = np.concatenate([np.arange(rp[j], rp[j + 1]) for j in big[:2000]])
+    sel = big[:2000]
+    q = dict(p)
+    q["rowptr"] = np.concatenate([rp, rp[-1] + np.cumsum(lens[sel])]).astype(np.uint64)
+    q["grp"] = np.concatenate([p["grp"], p["grp"][extra_idx]])
+    q["cnt"] = np.concatenate([p["cnt"], p["cnt"][extra_idx]])
+    c = p["ec_counts"].copy()
+    moved = c[sel] // 2
+    c[sel] -= moved
+    q["ec_counts"] = np.concatenate([c, moved])
+    res2, _, _, _ = solve_csr(gpu_core, q, trace=0)
+    assert_theta(res2["theta"], res["theta"], rel=5e-6)
+    # group permutation
+    perm = np.random.default_rng(1).permutation(G)
+    inv = np.argsort(perm)
+    r = dict(p)
+    r["grp"] = inv[p["grp"]].astype(np.uint32)         # old group g becomes inv[g]
+    r["group_sizes"] = p["group_sizes"][perm]
+    res3, _, _, _ = solve_csr(gpu_core, r, trace=0)
+    assert_theta(res3["theta"][inv], res["theta"], rel=5e-6)
+
+
+def test_error_behaviour(gpu_core):
+    """Errors surface as MswError with text (the C++ shim throws std::runtime_error the same way,
+    src/mSWEEP.cpp:403-406)."""
+    lut = precalc_lls(np.array([2, 2], np.uint64))
+    with pytest.raises(MswError, match="group id out of range"):
+        gpu_core.set_csr(np.array([0, 1], np.uint64), np.array([5], np.uint32), np.array([1], np.uint32), lut, -4.6, 2)
+    with pytest.raises(MswError, match="hit count exceeds"):
+        gpu_core.set_csr(np.array([0, 1], np.uint64), np.array([0], np.uint32), np.array([9], np.uint32), lut, -4.6, 2)
+    with pytest.raises(MswError, match="rowptr not monotone"):
+        gpu_core.set_csr(np.array([0, 2, 1, 2], np.uint64), np.array([0, 1], np.uint32), np.array([1, 1], np.uint32), lut, -4.6, 2)
+    with pytest.raises(MswError):
+        gpu_core.solve(np.zeros(3), np.ones(2))           # no likelihood resident after the failures
+    gpu_core.set_csr(np.array([0, 1], np.uint64), np.array([0], np.uint32), np.array([1], np.uint32), lut, -4.6, 2)
+    with pytest.raises(MswError, match="expected logc"):
+        gpu_core.solve(np.zeros(3), np.ones(2))
+    with pytest.raises(MswError, match="unknown algorithm"):
+        gpu_core.solve(np.zeros(1), np.ones(2), algo=7)
+    with pytest.raises(MswError):
+        Core(99)

@@ -1,0 +1,117 @@
+"""CPU: the optimiser oracle (rcgpar v1.2.1 restated -- parity unpinned by the reference tree,
+see oracle/msweep_oracle.h) against the independent numpy twin's golden trajectories, the
+structured formulation against the dense-state one, and mathematical properties."""
+import numpy as np
+import pytest
+
+from conftest import dense_from_csr, load_golden, lutidx_of
+from msweep_amd import synth
+from msweep_amd.likelihood import precalc_lls
+
+
+def _case_arrays(c):
+    L = np.array(c["logl"])
+    logc = np.array([-np.inf if x is None else x for x in c["logc"]])
+    return L, logc, np.array(c["alpha0"])
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_dense_oracle_matches_numpy_twin(oracle, idx):
+    c = load_golden("rcg_golden.json")["cases"][idx]
+    L, logc, alpha0 = _case_arrays(c)
+    r = oracle.rcg_optl_dense(L, logc, alpha0, c["tol"], c["max_iters"], trace=25)
+    e = c["expect"]
+    assert r["iters"] == e["iters"], c["name"]
+    k = min(len(e["trace"]["bound"]), r["iters"])
+    np.testing.assert_allclose(r["trace"]["bound"][:k], e["trace"]["bound"][:k], rtol=1e-12)
+    nn, en = r["trace"]["newnorm"][:k], np.array(e["trace"]["newnorm"][:k])
+    np.testing.assert_allclose(nn[:10], en[:10], rtol=1e-9, atol=1e-300)
+    assert r["trace"]["didreset"][:k].tolist() == e["trace"]["didreset"][:k]
+    np.testing.assert_allclose(r["trace"]["theta"][:min(k, 10)], np.array(e["trace"]["theta"])[:min(k, 10)], rtol=1e-9)
+    theta = oracle.mixture_components(r["gamma"], logc)
+    np.testing.assert_allclose(theta, e["theta"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(np.exp(r["gamma"]).sum(0), 1.0, rtol=1e-12)
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_structured_dense_matches_dense_state(oracle, idx):
+    c = load_golden("rcg_golden.json")["cases"][idx]
+    L, logc, alpha0 = _case_arrays(c)
+    d = oracle.rcg_optl_dense(L, logc, alpha0, trace=25)
+    s = oracle.rcg_optl_dense_structured(L, logc, alpha0, trace=25, want_gamma=True)
+    assert s["iters"] == d["iters"]
+    k = min(20, d["iters"])
+    np.testing.assert_allclose(s["trace"]["bound"][:k], d["trace"]["bound"][:k], rtol=1e-11)
+    assert s["trace"]["didreset"][:k].tolist() == d["trace"]["didreset"][:k].tolist()
+    np.testing.assert_allclose(s["trace"]["theta"][:10], d["trace"]["theta"][:10], rtol=1e-9)
+    np.testing.assert_allclose(s["theta"], oracle.mixture_components(d["gamma"], logc), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(np.exp(s["gamma"]), np.exp(d["gamma"]), atol=1e-7)
+
+
+def test_csr_structured_matches_dense_state(oracle):
+    p = synth.make_csr_problem(4000, 50, seed=5, max_other=6)
+    lut = precalc_lls(p["group_sizes"])
+    L = dense_from_csr(p, lut)
+    logc = np.log(p["ec_counts"].astype(float))
+    alpha0 = np.ones(50)
+    d = oracle.rcg_optl_dense(L, logc, alpha0, trace=30)
+    s = oracle.rcg_optl_csr(p["rowptr"], p["grp"], lutidx_of(p, lut), lut, np.log(0.01), 50, logc, alpha0,
+                            trace=30, want_gamma=True)
+    assert s["iters"] == d["iters"]
+    k = min(20, d["iters"])
+    np.testing.assert_allclose(s["trace"]["bound"][:k], d["trace"]["bound"][:k], rtol=1e-11)
+    np.testing.assert_allclose(s["trace"]["newnorm"][:10], d["trace"]["newnorm"][:10], rtol=1e-8)
+    assert s["trace"]["didreset"][:k].tolist() == d["trace"]["didreset"][:k].tolist()
+    th = oracle.mixture_components(d["gamma"], logc)
+    np.testing.assert_allclose(s["theta"], th, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(np.exp(s["gamma"]), np.exp(d["gamma"]), atol=1e-7)
+
+
+def test_known_answers(oracle):
+    # G = 1 -> theta = 1
+    L = np.log(np.random.default_rng(0).uniform(0.1, 0.9, (1, 7)))
+    r = oracle.rcg_optl_dense(L, np.zeros(7), np.ones(1))
+    assert oracle.mixture_components(r["gamma"], np.zeros(7))[0] == pytest.approx(1.0, rel=1e-14)
+    # (nearly) disjoint support: responsibilities are 0/1, theta_g = c_g / sum c
+    G, E = 3, 9
+    L = np.full((G, E), -800.0)
+    owner = np.arange(E) % G
+    L[owner, np.arange(E)] = -1.0
+    cnt = np.arange(1, E + 1, dtype=float)
+    r = oracle.rcg_optl_dense(L, np.log(cnt), np.ones(G))
+    th = oracle.mixture_components(r["gamma"], np.log(cnt))
+    exp = np.array([cnt[owner == g].sum() for g in range(G)]) / cnt.sum()
+    np.testing.assert_allclose(th, exp, rtol=1e-12)
+
+
+def test_invariances(oracle):
+    rng = np.random.default_rng(4)
+    c = load_golden("rcg_golden.json")["cases"][2]
+    L, logc, alpha0 = _case_arrays(c)
+    base = oracle.rcg_optl_dense_structured(L, logc, alpha0)
+    # permutation of groups and of ECs
+    pg, pe = rng.permutation(L.shape[0]), rng.permutation(L.shape[1])
+    r = oracle.rcg_optl_dense_structured(L[pg][:, pe], logc[pe], alpha0[pg])
+    np.testing.assert_allclose(r["theta"], base["theta"][pg], rtol=1e-6, atol=1e-10)
+    # bound never decreases over accepted steps; sum N = sum alpha + sum c
+    d = oracle.rcg_optl_dense(L, logc, alpha0, trace=100)
+    b = d["trace"]["bound"][:d["iters"]]
+    assert np.all(np.diff(b) > -1e-9)
+    th = oracle.mixture_components(d["gamma"], logc)
+    assert th.sum() == pytest.approx(1.0, abs=1e-12)
+    # fixed point: gamma_gj proportional to exp(L_gj + digamma(N_g)) at convergence
+    N = th * np.exp(logc).sum() + alpha0
+    dg = np.array([oracle.digamma(x) for x in N])
+    z = L + dg[:, None]
+    z -= np.log(np.exp(z).sum(0))[None, :]
+    np.testing.assert_allclose(np.exp(z), np.exp(d["gamma"]), atol=5e-4)
+
+
+def test_em_oracle_converges_to_same_optimum_region(oracle):
+    """EM (MAP with alpha0 = 1 -> ML) and RCG-VB optimise different objectives; with many reads
+    they agree to within the prior's influence."""
+    c = load_golden("rcg_golden.json")["cases"][6]
+    L, logc, alpha0 = _case_arrays(c)
+    em = oracle.em_dense(L, logc, alpha0, tol=1e-10, max_iters=20000)
+    assert em["theta"].sum() == pytest.approx(1.0, abs=1e-12)
+    np.testing.assert_allclose(em["theta"], c["expect"]["theta"], atol=2e-3)
