@@ -70,6 +70,11 @@ def cpu_baseline(prob, lut, n_ecs, iters):
                       f"{dt:.1f} s; iters/s on the sample = {r['iters'] / dt:.3f}"}
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -96,6 +101,7 @@ def main():
     E = len(prob["rowptr"]) - 1
     nnz = len(prob["grp"])
     t_gen = time.time() - t0
+    log(f"generated cfg3: E={E} nnz={nnz} in {t_gen:.1f}s")
 
     core = Core(local_rank)
     lik = from_grouped_counts(core, prob["rowptr"], prob["grp"], prob["cnt"], prob["ec_counts"],
@@ -111,6 +117,7 @@ def main():
             logc = np.log(counts)
     else:
         logc = lik.log_counts()
+    log("likelihood resident")
     core.set_fixed_iters(True)
     core.prepare(logc, alpha0)               # inputs resident in HBM before the timed region
     core.run(max_iters=max(a.warmup, 1))     # W untimed warm-up steps
@@ -133,6 +140,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tm = core.last_timing()
+    log(f"timed {a.steps} steps in {dt:.3f}s")
     assert tm["iters"] == a.steps, (tm["iters"], a.steps)
     if dist is not None:
         import torch
@@ -167,6 +175,7 @@ def main():
             "setup_s": {"generate": t_gen},
         }
         if not a.no_cpu_baseline:
+            log("cpu baseline ...")
             try:
                 line["cpu_baseline"] = cpu_baseline(prob, precalc_lls(prob["group_sizes"]), a.cpu_sample_ecs,
                                                     a.cpu_iters)

@@ -1,4 +1,4 @@
-// kernels.hpp -- hand-written gfx950 kernels of the RCG / EM abundance-estimation loop.
+// kernels.hpp -- hand-written gfx950 kernels of the RCG abundance-estimation loop.
 //
 // Formulation: the log-responsibilities keep the closed form
 //     gamma(g, j) = a * L(g, j) + u_g - lse_j ,   lse_j = logsumexp_g(a*L(g,j) + u_g)
@@ -61,55 +61,75 @@ __device__ __forceinline__ double digamma_ref(double x) {
 }
 
 // ---------------------------------------------------------------------------------------
-// device-resident CSR-of-ECs likelihood
+// Device-resident CSR-of-ECs likelihood in SELL-64 form.
+//   ECs are permuted: first the "long" ECs (more than kLongRow cells, kept as plain CSR and
+//   swept by a whole workgroup), then all others sorted by descending cell count and cut into
+//   slices of 64 consecutive ECs.  A slice stores its records column-major
+//   (rec[(off + k) * 64 + lane] = k-th cell of the slice's lane-th EC), padded to the slice's
+//   longest EC with a sentinel record (group id == n_groups, whose e_g is 0).  A wavefront
+//   sweeps one slice: lane l streams EC l's cells with perfectly coalesced loads.
+//   A record is (lutidx << 16 | grp) when both fit 16 bits, else {grp, lutidx}.
 // ---------------------------------------------------------------------------------------
-struct CsrDev {
-  const uint32_t *rowptr;    // [E+1]
-  const uint32_t *rec;       // narrow: [nnz] (lutidx << 16 | grp); wide: [2*nnz] {grp, lutidx}
-  const uint32_t *tile_row;  // [ntiles+1] first row of each tile
-  const double *cvec;        // [E] EC multiplicities as fp64
-  uint32_t ntiles;
-  uint32_t n_ecs;
-  uint32_t n_groups;
-  uint32_t n_lut;
+struct SellDev {
+  const uint32_t *rec;        // SELL records
+  const uint32_t *slice_off;  // [nslices + 1], in units of 64 records
+  const uint32_t *long_ptr;   // [n_long + 1] offsets into rec_long
+  const uint32_t *rec_long;   // records of the long ECs (CSR)
+  const uint32_t *perm;       // [E] permuted position -> original EC index
+  const double *cvec;         // [E] EC multiplicities, permuted order
+  uint32_t nslices, n_long, n_ecs, n_groups, n_lut;
 };
 
-constexpr int kTileRows = kPassThreads;  // one row per thread
-constexpr int kTileCap = 8192;           // staged nz records per tile (32 KiB narrow)
+constexpr int kLongRow = 256;  // ECs with more cells than this take the workgroup path
 
 template <bool WIDE>
 struct Rec;
 template <>
 struct Rec<false> {
   using T = uint32_t;
-  static __device__ __forceinline__ T load(const uint32_t *p, uint32_t i) { return p[i]; }
+  static __device__ __forceinline__ T load(const uint32_t *p, size_t i) { return p[i]; }
   static __device__ __forceinline__ uint32_t grp(T r) { return r & 0xffffu; }
   static __device__ __forceinline__ uint32_t idx(T r) { return r >> 16; }
 };
 template <>
 struct Rec<true> {
   using T = uint2;
-  static __device__ __forceinline__ T load(const uint32_t *p, uint32_t i) {
+  static __device__ __forceinline__ T load(const uint32_t *p, size_t i) {
     return reinterpret_cast<const uint2 *>(p)[i];
   }
   static __device__ __forceinline__ uint32_t grp(T r) { return r.x; }
   static __device__ __forceinline__ uint32_t idx(T r) { return r.y; }
 };
 
-// LDS carve-up shared by pass A and pass B.  nvec = number of G-length fp64 vectors kept in
-// LDS (2 in both passes), ntab = doubles per LUT slot (3 in pass A, 2 in pass B).
-__host__ __device__ inline size_t pass_lds_bytes(bool wide, bool glds, bool tlds, uint32_t G,
-                                                 uint32_t n_lut, int ntab) {
-  size_t b = 32 * sizeof(double);                      // reduction scratch
-  if (glds) b += 2 * (size_t)G * sizeof(double);
-  if (tlds) b += (size_t)ntab * n_lut * sizeof(double);
-  b += (kTileRows + 1 + 3) / 4 * 4 * sizeof(uint32_t);  // row pointers of the tile
-  b += (size_t)kTileCap * (wide ? 8 : 4);              // staged records
+// Visit the cells of the EC at permuted position p (utility kernels only).
+template <bool WIDE, class F>
+__device__ __forceinline__ void for_each_cell(const SellDev &S, uint32_t p, F f) {
+  using R = Rec<WIDE>;
+  if (p < S.n_long) {
+    for (uint32_t k = S.long_ptr[p]; k < S.long_ptr[p + 1]; ++k) f(R::load(S.rec_long, k));
+  } else {
+    const uint32_t q = p - S.n_long, s = q >> 6, lane = q & 63;
+    const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;
+    for (uint32_t k = 0; k < len; ++k) {
+      const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + lane);
+      if (R::grp(r) != S.n_groups) f(r);
+    }
+  }
+}
+
+// LDS bytes of the sweeps.  Pass A keeps {e_g, wc_g} pairs and 4 doubles per LUT slot, pass B
+// keeps e_g, the column-sum accumulators and 2 doubles per LUT slot.
+__host__ __device__ inline size_t pass_lds_bytes(bool glds, bool tlds, uint32_t G, uint32_t n_lut,
+                                                 bool passA) {
+  size_t b = 32 * sizeof(double);  // reduction scratch
+  if (glds) b += 2 * ((size_t)G + 1) * sizeof(double);
+  if (tlds) b += (size_t)(passA ? 4 : 2) * n_lut * sizeof(double);
   return b;
 }
 
 // ---------------------------------------------------------------------------------------
 // O(G) "prep" helpers, all executed by ONE 1024-thread workgroup.
+// Index G of e / ew is the sentinel slot: zeroed once at set-up and never written here.
 // ---------------------------------------------------------------------------------------
 // From (a, u): M = max u, e_g = exp(u_g - M), U = sum e, p0 = exp(a*logzi) and the pass-B
 // table {x - p0, x*T - p0*logzi}, x = exp(a*T).
@@ -152,21 +172,17 @@ __global__ __launch_bounds__(1024) void k_prepB(Scalars *sc, int G, int n_lut, c
 }
 
 // Gradient preparation: w_g = digamma(N_g) - 1 - u_g (the group part of rcgpar's
-// mixt_negnatgrad step), e_g, the centred w and the pass-A table.
+// mixt_negnatgrad step), {e_g, centred w_g} pairs and the pass-A table.
 __global__ __launch_bounds__(1024) void k_prepA(Scalars *sc, int G, int n_lut, const double *N,
                                                const double *u, const double *lut, double *w,
-                                               double *e, double *wc, double *tabA) {
+                                               double *e, double2 *ew, double *tabA) {
   __shared__ double sh[32];
   if (sc->done) return;
   const int tid = threadIdx.x, nt = blockDim.x;
   const double a = sc->a, oma = 1.0 - a, logzi = sc->logzi;
   const int flavor = sc->flavor;
   if (flavor != 0) {  // dense: only w is needed
-    for (int g = tid; g < G; g += nt) {
-      const double wg = digamma_ref(N[g]) - 1.0 - u[g];
-      w[g] = wg;
-      wc[g] = wg;
-    }
+    for (int g = tid; g < G; g += nt) w[g] = digamma_ref(N[g]) - 1.0 - u[g];
     return;
   }
   double m = -INFINITY;
@@ -187,9 +203,9 @@ __global__ __launch_bounds__(1024) void k_prepA(Scalars *sc, int G, int n_lut, c
   double s1 = 0.0, s2 = 0.0;
   for (int g = tid; g < G; g += nt) {
     const double wcg = w[g] - kappa;
-    wc[g] = wcg;
-    const double s0 = oma * logzi + wcg;
     const double eg = e[g];
+    ew[g] = make_double2(eg, wcg);
+    const double s0 = oma * logzi + wcg;
     s1 += eg * s0;
     s2 += eg * s0 * s0;
   }
@@ -199,9 +215,10 @@ __global__ __launch_bounds__(1024) void k_prepA(Scalars *sc, int G, int n_lut, c
   for (int i = tid; i < n_lut; i += nt) {
     const double T = lut[i];
     const double x = exp(a * T);
-    tabA[3 * i] = x - p0;
-    tabA[3 * i + 1] = oma * (x * T - p0 * logzi);
-    tabA[3 * i + 2] = oma * oma * (x * T * T - p0 * logzi * logzi);
+    tabA[4 * i] = x - p0;
+    tabA[4 * i + 1] = oma * (x * T - p0 * logzi);
+    tabA[4 * i + 2] = oma * oma * (x * T * T - p0 * logzi * logzi);
+    tabA[4 * i + 3] = 0.0;
   }
   if (tid == 0) {
     sc->M = M;
@@ -263,115 +280,111 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
 }
 
 // ---------------------------------------------------------------------------------------
-// Pass A (CSR): newnorm = sum_j Var_{q_j}(step_.j), q_j = softmax_g(a*L + u),
+// Pass A (SELL): newnorm = sum_j Var_{q_j}(step_.j), q_j = softmax_g(a*L + u),
 // step_gj = (1-a)*L_gj + w_g  (+ an irrelevant per-EC constant).
-// One persistent 1024-thread workgroup per CU; a tile = up to 1024 consecutive ECs whose
-// records are staged through LDS with coalesced loads; one thread per EC.
+// One persistent 1024-thread workgroup per CU; its 16 wavefronts take slices round-robin.
 // ---------------------------------------------------------------------------------------
+struct AccA {
+  double zs, t1, t2;
+};
+__device__ __forceinline__ void cellA(AccA &c, const double2 ew, const double *t) {
+  const double xm = t[0], A1 = t[1], A2 = t[2];
+  const double wx = ew.y * xm;
+  c.zs += ew.x * xm;
+  c.t1 += ew.x * (A1 + wx);
+  c.t2 += ew.x * (A2 + ew.y * (2.0 * A1 + wx));
+}
+
 template <bool WIDE, bool GLDS, bool TLDS>
-__global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, CsrDev S,
-                                                       const double *e_g, const double *wc_g,
-                                                       const double *tabA_g, double *partA) {
+__global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellDev S,
+                                                       const double2 *ew_g, const double *tabA_g,
+                                                       double *partA) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
   if (sc->done) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t G = S.n_groups, n_lut = S.n_lut;
   double *sh = reinterpret_cast<double *>(smem);
   double *p = sh + 32;
-  const double *e_l = e_g, *wc_l = wc_g, *tab = tabA_g;
+  const double2 *ew = ew_g;
+  const double *tab = tabA_g;
   if (GLDS) {
-    double *el = p, *wl = p + G;
-    p += 2 * (size_t)G;
-    for (uint32_t g = tid; g < G; g += kPassThreads) {
-      el[g] = e_g[g];
-      wl[g] = wc_g[g];
-    }
-    e_l = el;
-    wc_l = wl;
+    double2 *l = reinterpret_cast<double2 *>(p);
+    p += 2 * ((size_t)G + 1);
+    for (uint32_t g = tid; g <= G; g += kPassThreads) l[g] = ew_g[g];
+    ew = l;
   }
   if (TLDS) {
     double *tl = p;
-    p += 3 * (size_t)n_lut;
-    for (uint32_t i = tid; i < 3 * n_lut; i += kPassThreads) tl[i] = tabA_g[i];
+    for (uint32_t i = tid; i < 4 * n_lut; i += kPassThreads) tl[i] = tabA_g[i];
     tab = tl;
   }
-  uint32_t *rp = reinterpret_cast<uint32_t *>(p);
-  typename R::T *nzl = reinterpret_cast<typename R::T *>(rp + (kTileRows + 1 + 3) / 4 * 4);
   const double p0 = sc->p0, U = sc->U;
   const double zbase = p0 * U, b1 = p0 * sc->V1c, b2 = p0 * sc->V2c;
   double nn = 0.0;
   __syncthreads();
 
-  for (uint32_t t = blockIdx.x; t < S.ntiles; t += gridDim.x) {
-    const uint32_t rs = S.tile_row[t], nr = S.tile_row[t + 1] - rs;
-    if ((uint32_t)tid < nr) rp[tid] = S.rowptr[rs + tid];
-    if (tid == 0) rp[nr] = S.rowptr[rs + nr];
-    __syncthreads();
-    const uint32_t n0 = rp[0], nn_t = rp[nr] - n0;
-    if (nn_t <= (uint32_t)kTileCap) {
-      for (uint32_t i = tid; i < nn_t; i += kPassThreads) nzl[i] = R::load(S.rec, n0 + i);
-      __syncthreads();
-      if ((uint32_t)tid < nr) {
-        const uint32_t kb = rp[tid] - n0, ke = rp[tid + 1] - n0;
-        double zs = 0.0, t1 = 0.0, t2 = 0.0;
-        for (uint32_t k = kb; k < ke; ++k) {
-          const typename R::T r = nzl[k];
-          const uint32_t g = R::grp(r), i = R::idx(r);
-          const double eg = e_l[g], wg = wc_l[g];
-          const double xm = tab[3 * i], A1 = tab[3 * i + 1], A2 = tab[3 * i + 2];
-          const double wx = wg * xm;
-          zs += eg * xm;
-          t1 += eg * (A1 + wx);
-          t2 += eg * (A2 + wg * (2.0 * A1 + wx));
-        }
-        const double iZ = 1.0 / (zbase + zs);
-        const double S1 = (b1 + t1) * iZ, S2 = (b2 + t2) * iZ;
-        nn += S2 - S1 * S1;
-      }
-    } else {
-      // one long EC: the whole workgroup strides over its records straight from HBM
-      double zs = 0.0, t1 = 0.0, t2 = 0.0;
-      for (uint32_t k = tid; k < nn_t; k += kPassThreads) {
-        const typename R::T r = R::load(S.rec, n0 + k);
-        const uint32_t g = R::grp(r), i = R::idx(r);
-        const double eg = e_l[g], wg = wc_l[g];
-        const double xm = tab[3 * i], A1 = tab[3 * i + 1], A2 = tab[3 * i + 2];
-        const double wx = wg * xm;
-        zs += eg * xm;
-        t1 += eg * (A1 + wx);
-        t2 += eg * (A2 + wg * (2.0 * A1 + wx));
-      }
-      zs = block_sum(zs, sh);
-      t1 = block_sum(t1, sh);
-      t2 = block_sum(t2, sh);
-      if (tid == 0) {
-        const double iZ = 1.0 / (zbase + zs);
-        const double S1 = (b1 + t1) * iZ, S2 = (b2 + t2) * iZ;
-        nn += S2 - S1 * S1;
-      }
+  const uint32_t n_sell = S.n_ecs - S.n_long;
+  const uint32_t gw = blockIdx.x * (kPassThreads / 64) + (tid >> 6), nw = gridDim.x * (kPassThreads / 64);
+  for (uint32_t s = gw; s < S.nslices; s += nw) {
+    const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;
+    const size_t base = (size_t)o0 * 64 + lane;
+    AccA c = {0.0, 0.0, 0.0};
+    uint32_t k = 0;
+    for (; k + 4 <= len; k += 4) {
+      const typename R::T r0 = R::load(S.rec, base + (size_t)k * 64);
+      const typename R::T r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
+      const typename R::T r2 = R::load(S.rec, base + (size_t)(k + 2) * 64);
+      const typename R::T r3 = R::load(S.rec, base + (size_t)(k + 3) * 64);
+      const double2 e0 = ew[R::grp(r0)], e1 = ew[R::grp(r1)], e2 = ew[R::grp(r2)], e3 = ew[R::grp(r3)];
+      cellA(c, e0, tab + 4 * R::idx(r0));
+      cellA(c, e1, tab + 4 * R::idx(r1));
+      cellA(c, e2, tab + 4 * R::idx(r2));
+      cellA(c, e3, tab + 4 * R::idx(r3));
     }
-    __syncthreads();
+    for (; k < len; ++k) {
+      const typename R::T r = R::load(S.rec, base + (size_t)k * 64);
+      cellA(c, ew[R::grp(r)], tab + 4 * R::idx(r));
+    }
+    if (s * 64 + lane < n_sell) {
+      const double iZ = 1.0 / (zbase + c.zs);
+      const double S1 = (b1 + c.t1) * iZ, S2 = (b2 + c.t2) * iZ;
+      nn += S2 - S1 * S1;
+    }
+  }
+  // long ECs: the whole workgroup strides over one EC's cells
+  for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
+    AccA c = {0.0, 0.0, 0.0};
+    for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
+      const typename R::T rc = R::load(S.rec_long, k);
+      cellA(c, ew[R::grp(rc)], tab + 4 * R::idx(rc));
+    }
+    const double zs = block_sum(c.zs, sh), t1 = block_sum(c.t1, sh), t2 = block_sum(c.t2, sh);
+    if (tid == 0) {
+      const double iZ = 1.0 / (zbase + zs);
+      const double S1 = (b1 + t1) * iZ, S2 = (b2 + t2) * iZ;
+      nn += S2 - S1 * S1;
+    }
   }
   nn = block_sum(nn, sh);
   if (tid == 0) partA[blockIdx.x] = nn;
 }
 
 // ---------------------------------------------------------------------------------------
-// Pass B (CSR): per EC Z_j (softmax denominator), r_j = c_j / Z_j, the ELBO data terms
+// Pass B (SELL): per EC Z_j (softmax denominator), r_j = c_j / Z_j, the ELBO data terms
 // and the column sums A_g = sum_j r_j (x_gj - p0) accumulated in an LDS-private table
 // (rcgpar logsumexp + update_N_k + ELBO_rcg_mat in one sweep).
 // ---------------------------------------------------------------------------------------
 template <bool WIDE, bool GLDS, bool TLDS>
 __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int cond_reset,
-                                                       CsrDev S, const double *e_g,
+                                                       SellDev S, const double *e_g,
                                                        const double *tabB_g, double *partAcc,
                                                        double *partS, double *accGlobal) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
   if (sc->done) return;
   if (cond_reset && !sc->reset_pending) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t G = S.n_groups, n_lut = S.n_lut;
   double *sh = reinterpret_cast<double *>(smem);
   double *p = sh + 32;
@@ -379,9 +392,9 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
   double *acc = accGlobal;
   if (GLDS) {
     double *el = p;
-    acc = p + G;
-    p += 2 * (size_t)G;
-    for (uint32_t g = tid; g < G; g += kPassThreads) {
+    acc = p + (G + 1);
+    p += 2 * ((size_t)G + 1);
+    for (uint32_t g = tid; g <= G; g += kPassThreads) {
       el[g] = e_g[g];
       acc[g] = 0.0;
     }
@@ -389,76 +402,83 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
   }
   if (TLDS) {
     double *tl = p;
-    p += 2 * (size_t)n_lut;
     for (uint32_t i = tid; i < 2 * n_lut; i += kPassThreads) tl[i] = tabB_g[i];
     tab = tl;
   }
-  uint32_t *rp = reinterpret_cast<uint32_t *>(p);
-  typename R::T *nzl = reinterpret_cast<typename R::T *>(rp + (kTileRows + 1 + 3) / 4 * 4);
   const double p0 = sc->p0, U = sc->U, logzi = sc->logzi;
   const double zbase = p0 * U, hbase = p0 * logzi * U;
   double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;
   __syncthreads();
 
-  for (uint32_t t = blockIdx.x; t < S.ntiles; t += gridDim.x) {
-    const uint32_t rs = S.tile_row[t], nr = S.tile_row[t + 1] - rs;
-    if ((uint32_t)tid < nr) rp[tid] = S.rowptr[rs + tid];
-    if (tid == 0) rp[nr] = S.rowptr[rs + nr];
-    __syncthreads();
-    const uint32_t n0 = rp[0], nn_t = rp[nr] - n0;
-    if (nn_t <= (uint32_t)kTileCap) {
-      for (uint32_t i = tid; i < nn_t; i += kPassThreads) nzl[i] = R::load(S.rec, n0 + i);
-      __syncthreads();
-      if ((uint32_t)tid < nr) {
-        const uint32_t kb = rp[tid] - n0, ke = rp[tid + 1] - n0;
-        double zs = 0.0, hs = 0.0;
-        for (uint32_t k = kb; k < ke; ++k) {
-          const typename R::T r = nzl[k];
-          const double eg = e_l[R::grp(r)];
-          const uint32_t i = R::idx(r);
-          zs += eg * tab[2 * i];
-          hs += eg * tab[2 * i + 1];
-        }
-        const double Z = zbase + zs, H = hbase + hs;
-        const double c = S.cvec[rs + tid];
-        if (c != 0.0) {
-          const double rj = c / Z;
-          s_clogZ += c * log(Z);
-          s_rH += rj * H;
-          s_W += rj;
-          for (uint32_t k = kb; k < ke; ++k) {
-            const typename R::T r = nzl[k];
-            atomicAdd(&acc[R::grp(r)], rj * tab[2 * R::idx(r)]);
-          }
-        }
-      }
-    } else {
-      double zs = 0.0, hs = 0.0;
-      for (uint32_t k = tid; k < nn_t; k += kPassThreads) {
-        const typename R::T r = R::load(S.rec, n0 + k);
-        const double eg = e_l[R::grp(r)];
-        const uint32_t i = R::idx(r);
-        zs += eg * tab[2 * i];
-        hs += eg * tab[2 * i + 1];
-      }
-      zs = block_sum(zs, sh);
-      hs = block_sum(hs, sh);
-      const double Z = zbase + zs, H = hbase + hs;
-      const double c = S.cvec[rs];
+  const uint32_t n_sell = S.n_ecs - S.n_long;
+  const uint32_t gw = blockIdx.x * (kPassThreads / 64) + (tid >> 6), nw = gridDim.x * (kPassThreads / 64);
+  for (uint32_t s = gw; s < S.nslices; s += nw) {
+    const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;
+    const size_t base = (size_t)o0 * 64 + lane;
+    double zs = 0.0, hs = 0.0;
+    uint32_t k = 0;
+    for (; k + 4 <= len; k += 4) {
+      const typename R::T r0 = R::load(S.rec, base + (size_t)k * 64);
+      const typename R::T r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
+      const typename R::T r2 = R::load(S.rec, base + (size_t)(k + 2) * 64);
+      const typename R::T r3 = R::load(S.rec, base + (size_t)(k + 3) * 64);
+      const double e0 = e_l[R::grp(r0)], e1 = e_l[R::grp(r1)], e2 = e_l[R::grp(r2)], e3 = e_l[R::grp(r3)];
+      const double2 t0 = *reinterpret_cast<const double2 *>(tab + 2 * R::idx(r0));
+      const double2 t1 = *reinterpret_cast<const double2 *>(tab + 2 * R::idx(r1));
+      const double2 t2 = *reinterpret_cast<const double2 *>(tab + 2 * R::idx(r2));
+      const double2 t3 = *reinterpret_cast<const double2 *>(tab + 2 * R::idx(r3));
+      zs += e0 * t0.x; hs += e0 * t0.y;
+      zs += e1 * t1.x; hs += e1 * t1.y;
+      zs += e2 * t2.x; hs += e2 * t2.y;
+      zs += e3 * t3.x; hs += e3 * t3.y;
+    }
+    for (; k < len; ++k) {
+      const typename R::T r = R::load(S.rec, base + (size_t)k * 64);
+      const double eg = e_l[R::grp(r)];
+      const double2 t = *reinterpret_cast<const double2 *>(tab + 2 * R::idx(r));
+      zs += eg * t.x;
+      hs += eg * t.y;
+    }
+    const uint32_t q = s * 64 + lane;
+    if (q < n_sell) {
+      const double c = S.cvec[S.n_long + q];
       if (c != 0.0) {
+        const double Z = zbase + zs, H = hbase + hs;
         const double rj = c / Z;
-        if (tid == 0) {
-          s_clogZ += c * log(Z);
-          s_rH += rj * H;
-          s_W += rj;
-        }
-        for (uint32_t k = tid; k < nn_t; k += kPassThreads) {
-          const typename R::T r = R::load(S.rec, n0 + k);
+        s_clogZ += c * log(Z);
+        s_rH += rj * H;
+        s_W += rj;
+        for (uint32_t kk = 0; kk < len; ++kk) {
+          const typename R::T r = R::load(S.rec, base + (size_t)kk * 64);
           atomicAdd(&acc[R::grp(r)], rj * tab[2 * R::idx(r)]);
         }
       }
     }
-    __syncthreads();
+  }
+  for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
+    double zs = 0.0, hs = 0.0;
+    for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
+      const typename R::T rc = R::load(S.rec_long, k);
+      const double eg = e_l[R::grp(rc)];
+      zs += eg * tab[2 * R::idx(rc)];
+      hs += eg * tab[2 * R::idx(rc) + 1];
+    }
+    zs = block_sum(zs, sh);
+    hs = block_sum(hs, sh);
+    const double c = S.cvec[r];
+    if (c != 0.0) {
+      const double Z = zbase + zs, H = hbase + hs;
+      const double rj = c / Z;
+      if (tid == 0) {
+        s_clogZ += c * log(Z);
+        s_rH += rj * H;
+        s_W += rj;
+      }
+      for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
+        const typename R::T rc = R::load(S.rec_long, k);
+        atomicAdd(&acc[R::grp(rc)], rj * tab[2 * R::idx(rc)]);
+      }
+    }
   }
   s_clogZ = block_sum(s_clogZ, sh);
   s_rH = block_sum(s_rH, sh);
@@ -588,15 +608,16 @@ __global__ __launch_bounds__(1024) void k_finB(Scalars *sc, int mode, int G, int
 }
 
 // ---------------------------------------------------------------------------------------
-// Solve set-up: c_j = exp(logc_j) (or the bootstrap counts), sum of counts, bound constant
-// (rcgpar calc_bound_const), initial state gamma = log(1/G).
+// Solve set-up: c_j = exp(logc_j) (or the bootstrap counts) gathered into the permuted EC
+// order, sum of counts, bound constant (rcgpar calc_bound_const), initial gamma = log(1/G).
+// perm == nullptr: identity (dense flavour).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cvec_from_logc(const double *logc, uint32_t E, double *cvec,
-                                                       double *part) {
+__global__ __launch_bounds__(256) void k_cvec_from_logc(const double *logc, const uint32_t *perm,
+                                                       uint32_t E, double *cvec, double *part) {
   __shared__ double sh[32];
   double s = 0.0;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < E; j += gridDim.x * blockDim.x) {
-    const double c = exp(logc[j]);
+    const double c = exp(logc[perm ? perm[j] : j]);
     cvec[j] = c;
     s += c;
   }
@@ -604,12 +625,12 @@ __global__ __launch_bounds__(256) void k_cvec_from_logc(const double *logc, uint
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(256) void k_cvec_from_counts(const uint32_t *cnt, uint32_t E, double *cvec,
-                                                         double *part) {
+__global__ __launch_bounds__(256) void k_cvec_from_counts(const uint32_t *cnt, const uint32_t *perm,
+                                                         uint32_t E, double *cvec, double *part) {
   __shared__ double sh[32];
   double s = 0.0;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < E; j += gridDim.x * blockDim.x) {
-    const double c = (double)cnt[j];
+    const double c = (double)cnt[perm ? perm[j] : j];
     cvec[j] = c;
     s += c;
   }
@@ -812,17 +833,16 @@ __global__ __launch_bounds__(256) void k_transpose(const double *src, size_t ld,
 }
 
 // ---------------------------------------------------------------------------------------
-// gamma materialisation (K6): gamma(g, j) = a*L(g, j) + u_g - lse_j, rows = groups.
-// With (a, u, sub_lse) = (1, 0, false) the same kernels expand the resident likelihood.
+// gamma materialisation (K6): gamma(g, j) = a*L(g, j) + u_g - lse_j, rows = groups, columns in
+// the ORIGINAL EC order.  With (a, u, lse) = (1, 0, none) the same kernels expand the resident
+// likelihood.  Utility kernels, not on the timed path.
 // ---------------------------------------------------------------------------------------
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_lse_csr(CsrDev S, double a, double logzi, const double *u,
-                                                const double *lut, double *lse) {
-  // straightforward one-thread-per-EC evaluation (not on the timed path)
+__global__ __launch_bounds__(256) void k_lse_sell(SellDev S, double a, double logzi, const double *u,
+                                                 const double *lut, double *lse /*original order*/) {
   using R = Rec<WIDE>;
   __shared__ double sh[32];
   const int tid = threadIdx.x;
-  // M, U recomputed per block (G is small)
   double m = -INFINITY;
   for (uint32_t g = tid; g < S.n_groups; g += blockDim.x) m = fmax(m, u[g]);
   const double M = block_max(m, sh);
@@ -830,13 +850,12 @@ __global__ __launch_bounds__(256) void k_lse_csr(CsrDev S, double a, double logz
   for (uint32_t g = tid; g < S.n_groups; g += blockDim.x) su += exp(u[g] - M);
   const double U = block_sum(su, sh);
   const double p0 = exp(a * logzi);
-  for (uint32_t j = blockIdx.x * blockDim.x + tid; j < S.n_ecs; j += gridDim.x * blockDim.x) {
+  for (uint32_t p = blockIdx.x * blockDim.x + tid; p < S.n_ecs; p += gridDim.x * blockDim.x) {
     double zs = 0.0;
-    for (uint32_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
-      const typename R::T r = R::load(S.rec, k);
+    for_each_cell<WIDE>(S, p, [&](typename R::T r) {
       zs += exp(u[R::grp(r)] - M) * (exp(a * lut[R::idx(r)]) - p0);
-    }
-    lse[j] = M + log(p0 * U + zs);
+    });
+    lse[S.perm[p]] = M + log(p0 * U + zs);
   }
 }
 
@@ -851,19 +870,19 @@ __global__ __launch_bounds__(256) void k_gamma_fill(double *out, size_t ld, int 
 }
 
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_gamma_scatter(CsrDev S, double *out, size_t ld, int g_begin,
+__global__ __launch_bounds__(256) void k_gamma_scatter(SellDev S, double *out, size_t ld, int g_begin,
                                                       int g_end, double a, const double *u,
                                                       const double *lut, const double *lse) {
   using R = Rec<WIDE>;
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= S.n_ecs) return;
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= S.n_ecs) return;
+  const uint32_t j = S.perm[p];
   const double l = lse ? lse[j] : 0.0;
-  for (uint32_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
-    const typename R::T r = R::load(S.rec, k);
+  for_each_cell<WIDE>(S, p, [&](typename R::T r) {
     const int g = (int)R::grp(r);
     if (g >= g_begin && g < g_end)
       out[(size_t)(g - g_begin) * ld + j] = a * lut[R::idx(r)] + u[g] - l;
-  }
+  });
 }
 
 // dense flavour: gamma from Lt (EC-major) -> rows = groups slab [g_begin, g_end)

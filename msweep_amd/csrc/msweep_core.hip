@@ -37,18 +37,19 @@ struct msw_core {
 
   // ---- resident likelihood -----------------------------------------------------------
   int flavor = -1;  // -1 none, 0 CSR-of-ECs, 1 dense
-  uint32_t G = 0, E = 0, n_lut = 0, ntiles = 0;
-  uint64_t nnz = 0;
+  uint32_t G = 0, E = 0, n_lut = 0, nslices = 0, n_long = 0;
+  uint64_t nnz = 0, nslots = 0;
   bool wide = false, glds = true, tlds = true;
   double logzi = 0.0;
-  DevBuf<uint32_t> rowptr, rec, tile_row;
+  DevBuf<uint32_t> rec, slice_off, long_ptr, rec_long, perm;
   DevBuf<double> lut, Lt;
   int nblk = 0;      // persistent workgroups of the CSR sweeps
   int nblk_dense = 0;
   int nreg = 0;
 
   // ---- solve state ---------------------------------------------------------------------
-  DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, wc, e, N, Nc, Acc, tabA, tabB;
+  DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc, tabA, tabB;
+  DevBuf<double2> ew;
   DevBuf<double> partA, partS, partAcc, partC;
   DevBuf<Scalars> sc;
   Scalars *sc_host = nullptr;  // pinned
@@ -114,13 +115,16 @@ std::pair<hipEvent_t, hipEvent_t> &next_pair(std::vector<std::pair<hipEvent_t, h
   return v[used++];
 }
 
-CsrDev csr_view(msw_core *h) {
-  CsrDev S;
-  S.rowptr = h->rowptr.p;
+SellDev sell_view(msw_core *h) {
+  SellDev S;
   S.rec = h->rec.p;
-  S.tile_row = h->tile_row.p;
+  S.slice_off = h->slice_off.p;
+  S.long_ptr = h->long_ptr.p;
+  S.rec_long = h->rec_long.p;
+  S.perm = h->perm.p;
   S.cvec = h->cvec.p;
-  S.ntiles = h->ntiles;
+  S.nslices = h->nslices;
+  S.n_long = h->n_long;
   S.n_ecs = h->E;
   S.n_groups = h->G;
   S.n_lut = h->n_lut;
@@ -130,8 +134,8 @@ CsrDev csr_view(msw_core *h) {
 void choose_lds_mode(msw_core *h) {
   const bool opts[4][2] = {{true, true}, {true, false}, {false, true}, {false, false}};
   for (auto &o : opts) {
-    const size_t a = pass_lds_bytes(h->wide, o[0], o[1], h->G, h->n_lut, 3);
-    const size_t b = pass_lds_bytes(h->wide, o[0], o[1], h->G, h->n_lut, 2);
+    const size_t a = pass_lds_bytes(o[0], o[1], h->G, h->n_lut, true);
+    const size_t b = pass_lds_bytes(o[0], o[1], h->G, h->n_lut, false);
     if (std::max(a, b) <= kLdsMax) {
       h->glds = o[0];
       h->tlds = o[1];
@@ -143,12 +147,16 @@ void choose_lds_mode(msw_core *h) {
 
 void alloc_solve_state(msw_core *h) {
   const uint32_t G = h->G, E = h->E;
-  for (DevBuf<double> *b : {&h->alpha0, &h->u, &h->os_u, &h->step_u, &h->w, &h->wc, &h->e, &h->N,
-                            &h->Nc, &h->Acc, &h->logth})
-    b->alloc(G);
+  for (DevBuf<double> *b : {&h->alpha0, &h->u, &h->os_u, &h->step_u, &h->w, &h->e, &h->N, &h->Nc,
+                            &h->Acc, &h->logth})
+    b->alloc((size_t)G + 1);
+  h->ew.alloc((size_t)G + 1);
+  // slot G of e / ew is the sentinel group of SELL padding records: zero, never rewritten
+  h->e.zero(h->stream);
+  h->ew.zero(h->stream);
   h->cvec.alloc(E);
   h->logc_d.alloc(E);
-  h->tabA.alloc(3 * (size_t)std::max<uint32_t>(h->n_lut, 1));
+  h->tabA.alloc(4 * (size_t)std::max<uint32_t>(h->n_lut, 1));
   h->tabB.alloc(2 * (size_t)std::max<uint32_t>(h->n_lut, 1));
   const int nb = std::max(h->nblk, h->nblk_dense);
   h->partA.alloc(std::max(nb, 1024));
@@ -170,19 +178,19 @@ void alloc_solve_state(msw_core *h) {
 // ---- launch helpers for the templated sweeps ----------------------------------------------
 template <bool W, bool GL, bool TL>
 void launch_passA_t(msw_core *h) {
-  const size_t lds = pass_lds_bytes(W, GL, TL, h->G, h->n_lut, 3);
+  const size_t lds = pass_lds_bytes(GL, TL, h->G, h->n_lut, true);
   auto k = k_passA<W, GL, TL>;
   MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, csr_view(h),
-                     h->e.p, h->wc.p, h->tabA.p, h->partA.p);
+  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h),
+                     h->ew.p, h->tabA.p, h->partA.p);
 }
 template <bool W, bool GL, bool TL>
 void launch_passB_t(msw_core *h, int cond) {
-  const size_t lds = pass_lds_bytes(W, GL, TL, h->G, h->n_lut, 2);
+  const size_t lds = pass_lds_bytes(GL, TL, h->G, h->n_lut, false);
   auto k = k_passB<W, GL, TL>;
   MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, cond,
-                     csr_view(h), h->e.p, h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p);
+                     sell_view(h), h->e.p, h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p);
 }
 
 #define MSW_DISPATCH3(fn, ...)                                                       \
@@ -242,7 +250,7 @@ void launch_passB(msw_core *h, int cond) {
     MSW_HIP(hipEventRecord(ev->first, h->stream));
   }
   if (h->flavor == 0) {
-    if (!h->glds) MSW_HIP(hipMemsetAsync(h->Acc.p, 0, h->G * sizeof(double), h->stream));
+    if (!h->glds) MSW_HIP(hipMemsetAsync(h->Acc.p, 0, ((size_t)h->G + 1) * sizeof(double), h->stream));
     MSW_DISPATCH3(launch_passB_t, h, cond);
   } else {
     MSW_DISPATCH_NREG(launch_dense_B, h, cond);
@@ -280,12 +288,12 @@ void prepare_inputs(msw_core *h, const double *logc_host, const uint32_t *counts
   if (h->flavor < 0) throw Fail("no likelihood resident: call msw_core_set_csr / set_dense_logl first");
   const uint32_t E = h->E, G = h->G;
   if (counts_dev) {
-    hipLaunchKernelGGL(k_cvec_from_counts, dim3(kCvecBlocks), dim3(256), 0, h->stream, counts_dev, E,
-                       h->cvec.p, h->partC.p);
+    hipLaunchKernelGGL(k_cvec_from_counts, dim3(kCvecBlocks), dim3(256), 0, h->stream, counts_dev,
+                       h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->partC.p);
   } else {
     MSW_HIP(hipMemcpyAsync(h->logc_d.p, logc_host, E * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_cvec_from_logc, dim3(kCvecBlocks), dim3(256), 0, h->stream, h->logc_d.p, E,
-                       h->cvec.p, h->partC.p);
+    hipLaunchKernelGGL(k_cvec_from_logc, dim3(kCvecBlocks), dim3(256), 0, h->stream, h->logc_d.p,
+                       h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->partC.p);
   }
   if (alpha0_host)
     MSW_HIP(hipMemcpyAsync(h->alpha0.p, alpha0_host, G * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -322,7 +330,7 @@ void run_rcg(msw_core *h, size_t max_iters) {
     const size_t batch = std::min<size_t>(kIterBatch, max_iters - enq);
     for (size_t b = 0; b < batch; ++b) {
       hipLaunchKernelGGL(k_prepA, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->N.p,
-                         h->u.p, h->lut.p, h->w.p, h->e.p, h->wc.p, h->tabA.p);
+                         h->u.p, h->lut.p, h->w.p, h->e.p, h->ew.p, h->tabA.p);
       launch_passA(h);
       hipLaunchKernelGGL(k_step, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, nbA,
                          h->partA.p, h->w.p, h->u.p, h->os_u.p, h->step_u.p, h->lut.p, h->e.p,
@@ -371,8 +379,10 @@ void collect_timing(msw_core *h) {
   h->timing.iters = (uint64_t)h->sc_host->iter;
   const uint64_t recsz = h->wide ? 8 : 4;
   if (h->flavor == 0) {
-    h->timing.bytes_passA = h->nnz * recsz + 4ull * (h->E + 1);
-    h->timing.bytes_passB = h->nnz * recsz + 4ull * (h->E + 1) + 8ull * h->E;
+    // algorithmic bytes: every real cell record once + the per-EC count vector in
+    // pass B; SELL padding, slice offsets and the L2-served second read of pass B are not counted
+    h->timing.bytes_passA = h->nnz * recsz;
+    h->timing.bytes_passB = h->nnz * recsz + 8ull * h->E;
   } else {
     h->timing.bytes_passA = 8ull * h->E * h->G;
     h->timing.bytes_passB = 8ull * h->E * h->G + 8ull * h->E;

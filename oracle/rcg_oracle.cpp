@@ -70,6 +70,10 @@ inline double bound_const_of(const double *logc, size_t E, const double *alpha0,
 }
 
 // ---- dense-state pieces, rows = groups ---------------------------------------------
+// Loop structure as in rcgpar: serial over groups, OpenMP over ECs.  Each function opens ONE
+// parallel region; the inner `omp for schedule(static) nowait` gives every thread the same EC
+// range for every group, so no barrier is needed between groups (per-EC scratch is only touched
+// by its owner thread).  Same arithmetic per element as one region per group.
 struct Dense {
   size_t G, E;
   const double *L;
@@ -78,68 +82,88 @@ struct Dense {
 
   // rcgpar logsumexp(gamma_Z, m): m_j = logsumexp over groups; gamma -= m
   void logsumexp(double *gamma, double *m) const {
-#pragma omp parallel for schedule(static)
-    for (size_t j = 0; j < E; ++j) {
-      double mx = -std::numeric_limits<double>::infinity();
-      for (size_t g = 0; g < G; ++g) mx = std::max(mx, gamma[g * E + j]);
-      double s = 0.0;
-      for (size_t g = 0; g < G; ++g) s += std::exp(gamma[g * E + j] - mx);
-      m[j] = mx + std::log(s);
-    }
-    for (size_t g = 0; g < G; ++g) {
-#pragma omp parallel for schedule(static)
-      for (size_t j = 0; j < E; ++j) gamma[g * E + j] -= m[j];
+#pragma omp parallel
+    {
+#pragma omp for schedule(static)
+      for (size_t j = 0; j < E; ++j) {
+        double mx = -std::numeric_limits<double>::infinity();
+        for (size_t g = 0; g < G; ++g) mx = std::max(mx, gamma[g * E + j]);
+        double s = 0.0;
+        for (size_t g = 0; g < G; ++g) s += std::exp(gamma[g * E + j] - mx);
+        m[j] = mx + std::log(s);
+      }
+      for (size_t g = 0; g < G; ++g) {
+#pragma omp for schedule(static) nowait
+        for (size_t j = 0; j < E; ++j) gamma[g * E + j] -= m[j];
+      }
     }
   }
 
   // rcgpar mixt_negnatgrad: fills step (dL_dphi) and returns newnorm
   double negnatgrad(const double *gamma, const double *N, double *step, int weighted) const {
     std::vector<double> colsums(E, 0.0);
-    for (size_t g = 0; g < G; ++g) {
-      const double dg = orc_digamma(N[g]) - 1.0;
-#pragma omp parallel for schedule(static)
-      for (size_t j = 0; j < E; ++j) {
-        double s = L[g * E + j];
-        s += dg - gamma[g * E + j];
-        step[g * E + j] = s;
-        colsums[j] += s * std::exp(gamma[g * E + j]);
-      }
-    }
+    std::vector<double> dg(G);
+    for (size_t g = 0; g < G; ++g) dg[g] = orc_digamma(N[g]) - 1.0;
     double newnorm = 0.0;
-    for (size_t g = 0; g < G; ++g) {
-#pragma omp parallel for schedule(static) reduction(+ : newnorm)
-      for (size_t j = 0; j < E; ++j) {
-        double t = std::exp(gamma[g * E + j]) * (step[g * E + j] - colsums[j]) * step[g * E + j];
-        if (weighted) t *= std::exp(logc[j]);
-        newnorm += t;
+#pragma omp parallel
+    {
+      for (size_t g = 0; g < G; ++g) {
+#pragma omp for schedule(static) nowait
+        for (size_t j = 0; j < E; ++j) {
+          double s = L[g * E + j];
+          s += dg[g] - gamma[g * E + j];
+          step[g * E + j] = s;
+          colsums[j] += s * std::exp(gamma[g * E + j]);
+        }
       }
+      double local = 0.0;
+      for (size_t g = 0; g < G; ++g) {
+#pragma omp for schedule(static) nowait
+        for (size_t j = 0; j < E; ++j) {
+          double t = std::exp(gamma[g * E + j]) * (step[g * E + j] - colsums[j]) * step[g * E + j];
+          if (weighted) t *= std::exp(logc[j]);
+          local += t;
+        }
+      }
+#pragma omp atomic
+      newnorm += local;
     }
     return newnorm;
   }
 
   void update_N(const double *gamma, double *N) const {
-    for (size_t g = 0; g < G; ++g) {
-      double acc = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : acc)
-      for (size_t j = 0; j < E; ++j) acc += std::exp(gamma[g * E + j] + logc[j]);
-      N[g] = acc + alpha0[g];
+    for (size_t g = 0; g < G; ++g) N[g] = 0.0;
+#pragma omp parallel
+    {
+      for (size_t g = 0; g < G; ++g) {
+        double acc = 0.0;
+#pragma omp for schedule(static) nowait
+        for (size_t j = 0; j < E; ++j) acc += std::exp(gamma[g * E + j] + logc[j]);
+#pragma omp atomic
+        N[g] += acc;
+      }
     }
+    for (size_t g = 0; g < G; ++g) N[g] += alpha0[g];
   }
 
   long double elbo(const double *gamma, const double *N, long double bound_const) const {
     long double bound = bound_const;
-    for (size_t g = 0; g < G; ++g) {
+#pragma omp parallel
+    {
       long double acc = 0.0L;
-#pragma omp parallel for schedule(static) reduction(+ : acc)
-      for (size_t j = 0; j < E; ++j) {
-        const double gz = gamma[g * E + j];
-        const double w = std::exp(gz + logc[j]);
-        // 0 * (finite) = 0 for zero-count ECs (logc = -inf in bootstrap replicates)
-        acc += (w == 0.0) ? 0.0 : w * (L[g * E + j] - gz);
+      for (size_t g = 0; g < G; ++g) {
+#pragma omp for schedule(static) nowait
+        for (size_t j = 0; j < E; ++j) {
+          const double gz = gamma[g * E + j];
+          const double w = std::exp(gz + logc[j]);
+          // 0 * (finite) = 0 for zero-count ECs (logc = -inf in bootstrap replicates)
+          acc += (w == 0.0) ? 0.0 : w * (L[g * E + j] - gz);
+        }
       }
+#pragma omp critical
       bound += acc;
-      bound += std::lgamma(N[g]);
     }
+    for (size_t g = 0; g < G; ++g) bound += std::lgamma(N[g]);
     return bound;
   }
 };
@@ -210,8 +234,9 @@ size_t orc_rcg_optl_dense(const double *logl, size_t G, size_t E, const double *
     if (bound < oldbound) {
       didreset = true;
       // revert_step: undo the normalisation, then drop the conjugate part
+#pragma omp parallel
       for (size_t g = 0; g < G; ++g) {
-#pragma omp parallel for schedule(static)
+#pragma omp for schedule(static) nowait
         for (size_t j = 0; j < E; ++j) gamma[g * E + j] += oldm[j];
       }
       if (beta_FR > 0) {
@@ -239,12 +264,16 @@ void orc_mixture_components(const double *gamma, size_t G, size_t E, const doubl
                             double *theta) {
   double total = 0.0;
   for (size_t j = 0; j < E; ++j) total += std::exp(logc[j]);
+  for (size_t g = 0; g < G; ++g) theta[g] = 0.0;
+#pragma omp parallel
   for (size_t g = 0; g < G; ++g) {
     double acc = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : acc)
+#pragma omp for schedule(static) nowait
     for (size_t j = 0; j < E; ++j) acc += std::exp(gamma[g * E + j] + logc[j]);
-    theta[g] = acc / total;
+#pragma omp atomic
+    theta[g] += acc;
   }
+  for (size_t g = 0; g < G; ++g) theta[g] /= total;
 }
 
 }  // extern "C"
