@@ -1,0 +1,164 @@
+// dense_kernels.hpp -- sweeps for a dense likelihood (--read-likelihood path) and the transpose.
+#pragma once
+#include "device_util.hpp"
+
+namespace msw {
+
+// ---------------------------------------------------------------------------------------
+// Dense-L kernels.  L is kept EC-major on the device (Lt[j*G + g]) so that a wavefront
+// streams one EC's G values with coalesced loads; lane l owns groups l, l+64, ... and
+// keeps their u_g / w_g / column-sum accumulators in registers (no atomics).
+// ---------------------------------------------------------------------------------------
+template <int NREG>
+__global__ __launch_bounds__(256) void k_dense_passA(const Scalars *sc, const double *Lt, int G,
+                                                    uint32_t E, const double *u, const double *w,
+                                                    double *partA) {
+  __shared__ double sh[32];
+  if (sc->done) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
+  const double a = sc->a, oma = 1.0 - a;
+  double uu[NREG], ww[NREG];
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const int g = lane + 64 * i;
+    uu[i] = g < G ? u[g] : 0.0;
+    ww[i] = g < G ? w[g] : 0.0;
+  }
+  double nn = 0.0;
+  for (uint32_t j = gw; j < E; j += nw) {
+    const double *row = Lt + (size_t)j * G;
+    double pz[NREG], s[NREG];
+    double m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int g = lane + 64 * i;
+      const double x = g < G ? row[g] : 0.0;
+      pz[i] = g < G ? a * x + uu[i] : -INFINITY;
+      s[i] = oma * x + ww[i];
+      m = fmax(m, pz[i]);
+    }
+    m = wave_max(m);
+    double Z = 0.0, S1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int g = lane + 64 * i;
+      const double pe = g < G ? exp(pz[i] - m) : 0.0;
+      pz[i] = pe;
+      Z += pe;
+      S1 += pe * s[i];
+    }
+    Z = wave_sum(Z);
+    S1 = wave_sum(S1);
+    const double iZ = 1.0 / Z, sbar = S1 * iZ;
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const double d = s[i] - sbar;
+      v += pz[i] * d * d;
+    }
+    v = wave_sum(v);
+    nn += v * iZ;
+  }
+  // every lane of a wave holds the same nn; take lane 0 of each wave
+  double t = (lane == 0) ? nn : 0.0;
+  t = block_sum(t, sh);
+  if (threadIdx.x == 0) partA[blockIdx.x] = t;
+}
+
+template <int NREG>
+__global__ __launch_bounds__(256) void k_dense_passB(const Scalars *sc, int cond_reset,
+                                                    const double *Lt, int G, uint32_t E,
+                                                    const double *cvec, const double *u,
+                                                    double *partAcc, double *partS) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double *sh = reinterpret_cast<double *>(smem);
+  double *accl = sh + 32;  // [4][G]
+  if (sc->done) return;
+  if (cond_reset && !sc->reset_pending) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
+  const double a = sc->a;
+  double uu[NREG], acc[NREG];
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const int g = lane + 64 * i;
+    uu[i] = g < G ? u[g] : 0.0;
+    acc[i] = 0.0;
+  }
+  double s_clogZ = 0.0, s_rH = 0.0;
+  for (uint32_t j = gw; j < E; j += nw) {
+    const double *row = Lt + (size_t)j * G;
+    double x[NREG], pz[NREG];
+    double m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int g = lane + 64 * i;
+      x[i] = g < G ? row[g] : 0.0;
+      pz[i] = g < G ? a * x[i] + uu[i] : -INFINITY;
+      m = fmax(m, pz[i]);
+    }
+    m = wave_max(m);
+    double Z = 0.0, hs = 0.0;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int g = lane + 64 * i;
+      const double y = pz[i] - m;
+      const double pe = g < G ? exp(y) : 0.0;
+      hs += g < G ? pe * (x[i] - y) : 0.0;
+      pz[i] = pe;
+      Z += pe;
+    }
+    Z = wave_sum(Z);
+    hs = wave_sum(hs);
+    const double c = cvec[j];
+    if (c != 0.0) {
+      const double rj = c / Z;
+      s_clogZ += c * log(Z);
+      s_rH += rj * hs;
+#pragma unroll
+      for (int i = 0; i < NREG; ++i) acc[i] += rj * pz[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const int g = lane + 64 * i;
+    if (g < G) accl[wv * G + g] = acc[i];
+  }
+  double t1 = (lane == 0) ? s_clogZ : 0.0, t2 = (lane == 0) ? s_rH : 0.0;
+  t1 = block_sum(t1, sh);
+  t2 = block_sum(t2, sh);
+  if (threadIdx.x == 0) {
+    partS[4 * blockIdx.x + 0] = t1;
+    partS[4 * blockIdx.x + 1] = t2;
+    partS[4 * blockIdx.x + 2] = 0.0;
+    partS[4 * blockIdx.x + 3] = 0.0;
+  }
+  __syncthreads();
+  double *dst = partAcc + (size_t)blockIdx.x * G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x)
+    dst[g] = ((accl[g] + accl[G + g]) + accl[2 * G + g]) + accl[3 * G + g];
+}
+
+// [G][E] (ld) -> [E][G] transpose through LDS, 64 x 64 tiles, 256 threads.
+__global__ __launch_bounds__(256) void k_transpose(const double *src, size_t ld, int G, uint32_t E,
+                                                  double *dst) {
+  __shared__ double tile[64][65];
+  const uint32_t j0 = blockIdx.x * 64;
+  const int g0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int g = g0 + r;
+    const uint32_t j = j0 + tx;
+    tile[r][tx] = (g < G && j < E) ? src[(size_t)g * ld + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const uint32_t j = j0 + r;
+    const int g = g0 + tx;
+    if (g < G && j < E) dst[(size_t)j * G + g] = tile[tx][r];
+  }
+}
+
+
+}  // namespace msw

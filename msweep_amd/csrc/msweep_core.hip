@@ -12,6 +12,7 @@
 #include <limits>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -48,9 +49,9 @@ struct msw_core {
   int nreg = 0;
 
   // ---- solve state ---------------------------------------------------------------------
-  DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc, tabA, tabB;
+  DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc, tabB;
   DevBuf<double2> ew;
-  DevBuf<double> partA, partS, partAcc, partC;
+  DevBuf<double> partA, partS, partAcc, partC, partR;
   DevBuf<Scalars> sc;
   Scalars *sc_host = nullptr;  // pinned
   DevBuf<double> tr_bound, tr_newnorm, tr_beta, tr_theta;
@@ -156,11 +157,11 @@ void alloc_solve_state(msw_core *h) {
   h->ew.zero(h->stream);
   h->cvec.alloc(E);
   h->logc_d.alloc(E);
-  h->tabA.alloc(4 * (size_t)std::max<uint32_t>(h->n_lut, 1));
-  h->tabB.alloc(2 * (size_t)std::max<uint32_t>(h->n_lut, 1));
+  h->tabB.alloc((size_t)std::max<uint32_t>(h->n_lut, 1));
   const int nb = std::max(h->nblk, h->nblk_dense);
   h->partA.alloc(std::max(nb, 1024));
   h->partS.alloc(4 * (size_t)std::max(nb, 1024));
+  h->partR.alloc(2 * ((size_t)G / 64 + 2));
   h->partAcc.alloc((size_t)std::max(nb, 1) * G);
   h->partC.alloc(1024);
   h->sc.alloc(1);
@@ -182,7 +183,7 @@ void launch_passA_t(msw_core *h) {
   auto k = k_passA<W, GL, TL>;
   MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h),
-                     h->ew.p, h->tabA.p, h->partA.p);
+                     h->ew.p, h->tabB.p, h->lut.p, h->partA.p);
 }
 template <bool W, bool GL, bool TL>
 void launch_passB_t(msw_core *h, int cond) {
@@ -190,7 +191,7 @@ void launch_passB_t(msw_core *h, int cond) {
   auto k = k_passB<W, GL, TL>;
   MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, cond,
-                     sell_view(h), h->e.p, h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p);
+                     sell_view(h), h->e.p, h->tabB.p, h->lut.p, h->partAcc.p, h->partS.p, h->Acc.p);
 }
 
 #define MSW_DISPATCH3(fn, ...)                                                       \
@@ -258,21 +259,20 @@ void launch_passB(msw_core *h, int cond) {
   MSW_HIP(hipGetLastError());
   if (ev) MSW_HIP(hipEventRecord(ev->second, h->stream));
   if (!cond) h->timing.passB_launches++;
-  // column sums across workgroups
-  const bool need_red = (h->flavor == 1) || h->glds;
-  if (need_red) {
-    const int nb = h->flavor == 0 ? h->nblk : h->nblk_dense;
-    hipLaunchKernelGGL(k_redB, dim3((h->G + 255) / 256), dim3(256), 0, h->stream, h->sc.p, cond,
-                       (int)h->G, nb, h->partAcc.p, h->Acc.p);
-  }
+  // column sums across workgroups + N_g / lgamma / digamma, spread over G/64 workgroups
+  const bool partials = (h->flavor == 1) || h->glds;
+  const int nb = h->flavor == 0 ? h->nblk : h->nblk_dense;
+  hipLaunchKernelGGL(k_redfin, dim3((h->G + 63) / 64), dim3(256), 0, h->stream, h->sc.p, cond, (int)h->G,
+                     partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->e.p, h->u.p,
+                     h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->partR.p);
 }
 
-void launch_finB(msw_core *h, int mode) {
+void launch_fin(msw_core *h, int mode) {
   TraceDev tr{h->tr_bound.p, h->tr_newnorm.p, h->tr_beta.p, h->tr_theta.p, h->tr_reset.p};
   const int nb = h->flavor == 0 ? h->nblk : h->nblk_dense;
-  hipLaunchKernelGGL(k_finB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G,
-                     (int)h->n_lut, nb, h->partS.p, h->Acc.p, h->alpha0.p, h->u.p, h->os_u.p,
-                     h->step_u.p, h->lut.p, h->e.p, h->tabB.p, h->Nc.p, h->N.p, tr);
+  hipLaunchKernelGGL(k_fin, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G, (int)h->n_lut,
+                     nb, (int)((h->G + 63) / 64), h->partS.p, h->partR.p, h->Nc.p, h->w.p, h->u.p,
+                     h->os_u.p, h->step_u.p, h->lut.p, h->e.p, h->tabB.p, h->ew.p, tr);
 }
 
 void poll(msw_core *h) {
@@ -323,22 +323,20 @@ void run_rcg(msw_core *h, size_t max_iters) {
   launch_passB(h, 0);
   h->timing.passB_launches--;  // the initial evaluation is not an iteration
   if (h->profiling && h->evB_used) h->evB_used--;
-  launch_finB(h, 2);
+  launch_fin(h, 2);
   size_t enq = 0;
   const int nbA = h->flavor == 0 ? h->nblk : h->nblk_dense;
   while (enq < max_iters) {
     const size_t batch = std::min<size_t>(kIterBatch, max_iters - enq);
     for (size_t b = 0; b < batch; ++b) {
-      hipLaunchKernelGGL(k_prepA, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->N.p,
-                         h->u.p, h->lut.p, h->w.p, h->e.p, h->ew.p, h->tabA.p);
       launch_passA(h);
       hipLaunchKernelGGL(k_step, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, nbA,
                          h->partA.p, h->w.p, h->u.p, h->os_u.p, h->step_u.p, h->lut.p, h->e.p,
                          h->tabB.p);
       launch_passB(h, 0);
-      launch_finB(h, 0);
+      launch_fin(h, 0);
       launch_passB(h, 1);
-      launch_finB(h, 1);
+      launch_fin(h, 1);
     }
     MSW_HIP(hipGetLastError());
     enq += batch;

@@ -1,0 +1,285 @@
+// sweep_kernels.hpp -- the two HBM-streaming sweeps of one RCG iteration over the SELL-64
+// likelihood: pass A (natural-gradient norm) and pass B (softmax / column sums / ELBO).
+#pragma once
+#include "device_util.hpp"
+#include "sell.hpp"
+
+namespace msw {
+
+// ---------------------------------------------------------------------------------------
+// Pass A (SELL): newnorm = sum_j Var_{q_j}(step_.j), q_j = softmax_g(a*L + u),
+// step_gj = (1-a)*L_gj + w_g  (+ an irrelevant per-EC constant).
+// One persistent 1024-thread workgroup per CU; its 16 wavefronts take slices round-robin.
+// ---------------------------------------------------------------------------------------
+struct AccA {
+  double zs, t1, t2;
+};
+struct CstA {
+  double p0, oma, oma2, p0l, p0l2;  // p0, (1-a), (1-a)^2, p0*logzi, p0*logzi^2
+};
+__device__ __forceinline__ void cellA(AccA &c, const CstA &k, const double2 ew, const double x,
+                                      const double T) {
+  const double xm = x - k.p0;
+  const double xT = x * T;
+  const double A1 = k.oma * (xT - k.p0l);
+  const double A2 = k.oma2 * (xT * T - k.p0l2);
+  const double wx = ew.y * xm;
+  c.zs += ew.x * xm;
+  c.t1 += ew.x * (A1 + wx);
+  c.t2 += ew.x * (A2 + ew.y * (2.0 * A1 + wx));
+}
+
+template <bool WIDE, bool GLDS, bool TLDS>
+__global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellDev S,
+                                                       const double2 *ew_g, const double *X_g,
+                                                       const double *T_g, double *partA) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using R = Rec<WIDE>;
+  if (sc->done) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t G = S.n_groups, n_lut = S.n_lut;
+  double *sh = reinterpret_cast<double *>(smem);
+  double *p = sh + 32;
+  // group vectors as two 8-byte arrays in LDS (same bank rule as pass B: group id mod 32)
+  const double *X = X_g, *T = T_g;
+  double *e_l = p, *w_l = p + (G + 1);
+  if (GLDS) {
+    p += 2 * ((size_t)G + 1);
+    for (uint32_t g = tid; g <= G; g += kPassThreads) {
+      const double2 v = ew_g[g];
+      e_l[g] = v.x;
+      w_l[g] = v.y;
+    }
+  }
+  auto ew = [&](uint32_t g) -> double2 { return GLDS ? make_double2(e_l[g], w_l[g]) : ew_g[g]; };
+  if (TLDS) {
+    double *xl = p, *tl = p + n_lut;
+    for (uint32_t i = tid; i < n_lut; i += kPassThreads) {
+      xl[i] = X_g[i];
+      tl[i] = T_g[i];
+    }
+    X = xl;
+    T = tl;
+  }
+  const double p0 = sc->p0, U = sc->U, logzi = sc->logzi, oma = 1.0 - sc->a;
+  const CstA cst = {p0, oma, oma * oma, p0 * logzi, p0 * logzi * logzi};
+  const double zbase = p0 * U, b1 = p0 * sc->V1c, b2 = p0 * sc->V2c;
+  double nn = 0.0;
+  __syncthreads();
+
+  const uint32_t n_sell = S.n_ecs - S.n_long;
+  const uint32_t gw = blockIdx.x * (kPassThreads / 64) + (tid >> 6), nw = gridDim.x * (kPassThreads / 64);
+  for (uint32_t s = gw; s < S.nslices; s += nw) {
+    const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;  // len is even
+    const size_t base = (size_t)o0 * 64 + lane;
+    AccA c = {0.0, 0.0, 0.0};
+    uint32_t k = 0;
+    for (; k + 4 <= len; k += 4) {
+      const typename R::T r0 = R::load(S.rec, base + (size_t)k * 64);
+      const typename R::T r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
+      const typename R::T r2 = R::load(S.rec, base + (size_t)(k + 2) * 64);
+      const typename R::T r3 = R::load(S.rec, base + (size_t)(k + 3) * 64);
+      const double2 e0 = ew(R::grp(r0)), e1 = ew(R::grp(r1)), e2 = ew(R::grp(r2)), e3 = ew(R::grp(r3));
+      const double x0 = X[R::idx(r0)], x1 = X[R::idx(r1)], x2 = X[R::idx(r2)], x3 = X[R::idx(r3)];
+      const double T0 = T[R::idx(r0)], T1 = T[R::idx(r1)], T2 = T[R::idx(r2)], T3 = T[R::idx(r3)];
+      cellA(c, cst, e0, x0, T0);
+      cellA(c, cst, e1, x1, T1);
+      cellA(c, cst, e2, x2, T2);
+      cellA(c, cst, e3, x3, T3);
+    }
+    if (k < len) {
+      const typename R::T r0 = R::load(S.rec, base + (size_t)k * 64);
+      const typename R::T r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
+      const double2 e0 = ew(R::grp(r0)), e1 = ew(R::grp(r1));
+      const double x0 = X[R::idx(r0)], x1 = X[R::idx(r1)];
+      const double T0 = T[R::idx(r0)], T1 = T[R::idx(r1)];
+      cellA(c, cst, e0, x0, T0);
+      cellA(c, cst, e1, x1, T1);
+    }
+    if (s * 64 + lane < n_sell) {
+      const double iZ = 1.0 / (zbase + c.zs);
+      const double S1 = (b1 + c.t1) * iZ, S2 = (b2 + c.t2) * iZ;
+      nn += S2 - S1 * S1;
+    }
+  }
+  // long ECs: the whole workgroup strides over one EC's cells
+  for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
+    AccA c = {0.0, 0.0, 0.0};
+    for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
+      const typename R::T rc = R::load(S.rec_long, k);
+      cellA(c, cst, ew(R::grp(rc)), X[R::idx(rc)], T[R::idx(rc)]);
+    }
+    const double zs = block_sum(c.zs, sh), t1 = block_sum(c.t1, sh), t2 = block_sum(c.t2, sh);
+    if (tid == 0) {
+      const double iZ = 1.0 / (zbase + zs);
+      const double S1 = (b1 + t1) * iZ, S2 = (b2 + t2) * iZ;
+      nn += S2 - S1 * S1;
+    }
+  }
+  nn = block_sum(nn, sh);
+  if (tid == 0) partA[blockIdx.x] = nn;
+}
+
+// ---------------------------------------------------------------------------------------
+// Pass B (SELL): per EC Z_j (softmax denominator), r_j = c_j / Z_j, the ELBO data terms
+// and the column sums A_g = sum_j r_j (x_gj - p0) accumulated in an LDS-private table
+// (rcgpar logsumexp + update_N_k + ELBO_rcg_mat in one sweep).  ECs of up to kRegCells cells
+// keep their (group, x - p0) pairs in registers between the row sum and the scatter.
+// ---------------------------------------------------------------------------------------
+constexpr int kRegCells = 16;
+
+template <bool WIDE, bool GLDS, bool TLDS>
+__global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int cond_reset,
+                                                       SellDev S, const double *e_g,
+                                                       const double *X_g, const double *T_g,
+                                                       double *partAcc, double *partS,
+                                                       double *accGlobal) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using R = Rec<WIDE>;
+  if (sc->done) return;
+  if (cond_reset && !sc->reset_pending) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t G = S.n_groups, n_lut = S.n_lut;
+  double *sh = reinterpret_cast<double *>(smem);
+  double *p = sh + 32;
+  const double *e_l = e_g, *X = X_g, *T = T_g;
+  double *acc = accGlobal;
+  if (GLDS) {
+    double *el = p;
+    acc = p + (G + 1);
+    p += 2 * ((size_t)G + 1);
+    for (uint32_t g = tid; g <= G; g += kPassThreads) {
+      el[g] = e_g[g];
+      acc[g] = 0.0;
+    }
+    e_l = el;
+  }
+  if (TLDS) {
+    double *xl = p, *tl = p + n_lut;
+    for (uint32_t i = tid; i < n_lut; i += kPassThreads) {
+      xl[i] = X_g[i];
+      tl[i] = T_g[i];
+    }
+    X = xl;
+    T = tl;
+  }
+  const double p0 = sc->p0, U = sc->U, logzi = sc->logzi;
+  const double p0l = p0 * logzi;
+  const double zbase = p0 * U, hbase = p0l * U;
+  double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;
+  __syncthreads();
+
+  const uint32_t n_sell = S.n_ecs - S.n_long;
+  const uint32_t gw = blockIdx.x * (kPassThreads / 64) + (tid >> 6), nw = gridDim.x * (kPassThreads / 64);
+  for (uint32_t s = gw; s < S.nslices; s += nw) {
+    const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;  // len is even
+    const size_t base = (size_t)o0 * 64 + lane;
+    const uint32_t q = s * 64 + lane;
+    const double c = q < n_sell ? S.cvec[S.n_long + q] : 0.0;
+    double zs = 0.0, hs = 0.0;
+    if (len <= (uint32_t)kRegCells) {
+      uint32_t gc[kRegCells];
+      double xc[kRegCells];
+#pragma unroll
+      for (int k = 0; k < kRegCells; k += 2) {
+        if ((uint32_t)k < len) {
+          const typename R::T r0 = R::load(S.rec, base + (size_t)k * 64);
+          const typename R::T r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
+          const uint32_t g0 = R::grp(r0), g1 = R::grp(r1);
+          const double e0 = e_l[g0], e1 = e_l[g1];
+          const double x0 = X[R::idx(r0)], x1 = X[R::idx(r1)];
+          const double T0 = T[R::idx(r0)], T1 = T[R::idx(r1)];
+          const double m0 = x0 - p0, m1 = x1 - p0;
+          zs += e0 * m0;
+          hs += e0 * (x0 * T0 - p0l);
+          zs += e1 * m1;
+          hs += e1 * (x1 * T1 - p0l);
+          gc[k] = g0;
+          gc[k + 1] = g1;
+          xc[k] = m0;
+          xc[k + 1] = m1;
+        }
+      }
+      if (c != 0.0) {
+        const double Z = zbase + zs, H = hbase + hs;
+        const double rj = c / Z;
+        s_clogZ += c * log(Z);
+        s_rH += rj * H;
+        s_W += rj;
+#pragma unroll
+        for (int k = 0; k < kRegCells; k += 2) {
+          if ((uint32_t)k < len) {
+            atomicAdd(&acc[gc[k]], rj * xc[k]);
+            atomicAdd(&acc[gc[k + 1]], rj * xc[k + 1]);
+          }
+        }
+      }
+    } else {
+      for (uint32_t k = 0; k < len; k += 2) {
+        const typename R::T r0 = R::load(S.rec, base + (size_t)k * 64);
+        const typename R::T r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
+        const double e0 = e_l[R::grp(r0)], e1 = e_l[R::grp(r1)];
+        const double x0 = X[R::idx(r0)], x1 = X[R::idx(r1)];
+        const double T0 = T[R::idx(r0)], T1 = T[R::idx(r1)];
+        zs += e0 * (x0 - p0);
+        hs += e0 * (x0 * T0 - p0l);
+        zs += e1 * (x1 - p0);
+        hs += e1 * (x1 * T1 - p0l);
+      }
+      if (c != 0.0) {
+        const double Z = zbase + zs, H = hbase + hs;
+        const double rj = c / Z;
+        s_clogZ += c * log(Z);
+        s_rH += rj * H;
+        s_W += rj;
+        for (uint32_t k = 0; k < len; ++k) {
+          const typename R::T r = R::load(S.rec, base + (size_t)k * 64);
+          atomicAdd(&acc[R::grp(r)], rj * (X[R::idx(r)] - p0));
+        }
+      }
+    }
+  }
+  for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
+    double zs = 0.0, hs = 0.0;
+    for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
+      const typename R::T rc = R::load(S.rec_long, k);
+      const double eg = e_l[R::grp(rc)];
+      const double x = X[R::idx(rc)];
+      zs += eg * (x - p0);
+      hs += eg * (x * T[R::idx(rc)] - p0l);
+    }
+    zs = block_sum(zs, sh);
+    hs = block_sum(hs, sh);
+    const double c = S.cvec[r];
+    if (c != 0.0) {
+      const double Z = zbase + zs, H = hbase + hs;
+      const double rj = c / Z;
+      if (tid == 0) {
+        s_clogZ += c * log(Z);
+        s_rH += rj * H;
+        s_W += rj;
+      }
+      for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
+        const typename R::T rc = R::load(S.rec_long, k);
+        atomicAdd(&acc[R::grp(rc)], rj * (X[R::idx(rc)] - p0));
+      }
+    }
+  }
+  s_clogZ = block_sum(s_clogZ, sh);
+  s_rH = block_sum(s_rH, sh);
+  s_W = block_sum(s_W, sh);
+  if (tid == 0) {
+    partS[4 * blockIdx.x + 0] = s_clogZ;
+    partS[4 * blockIdx.x + 1] = s_rH;
+    partS[4 * blockIdx.x + 2] = s_W;
+    partS[4 * blockIdx.x + 3] = 0.0;
+  }
+  if (GLDS) {
+    __syncthreads();
+    double *dst = partAcc + (size_t)blockIdx.x * G;
+    for (uint32_t g = tid; g < G; g += kPassThreads) dst[g] = acc[g];
+  }
+}
+
+
+}  // namespace msw
