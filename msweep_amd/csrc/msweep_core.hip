@@ -67,6 +67,10 @@ struct msw_core {
   DevBuf<double> cp;
   DevBuf<uint64_t> mtwords;
   DevBuf<uint32_t> bcounts;
+  DevBuf<MtState> mt;
+  bool mt_valid = false;
+  int32_t mt_seed = 0;
+  uint64_t mt_pos = 0;
 
   // ---- measurement ---------------------------------------------------------------------------
   bool profiling = false, fixed_iters = false;
@@ -348,11 +352,16 @@ void run_rcg(msw_core *h, size_t max_iters) {
 void finish_solve(msw_core *h, double *theta_out, size_t *iters_out, double *bound_out) {
   poll(h);
   const uint32_t G = h->G;
-  std::vector<double> nc(G);
-  MSW_HIP(hipMemcpy(nc.data(), h->Nc.p, G * sizeof(double), hipMemcpyDeviceToHost));
-  const double csum = h->sc_host->csum;
-  if (theta_out)
-    for (uint32_t g = 0; g < G; ++g) theta_out[g] = nc[g] / csum;
+  if (theta_out) {
+    if (h->last_algo == MSW_ALGO_EM) {
+      MSW_HIP(hipMemcpy(theta_out, h->logth.p, G * sizeof(double), hipMemcpyDeviceToHost));  // theta of the last M-step
+    } else {
+      std::vector<double> nc(G);
+      MSW_HIP(hipMemcpy(nc.data(), h->Nc.p, G * sizeof(double), hipMemcpyDeviceToHost));
+      const double csum = h->sc_host->csum;
+      for (uint32_t g = 0; g < G; ++g) theta_out[g] = nc[g] / csum;
+    }
+  }
   if (iters_out) *iters_out = (size_t)h->sc_host->iter;
   if (bound_out) *bound_out = h->sc_host->bound;
   h->have_solution = true;
@@ -408,7 +417,9 @@ void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, dou
 }  // namespace
 
 #include "host_likelihood.inc"
+#include "host_em.inc"
 #include "host_bootstrap.inc"
+#include "host_build.inc"
 
 // =========================================================================================
 // C ABI

@@ -1,0 +1,97 @@
+"""GPU: bootstrap resampling (bit-exact with libstdc++'s stream), the bootstrap driver, and the EM
+variant, against the oracle and the committed golden vectors."""
+import numpy as np
+import pytest
+
+from conftest import dense_from_csr, load_golden, lutidx_of
+from msweep_amd import synth
+from msweep_amd.core import ALGO_EM, ALGO_RCG
+from msweep_amd.likelihood import from_dense, from_grouped_counts, precalc_lls
+from test_gpu_rcg import assert_theta
+
+pytestmark = pytest.mark.gpu
+
+
+def test_resample_counts_match_libstdcxx_golden(gpu_core):
+    g = load_golden("bootstrap_golden.json")
+    for c in g["cases"]:
+        exp = np.array(c["counts"], np.uint32)
+        got = gpu_core.resample_counts(c["weights"], c["seed"], c["draws"], 0, len(exp))
+        np.testing.assert_array_equal(got, exp)
+        # any slice of the ONE sequential stream, asked for on its own (what rank r of N does)
+        if len(exp) > 1:
+            got1 = gpu_core.resample_counts(c["weights"], c["seed"], c["draws"], 1, len(exp))
+            np.testing.assert_array_equal(got1, exp[1:])
+
+
+def test_resample_counts_match_oracle_large(gpu_core, oracle):
+    rng = np.random.default_rng(21)
+    w = rng.integers(0, 500, 200_000).astype(np.uint32)
+    w[rng.random(len(w)) < 0.3] = 0
+    exp = oracle.bootstrap_counts(w, -99, 300_000, 3)
+    got = gpu_core.resample_counts(w, -99, 300_000, 0, 3)
+    np.testing.assert_array_equal(got, exp)
+    # backwards seek re-seeds the stream
+    np.testing.assert_array_equal(gpu_core.resample_counts(w, -99, 300_000, 1, 2), exp[1:2])
+    assert np.all(got.sum(1) == 300_000)
+
+
+def test_bootstrap_driver_matches_replicate_by_replicate_oracle(gpu_core, oracle):
+    p = synth.make_csr_problem(30000, 80, seed=14, max_other=6)
+    G = 80
+    alpha0 = np.ones(G)
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    w = p["ec_counts"].astype(np.uint32)
+    draws = int(w.sum())
+    theta, iters = gpu_core.bootstrap(w, 42, draws, 0, 4, alpha0)
+    counts = oracle.bootstrap_counts(w, 42, draws, 4)
+    lut = precalc_lls(p["group_sizes"])
+    for b in range(4):
+        with np.errstate(divide="ignore"):
+            logc = np.log(counts[b].astype(float))       # -inf for ECs drawn zero times (:70)
+        ref = oracle.rcg_optl_csr(p["rowptr"], p["grp"], lutidx_of(p, lut), lut, np.log(0.01), G, logc, alpha0)
+        assert iters[b] == ref["iters"]
+        assert_theta(theta[b], ref["theta"])
+        assert theta[b].sum() == pytest.approx(1.0, abs=1e-12)   # normalised by the resampled total
+    # a slice of the replicate stream equals the same rows of the full run (N-GPU invariance)
+    theta2, _ = gpu_core.bootstrap(w, 42, draws, 2, 4, alpha0)
+    np.testing.assert_array_equal(theta2, theta[2:4])
+    # --bootstrap-count smaller than the number of reads
+    theta3, _ = gpu_core.bootstrap(w, 7, 5000, 0, 1, alpha0)
+    c3 = oracle.bootstrap_counts(w, 7, 5000, 1)[0]
+    with np.errstate(divide="ignore"):
+        r3 = oracle.rcg_optl_csr(p["rowptr"], p["grp"], lutidx_of(p, lut), lut, np.log(0.01), G,
+                                 np.log(c3.astype(float)), alpha0)
+    assert_theta(theta3[0], r3["theta"])
+
+
+@pytest.mark.parametrize("idx", [1, 2, 3, 6])
+def test_em_dense_matches_oracle(gpu_core, oracle, idx):
+    c = load_golden("rcg_golden.json")["cases"][idx]
+    L = np.array(c["logl"])
+    logc = np.array([-np.inf if x is None else x for x in c["logc"]])
+    alpha0 = np.array(c["alpha0"])
+    from_dense(gpu_core, L, logc)
+    res = gpu_core.solve(logc, alpha0, tol=1e-9, max_iters=5000, algo=ALGO_EM)
+    ref = oracle.em_dense(L, logc, alpha0, tol=1e-9, max_iters=5000, want_gamma=True)
+    assert abs(res["iters"] - ref["iters"]) <= 2
+    np.testing.assert_allclose(res["theta"], ref["theta"], rtol=1e-6, atol=1e-9)
+    assert res["bound"] == pytest.approx(ref["bound"], rel=1e-10)
+    np.testing.assert_allclose(np.exp(gpu_core.gamma()), np.exp(ref["gamma"]), atol=1e-6)
+
+
+def test_em_csr_matches_oracle_and_rcg_region(gpu_core, oracle):
+    p = synth.make_csr_problem(20000, 60, seed=15, max_other=6)
+    G = 60
+    alpha0 = np.ones(G)
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    em = gpu_core.solve(lik.log_counts(), alpha0, tol=1e-8, max_iters=20000, algo=ALGO_EM)
+    lut = precalc_lls(p["group_sizes"])
+    ref = oracle.em_dense(dense_from_csr(p, lut), lik.log_counts(), alpha0, tol=1e-8, max_iters=20000)
+    assert abs(em["iters"] - ref["iters"]) <= 2
+    np.testing.assert_allclose(em["theta"], ref["theta"], rtol=1e-6, atol=1e-9)
+    rcg = gpu_core.solve(lik.log_counts(), alpha0, algo=ALGO_RCG)
+    np.testing.assert_allclose(em["theta"], rcg["theta"], atol=5e-3)   # different objectives, same region
+    # --emprecision float is accepted (served in fp64)
+    em32 = gpu_core.solve(lik.log_counts(), alpha0, tol=1e-8, max_iters=20000, algo=ALGO_EM, prec=1)
+    np.testing.assert_array_equal(em32["theta"], em["theta"])
