@@ -54,8 +54,11 @@ def test_bootstrap_driver_matches_replicate_by_replicate_oracle(gpu_core, oracle
         assert_theta(theta[b], ref["theta"])
         assert theta[b].sum() == pytest.approx(1.0, abs=1e-12)   # normalised by the resampled total
     # a slice of the replicate stream equals the same rows of the full run (N-GPU invariance)
+    # (identical resampled counts; the solves differ only by the order of the LDS atomic adds of
+    # the column sums, i.e. by rounding)
     theta2, _ = gpu_core.bootstrap(w, 42, draws, 2, 4, alpha0)
-    np.testing.assert_array_equal(theta2, theta[2:4])
+    for b in range(2):
+        assert_theta(theta2[b], theta[2 + b])
     # --bootstrap-count smaller than the number of reads
     theta3, _ = gpu_core.bootstrap(w, 7, 5000, 0, 1, alpha0)
     c3 = oracle.bootstrap_counts(w, 7, 5000, 1)[0]
@@ -94,4 +97,4 @@ def test_em_csr_matches_oracle_and_rcg_region(gpu_core, oracle):
     np.testing.assert_allclose(em["theta"], rcg["theta"], atol=5e-3)   # different objectives, same region
     # --emprecision float is accepted (served in fp64)
     em32 = gpu_core.solve(lik.log_counts(), alpha0, tol=1e-8, max_iters=20000, algo=ALGO_EM, prec=1)
-    np.testing.assert_array_equal(em32["theta"], em["theta"])
+    np.testing.assert_allclose(em32["theta"], em["theta"], rtol=1e-9, atol=1e-15)
