@@ -108,11 +108,11 @@ def main():
                               prob["group_sizes"])
     alpha0 = np.ones(G)
     if world > 1:
-        # replicate `rank` of the bootstrap: multinomial resample of the EC counts.  (Synthetic
-        # bench input; the parity-exact mt19937_64 stream is msw_core_resample_counts.)
-        rng = np.random.Generator(np.random.PCG64(1000 + rank))
-        c = prob["ec_counts"].astype(np.float64)
-        counts = rng.multinomial(int(c.sum()), c / c.sum()).astype(np.float64)
+        # replicate `rank` of the bootstrap, drawn on the device from the reference's ONE sequential
+        # mt19937_64(--seed 42) stream (src/BootstrapSample.cpp:60-73): rank r owns draws
+        # [r * n_reads, (r + 1) * n_reads), exactly what a single-GPU run would give replicate r
+        w = prob["ec_counts"].astype(np.uint32)
+        counts = core.resample_counts(w, 42, int(w.sum()), rank, rank + 1)[0].astype(np.float64)
         with np.errstate(divide="ignore"):
             logc = np.log(counts)
     else:

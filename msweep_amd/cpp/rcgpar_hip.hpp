@@ -1,0 +1,160 @@
+// rcgpar_hip.hpp -- C++ host shim over the C ABI (include/msweep_core.h) with the signatures
+// mSWEEP's rcg_optl() wrapper calls (reference: src/mSWEEP.cpp:176-205, 419-423, 512-516):
+//
+//   rcgpar::rcg_optl_torch(logl, log_times_observed, alpha0, tol, max_iters, log)
+//   rcgpar::em_torch      (logl, log_times_observed, alpha0, tol, max_iters, log, precision)
+//   rcgpar::mixture_components_torch(probs, log_times_observed)
+//
+// `logl` is any matrix type with get_rows() / get_cols() / operator()(row, col) -- the part of
+// seamat::Matrix<double> the reference uses (include/Likelihood.hpp:176,182,258; Sample.hpp:84-85).
+// The return type is a template parameter so that mSWEEP instantiates it with
+// seamat::DenseMatrix<double> (constructible as (rows, cols, fill), writable through
+// operator()); `msw::DenseMatrix` below is a stand-alone equivalent for tests.
+// A non-zero C-ABI status becomes std::runtime_error, which mSWEEP's try/catch blocks
+// (src/mSWEEP.cpp:400-406, 506-511) already handle.
+//
+// The preferred integration keeps the likelihood on the device: msw::DeviceLikelihood owns a
+// core handle, is filled once per grouping (set_csr / build / set_dense) and serves the
+// 1 + --iters estimation calls without re-uploading.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/msweep_core.h"
+
+namespace msw {
+
+class DenseMatrix {  // rows = groups, row-major: the subset of seamat::DenseMatrix<double> mSWEEP uses
+ public:
+  DenseMatrix() = default;
+  DenseMatrix(size_t rows, size_t cols, double fill = 0.0) : r_(rows), c_(cols), v_(rows * cols, fill) {}
+  size_t get_rows() const { return r_; }
+  size_t get_cols() const { return c_; }
+  double &operator()(size_t r, size_t c) { return v_[r * c_ + c]; }
+  const double &operator()(size_t r, size_t c) const { return v_[r * c_ + c]; }
+  double *data() { return v_.data(); }
+  const double *data() const { return v_.data(); }
+
+ private:
+  size_t r_ = 0, c_ = 0;
+  std::vector<double> v_;
+};
+
+inline void check(msw_handle h, int rc) {
+  if (rc != 0) throw std::runtime_error(msw_last_error(h));
+}
+
+// One grouping's likelihood, resident on one GPU.
+class DeviceLikelihood {
+ public:
+  explicit DeviceLikelihood(int device = 0) {
+    if (msw_core_create(device, &h_) != 0) throw std::runtime_error(msw_last_error(nullptr));
+  }
+  ~DeviceLikelihood() { msw_core_destroy(h_); }
+  DeviceLikelihood(const DeviceLikelihood &) = delete;
+  DeviceLikelihood &operator=(const DeviceLikelihood &) = delete;
+  msw_handle handle() const { return h_; }
+
+  template <class MatrixT>
+  void set_dense(const MatrixT &logl) {  // rows = groups (seamat layout)
+    const size_t G = logl.get_rows(), E = logl.get_cols();
+    std::vector<double> buf(G * E);
+    for (size_t g = 0; g < G; ++g)
+      for (size_t j = 0; j < E; ++j) buf[g * E + j] = logl(g, j);
+    check(h_, msw_core_set_dense_logl(h_, buf.data(), G, E, E));
+  }
+  void set_csr(const std::vector<uint64_t> &rowptr, const std::vector<uint32_t> &grp,
+               const std::vector<uint32_t> &cnt, const std::vector<double> &lut, size_t lut_ld, double logzi,
+               size_t n_groups) {
+    check(h_, msw_core_set_csr(h_, rowptr.data(), grp.data(), cnt.data(), lut.data(), lut_ld, logzi, n_groups,
+                               rowptr.size() - 1));
+  }
+
+ private:
+  msw_handle h_ = nullptr;
+};
+
+struct Estimate {
+  std::vector<double> theta;
+  size_t iters = 0;
+  double bound = 0.0;
+};
+
+inline Estimate solve(DeviceLikelihood &lik, const std::vector<double> &log_times_observed,
+                      const std::vector<double> &alpha0, double tol, size_t max_iters, int algo, int prec,
+                      std::ostream *log) {
+  Estimate r;
+  r.theta.resize(alpha0.size());
+  check(lik.handle(), msw_core_solve(lik.handle(), log_times_observed.data(), alpha0.data(), tol, max_iters, algo,
+                                     prec, r.theta.data(), &r.iters, &r.bound));
+  if (log && log->good()) {  // rcgpar logs every 5th iteration
+    const size_t n = r.iters < 4096 ? r.iters : 4096;
+    std::vector<double> b(n), g(n);
+    size_t got = 0;
+    check(lik.handle(), msw_core_trace(lik.handle(), n, b.data(), g.data(), nullptr, nullptr, nullptr, &got));
+    for (size_t k = 0; k < got; k += 5) *log << "  iter: " << k << ", bound: " << b[k] << ", |g|: " << g[k] << '\n';
+  }
+  return r;
+}
+
+template <class DenseT>
+DenseT gamma_of(DeviceLikelihood &lik, size_t n_groups, size_t n_ecs) {
+  std::vector<double> buf(n_groups * n_ecs);
+  check(lik.handle(), msw_core_gamma(lik.handle(), buf.data(), n_ecs));
+  DenseT out(n_groups, n_ecs, 0.0);
+  for (size_t g = 0; g < n_groups; ++g)
+    for (size_t j = 0; j < n_ecs; ++j) out(g, j) = buf[g * n_ecs + j];
+  return out;
+}
+
+}  // namespace msw
+
+namespace rcgpar {
+
+// Drop-in for the call at src/mSWEEP.cpp:194 (a dense `ll_mat` is uploaded for the call).
+template <class DenseT = msw::DenseMatrix, class MatrixT>
+DenseT rcg_optl_torch(const MatrixT &logl, const std::vector<double> &log_times_observed,
+                      const std::vector<double> &alpha0, const double &tol, size_t max_iters, std::ostream &log,
+                      int device = 0) {
+  msw::DeviceLikelihood lik(device);
+  lik.set_dense(logl);
+  msw::solve(lik, log_times_observed, alpha0, tol, max_iters, MSW_ALGO_RCG, MSW_PREC_DOUBLE, &log);
+  return msw::gamma_of<DenseT>(lik, logl.get_rows(), logl.get_cols());
+}
+
+// Drop-in for the call at src/mSWEEP.cpp:202.
+template <class DenseT = msw::DenseMatrix, class MatrixT>
+DenseT em_torch(const MatrixT &logl, const std::vector<double> &log_times_observed,
+                const std::vector<double> &alpha0, const double &tol, size_t max_iters, std::ostream &log,
+                std::string precision, int device = 0) {
+  if (precision != "double" && precision != "float") throw std::runtime_error("em_torch: unknown precision " + precision);
+  msw::DeviceLikelihood lik(device);
+  lik.set_dense(logl);
+  msw::solve(lik, log_times_observed, alpha0, tol, max_iters, MSW_ALGO_EM,
+             precision == "float" ? MSW_PREC_FLOAT : MSW_PREC_DOUBLE, &log);
+  return msw::gamma_of<DenseT>(lik, logl.get_rows(), logl.get_cols());
+}
+
+// rcgpar::mixture_components[_torch] (src/mSWEEP.cpp:420,422): theta_g = sum_j exp(gamma_gj + logc_j) / sum_j c_j.
+// Host loop over the returned matrix, as the reference does; with msw::solve() the same vector is
+// already available as Estimate::theta without materialising gamma.
+template <class MatrixT>
+std::vector<double> mixture_components_torch(const MatrixT &probs, const std::vector<double> &log_times_observed) {
+  const size_t G = probs.get_rows(), E = probs.get_cols();
+  double total = 0.0;
+  for (size_t j = 0; j < E; ++j) total += std::exp(log_times_observed[j]);
+  std::vector<double> theta(G, 0.0);
+  for (size_t g = 0; g < G; ++g) {
+    double acc = 0.0;
+    for (size_t j = 0; j < E; ++j) acc += std::exp(probs(g, j) + log_times_observed[j]);
+    theta[g] = acc / total;
+  }
+  return theta;
+}
+
+}  // namespace rcgpar
