@@ -1,15 +1,37 @@
 // sweep_kernels.hpp -- the two HBM-streaming sweeps of one RCG iteration over the SELL-64
 // likelihood: pass A (natural-gradient norm) and pass B (softmax / column sums / ELBO).
+//
+// Both kernels: one persistent 1024-thread workgroup per CU; its 16 wavefronts take slices
+// round-robin.  A slice of up to kRegCells cells per EC is held in registers: while slice s is
+// being processed the records of the wave's next slice are already in flight (the record stream
+// is the only HBM traffic; everything else is gathered from LDS).  Slice bounds are wave-uniform
+// and kept in SGPRs (readfirstlane) so the cell loops are scalar branches, not exec-mask loops.
 #pragma once
 #include "device_util.hpp"
 #include "sell.hpp"
 
 namespace msw {
 
+constexpr int kRegCells = 16;  // cells per EC a wave keeps in registers (longer slices stream)
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Issue the loads of one slice (<= kRegCells cells per EC, even count) into registers.
+template <bool WIDE>
+__device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uint32_t len,
+                                           typename Rec<WIDE>::T (&r)[kRegCells]) {
+#pragma unroll
+  for (int k = 0; k < kRegCells; k += 2) {
+    if ((uint32_t)k < len) {
+      r[k] = Rec<WIDE>::load(rec, base + (size_t)k * 64);
+      r[k + 1] = Rec<WIDE>::load(rec, base + (size_t)(k + 1) * 64);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
-// Pass A (SELL): newnorm = sum_j Var_{q_j}(step_.j), q_j = softmax_g(a*L + u),
+// Pass A: newnorm = sum_j Var_{q_j}(step_.j), q_j = softmax_g(a*L + u),
 // step_gj = (1-a)*L_gj + w_g  (+ an irrelevant per-EC constant).
-// One persistent 1024-thread workgroup per CU; its 16 wavefronts take slices round-robin.
 // ---------------------------------------------------------------------------------------
 struct AccA {
   double zs, t1, t2;
@@ -17,16 +39,16 @@ struct AccA {
 struct CstA {
   double p0, oma, oma2, p0l, p0l2;  // p0, (1-a), (1-a)^2, p0*logzi, p0*logzi^2
 };
-__device__ __forceinline__ void cellA(AccA &c, const CstA &k, const double2 ew, const double x,
-                                      const double T) {
+__device__ __forceinline__ void cellA(AccA &c, const CstA &k, const double e, const double w,
+                                      const double x, const double T) {
   const double xm = x - k.p0;
   const double xT = x * T;
   const double A1 = k.oma * (xT - k.p0l);
   const double A2 = k.oma2 * (xT * T - k.p0l2);
-  const double wx = ew.y * xm;
-  c.zs += ew.x * xm;
-  c.t1 += ew.x * (A1 + wx);
-  c.t2 += ew.x * (A2 + ew.y * (2.0 * A1 + wx));
+  const double wx = w * xm;
+  c.zs += e * xm;
+  c.t1 += e * (A1 + wx);
+  c.t2 += e * (A2 + w * (2.0 * A1 + wx));
 }
 
 template <bool WIDE, bool GLDS, bool TLDS>
@@ -35,12 +57,13 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
                                                        const double *T_g, double *partA) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
+  using RT = typename R::T;
   if (sc->done) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t G = S.n_groups, n_lut = S.n_lut;
   double *sh = reinterpret_cast<double *>(smem);
   double *p = sh + 32;
-  // group vectors as two 8-byte arrays in LDS (same bank rule as pass B: group id mod 32)
+  // group vectors as two 8-byte arrays in LDS (bank rule of the upload scheduler: group id mod 32)
   const double *X = X_g, *T = T_g;
   double *e_l = p, *w_l = p + (G + 1);
   if (GLDS) {
@@ -51,7 +74,6 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
       w_l[g] = v.y;
     }
   }
-  auto ew = [&](uint32_t g) -> double2 { return GLDS ? make_double2(e_l[g], w_l[g]) : ew_g[g]; };
   if (TLDS) {
     double *xl = p, *tl = p + n_lut;
     for (uint32_t i = tid; i < n_lut; i += kPassThreads) {
@@ -61,6 +83,8 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
     X = xl;
     T = tl;
   }
+  auto E_ = [&](uint32_t g) -> double { return GLDS ? e_l[g] : ew_g[g].x; };
+  auto W_ = [&](uint32_t g) -> double { return GLDS ? w_l[g] : ew_g[g].y; };
   const double p0 = sc->p0, U = sc->U, logzi = sc->logzi, oma = 1.0 - sc->a;
   const CstA cst = {p0, oma, oma * oma, p0 * logzi, p0 * logzi * logzi};
   const double zbase = p0 * U, b1 = p0 * sc->V1c, b2 = p0 * sc->V2c;
@@ -68,46 +92,65 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
-  const uint32_t gw = blockIdx.x * (kPassThreads / 64) + (tid >> 6), nw = gridDim.x * (kPassThreads / 64);
-  for (uint32_t s = gw; s < S.nslices; s += nw) {
-    const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;  // len is even
-    const size_t base = (size_t)o0 * 64 + lane;
+  const uint32_t nw = gridDim.x * (kPassThreads / 64);
+  // Two register buffers in ping-pong: while one slice is processed the records of the wave's
+  // next slice are in flight.  The explicit vmcnt(0) sits BEFORE the next buffer's loads are
+  // issued, so it only waits for the buffer about to be consumed.
+  RT buf0[kRegCells] = {}, buf1[kRegCells] = {};
+  uint32_t o0 = 0, len0 = 0, o1 = 0, len1 = 0;
+  auto issue = [&](uint32_t sl, RT(&b)[kRegCells], uint32_t &o, uint32_t &len) {
+    o = uniform(S.slice_off[sl]);
+    len = uniform(S.slice_off[sl + 1]) - o;
+    if (len <= (uint32_t)kRegCells) load_slice<WIDE>(S.rec, (size_t)o * 64 + lane, len, b);
+  };
+  auto process = [&](uint32_t sl, RT(&b)[kRegCells], uint32_t o, uint32_t len) {
     AccA c = {0.0, 0.0, 0.0};
-    uint32_t k = 0;
-    for (; k + 4 <= len; k += 4) {
-      const typename R::T r0 = R::load(S.rec, base + (size_t)k * 64);
-      const typename R::T r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
-      const typename R::T r2 = R::load(S.rec, base + (size_t)(k + 2) * 64);
-      const typename R::T r3 = R::load(S.rec, base + (size_t)(k + 3) * 64);
-      const double2 e0 = ew(R::grp(r0)), e1 = ew(R::grp(r1)), e2 = ew(R::grp(r2)), e3 = ew(R::grp(r3));
-      const double x0 = X[R::idx(r0)], x1 = X[R::idx(r1)], x2 = X[R::idx(r2)], x3 = X[R::idx(r3)];
-      const double T0 = T[R::idx(r0)], T1 = T[R::idx(r1)], T2 = T[R::idx(r2)], T3 = T[R::idx(r3)];
-      cellA(c, cst, e0, x0, T0);
-      cellA(c, cst, e1, x1, T1);
-      cellA(c, cst, e2, x2, T2);
-      cellA(c, cst, e3, x3, T3);
+    if (len <= (uint32_t)kRegCells) {
+#pragma unroll
+      for (int k = 0; k < kRegCells; k += 2) {
+        if ((uint32_t)k < len) {
+          const uint32_t g0 = R::grp(b[k]), g1 = R::grp(b[k + 1]);
+          const uint32_t i0 = R::idx(b[k]), i1 = R::idx(b[k + 1]);
+          const double e0 = E_(g0), e1 = E_(g1), w0 = W_(g0), w1 = W_(g1);
+          const double x0 = X[i0], x1 = X[i1], T0 = T[i0], T1 = T[i1];
+          cellA(c, cst, e0, w0, x0, T0);
+          cellA(c, cst, e1, w1, x1, T1);
+        }
+      }
+    } else {
+      const size_t base = (size_t)o * 64 + lane;
+      for (uint32_t k = 0; k < len; k += 2) {
+        const RT r0 = R::load(S.rec, base + (size_t)k * 64);
+        const RT r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
+        cellA(c, cst, E_(R::grp(r0)), W_(R::grp(r0)), X[R::idx(r0)], T[R::idx(r0)]);
+        cellA(c, cst, E_(R::grp(r1)), W_(R::grp(r1)), X[R::idx(r1)], T[R::idx(r1)]);
+      }
     }
-    if (k < len) {
-      const typename R::T r0 = R::load(S.rec, base + (size_t)k * 64);
-      const typename R::T r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
-      const double2 e0 = ew(R::grp(r0)), e1 = ew(R::grp(r1));
-      const double x0 = X[R::idx(r0)], x1 = X[R::idx(r1)];
-      const double T0 = T[R::idx(r0)], T1 = T[R::idx(r1)];
-      cellA(c, cst, e0, x0, T0);
-      cellA(c, cst, e1, x1, T1);
-    }
-    if (s * 64 + lane < n_sell) {
+    if (sl * 64 + lane < n_sell) {
       const double iZ = 1.0 / (zbase + c.zs);
       const double S1 = (b1 + c.t1) * iZ, S2 = (b2 + c.t2) * iZ;
       nn += S2 - S1 * S1;
     }
+  };
+  uint32_t s0 = uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)), s1;
+  if (s0 < S.nslices) issue(s0, buf0, o0, len0);
+  while (s0 < S.nslices) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): buf0 has landed
+    s1 = s0 + nw;
+    if (s1 < S.nslices) issue(s1, buf1, o1, len1);
+    process(s0, buf0, o0, len0);
+    if (s1 >= S.nslices) break;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // buf1 has landed
+    s0 = s1 + nw;
+    if (s0 < S.nslices) issue(s0, buf0, o0, len0);
+    process(s1, buf1, o1, len1);
   }
   // long ECs: the whole workgroup strides over one EC's cells
   for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
     AccA c = {0.0, 0.0, 0.0};
     for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
-      const typename R::T rc = R::load(S.rec_long, k);
-      cellA(c, cst, ew(R::grp(rc)), X[R::idx(rc)], T[R::idx(rc)]);
+      const RT rc = R::load(S.rec_long, k);
+      cellA(c, cst, E_(R::grp(rc)), W_(R::grp(rc)), X[R::idx(rc)], T[R::idx(rc)]);
     }
     const double zs = block_sum(c.zs, sh), t1 = block_sum(c.t1, sh), t2 = block_sum(c.t2, sh);
     if (tid == 0) {
@@ -121,13 +164,11 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
 }
 
 // ---------------------------------------------------------------------------------------
-// Pass B (SELL): per EC Z_j (softmax denominator), r_j = c_j / Z_j, the ELBO data terms
-// and the column sums A_g = sum_j r_j (x_gj - p0) accumulated in an LDS-private table
-// (rcgpar logsumexp + update_N_k + ELBO_rcg_mat in one sweep).  ECs of up to kRegCells cells
-// keep their (group, x - p0) pairs in registers between the row sum and the scatter.
+// Pass B: per EC Z_j (softmax denominator), r_j = c_j / Z_j, the ELBO data terms and the column
+// sums A_g = sum_j r_j (x_gj - p0) accumulated in an LDS-private table (rcgpar logsumexp +
+// update_N_k + ELBO_rcg_mat in one sweep).  The (group, x - p0) pairs of an EC stay in registers
+// between the row sum and the scatter.
 // ---------------------------------------------------------------------------------------
-constexpr int kRegCells = 16;
-
 template <bool WIDE, bool GLDS, bool TLDS>
 __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int cond_reset,
                                                        SellDev S, const double *e_g,
@@ -136,6 +177,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
                                                        double *accGlobal) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
+  using RT = typename R::T;
   if (sc->done) return;
   if (cond_reset && !sc->reset_pending) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -170,32 +212,32 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
-  const uint32_t gw = blockIdx.x * (kPassThreads / 64) + (tid >> 6), nw = gridDim.x * (kPassThreads / 64);
-  for (uint32_t s = gw; s < S.nslices; s += nw) {
-    const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;  // len is even
-    const size_t base = (size_t)o0 * 64 + lane;
-    const uint32_t q = s * 64 + lane;
-    const double c = q < n_sell ? S.cvec[S.n_long + q] : 0.0;
+  const uint32_t nw = gridDim.x * (kPassThreads / 64);
+  RT buf0[kRegCells] = {}, buf1[kRegCells] = {};
+  uint32_t o0 = 0, len0 = 0, o1 = 0, len1 = 0;
+  double c0 = 0.0, c1 = 0.0;
+  auto issue = [&](uint32_t sl, RT(&b)[kRegCells], uint32_t &o, uint32_t &len, double &c) {
+    o = uniform(S.slice_off[sl]);
+    len = uniform(S.slice_off[sl + 1]) - o;
+    if (len <= (uint32_t)kRegCells) load_slice<WIDE>(S.rec, (size_t)o * 64 + lane, len, b);
+    c = (sl * 64 + lane < n_sell) ? S.cvec[S.n_long + sl * 64 + lane] : 0.0;
+  };
+  auto process = [&](RT(&b)[kRegCells], uint32_t o, uint32_t len, double c) {
     double zs = 0.0, hs = 0.0;
     if (len <= (uint32_t)kRegCells) {
-      uint32_t gc[kRegCells];
       double xc[kRegCells];
 #pragma unroll
       for (int k = 0; k < kRegCells; k += 2) {
         if ((uint32_t)k < len) {
-          const typename R::T r0 = R::load(S.rec, base + (size_t)k * 64);
-          const typename R::T r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
-          const uint32_t g0 = R::grp(r0), g1 = R::grp(r1);
+          const uint32_t g0 = R::grp(b[k]), g1 = R::grp(b[k + 1]);
+          const uint32_t i0 = R::idx(b[k]), i1 = R::idx(b[k + 1]);
           const double e0 = e_l[g0], e1 = e_l[g1];
-          const double x0 = X[R::idx(r0)], x1 = X[R::idx(r1)];
-          const double T0 = T[R::idx(r0)], T1 = T[R::idx(r1)];
+          const double x0 = X[i0], x1 = X[i1], T0 = T[i0], T1 = T[i1];
           const double m0 = x0 - p0, m1 = x1 - p0;
           zs += e0 * m0;
           hs += e0 * (x0 * T0 - p0l);
           zs += e1 * m1;
           hs += e1 * (x1 * T1 - p0l);
-          gc[k] = g0;
-          gc[k + 1] = g1;
           xc[k] = m0;
           xc[k + 1] = m1;
         }
@@ -209,15 +251,16 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
 #pragma unroll
         for (int k = 0; k < kRegCells; k += 2) {
           if ((uint32_t)k < len) {
-            atomicAdd(&acc[gc[k]], rj * xc[k]);
-            atomicAdd(&acc[gc[k + 1]], rj * xc[k + 1]);
+            atomicAdd(&acc[R::grp(b[k])], rj * xc[k]);
+            atomicAdd(&acc[R::grp(b[k + 1])], rj * xc[k + 1]);
           }
         }
       }
     } else {
+      const size_t base = (size_t)o * 64 + lane;
       for (uint32_t k = 0; k < len; k += 2) {
-        const typename R::T r0 = R::load(S.rec, base + (size_t)k * 64);
-        const typename R::T r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
+        const RT r0 = R::load(S.rec, base + (size_t)k * 64);
+        const RT r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
         const double e0 = e_l[R::grp(r0)], e1 = e_l[R::grp(r1)];
         const double x0 = X[R::idx(r0)], x1 = X[R::idx(r1)];
         const double T0 = T[R::idx(r0)], T1 = T[R::idx(r1)];
@@ -233,16 +276,29 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
         s_rH += rj * H;
         s_W += rj;
         for (uint32_t k = 0; k < len; ++k) {
-          const typename R::T r = R::load(S.rec, base + (size_t)k * 64);
+          const RT r = R::load(S.rec, base + (size_t)k * 64);
           atomicAdd(&acc[R::grp(r)], rj * (X[R::idx(r)] - p0));
         }
       }
     }
+  };
+  uint32_t s0 = uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)), s1;
+  if (s0 < S.nslices) issue(s0, buf0, o0, len0, c0);
+  while (s0 < S.nslices) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): buf0 / c0 have landed
+    s1 = s0 + nw;
+    if (s1 < S.nslices) issue(s1, buf1, o1, len1, c1);
+    process(buf0, o0, len0, c0);
+    if (s1 >= S.nslices) break;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    s0 = s1 + nw;
+    if (s0 < S.nslices) issue(s0, buf0, o0, len0, c0);
+    process(buf1, o1, len1, c1);
   }
   for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
     double zs = 0.0, hs = 0.0;
     for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
-      const typename R::T rc = R::load(S.rec_long, k);
+      const RT rc = R::load(S.rec_long, k);
       const double eg = e_l[R::grp(rc)];
       const double x = X[R::idx(rc)];
       zs += eg * (x - p0);
@@ -260,7 +316,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
         s_W += rj;
       }
       for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
-        const typename R::T rc = R::load(S.rec_long, k);
+        const RT rc = R::load(S.rec_long, k);
         atomicAdd(&acc[R::grp(rc)], rj * (X[R::idx(rc)] - p0));
       }
     }
@@ -280,6 +336,5 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
     for (uint32_t g = tid; g < G; g += kPassThreads) dst[g] = acc[g];
   }
 }
-
 
 }  // namespace msw

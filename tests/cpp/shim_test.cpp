@@ -30,7 +30,8 @@ int main(int argc, char **argv) {
       for (size_t g = 0; g < G; ++g) s += std::exp(gamma(g, j));
       worst = std::max(worst, std::fabs(s - 1.0));
     }
-    std::printf("colsum_err %.3e\nlog_lines %zu\ntheta", worst, (size_t)std::count(log.str().begin(), log.str().end(), '\n'));
+    const std::string logged = log.str();
+    std::printf("colsum_err %.3e\nlog_lines %zu\ntheta", worst, (size_t)std::count(logged.begin(), logged.end(), '\n'));
     for (double t : theta) std::printf(" %.17g", t);
     std::printf("\n");
     // error path: a bad call surfaces as std::runtime_error

@@ -50,5 +50,6 @@ def test_em_torch_shim(shim_binary, oracle):
     L = np.array(c["logl"]); logc = np.array(c["logc"], float); alpha0 = np.array(c["alpha0"])
     out = _run(shim_binary, "em", L, logc, alpha0)
     theta = np.array([float(x) for x in out["theta"].split()])
-    ref = oracle.em_dense(L, logc, alpha0, tol=1e-6, max_iters=5000)
-    np.testing.assert_allclose(theta, ref["theta"], rtol=1e-6, atol=1e-9)
+    # the shim, like mSWEEP (src/mSWEEP.cpp:422), forms theta with mixture_components on the returned gamma
+    ref = oracle.em_dense(L, logc, alpha0, tol=1e-6, max_iters=5000, want_gamma=True)
+    np.testing.assert_allclose(theta, oracle.mixture_components(ref["gamma"], logc), rtol=1e-6, atol=1e-9)
