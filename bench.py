@@ -121,7 +121,6 @@ def main():
     core.set_fixed_iters(True)
     core.prepare(logc, alpha0)               # inputs resident in HBM before the timed region
     core.run(max_iters=max(a.warmup, 1))     # W untimed warm-up steps
-    core.set_profiling(True)
 
     def sync():
         if dist is not None:
@@ -139,9 +138,16 @@ def main():
         torch.cuda.synchronize()
     sync()
     dt = time.perf_counter() - t0
-    tm = core.last_timing()
+    tm0 = core.last_timing()
     log(f"timed {a.steps} steps in {dt:.3f}s")
-    assert tm["iters"] == a.steps, (tm["iters"], a.steps)
+    assert tm0["iters"] == a.steps, (tm0["iters"], a.steps)
+    # Same K steps again with HIP events around every sweep launch (on the solve stream) for the
+    # per-kernel durations of the roofline object.  Kept out of the timed run: every event record
+    # is a barrier packet that costs ~6 us of idle GPU between two kernels.
+    core.set_profiling(True)
+    core.run(max_iters=a.steps)
+    tm = core.last_timing()
+    core.set_profiling(False)
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64).cuda()
@@ -166,7 +172,7 @@ def main():
                        "sharding": "single solve" if n_gpus == 1 else f"bootstrap replicates, 1 per GPU x {n_gpus}"},
             "iters_per_sec": a.steps * n_gpus / dt,
             "reads_x_groups_cells_per_sec": float(a.reads) * G * a.steps * n_gpus / dt,
-            "device_ms_per_step": tm["solve_ms"] / a.steps,
+            "device_ms_per_step": tm0["solve_ms"] / a.steps,
             "kernels": {"k_passA_ms": msA, "k_passB_ms": msB, "passA_launches": tm["passA_launches"],
                         "passB_launches": tm["passB_launches"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -68,7 +68,7 @@ struct Scalars {
   double bound, oldbound, bound_const;
   double tol, csum;
   // per-pass shared quantities
-  double M, U, p0, V1c, V2c, W;
+  double M, U, p0, V1c, V2c, W, kappa;
   double logzi;
   int32_t didreset, reset_pending, done, iter;
   int32_t max_iters, fixed_iters, trace_theta, flavor;  // flavor: 0 csr, 1 dense

@@ -26,7 +26,7 @@ using namespace msw;
 namespace {
 thread_local std::string g_create_error;
 constexpr size_t kLdsMax = 160 * 1024;
-constexpr int kIterBatch = 8;
+constexpr int kIterBatch = 16;
 constexpr double kInitBound = -100000.0;  // rcgpar: `long double bound = -100000.0`
 }  // namespace
 
@@ -165,7 +165,7 @@ void alloc_solve_state(msw_core *h) {
   const int nb = std::max(h->nblk, h->nblk_dense);
   h->partA.alloc(std::max(nb, 1024));
   h->partS.alloc(4 * (size_t)std::max(nb, 1024));
-  h->partR.alloc(2 * ((size_t)G / 64 + 2));
+  h->partR.alloc(kRedfinParts * ((size_t)G / 64 + 2));
   h->partAcc.alloc((size_t)std::max(nb, 1) * G);
   h->partC.alloc(1024);
   h->sc.alloc(1);
@@ -185,7 +185,11 @@ template <bool W, bool GL, bool TL>
 void launch_passA_t(msw_core *h) {
   const size_t lds = pass_lds_bytes(GL, TL, h->G, h->n_lut, true);
   auto k = k_passA<W, GL, TL>;
-  MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static size_t lds_set = 0;  // per instantiation: raise the dynamic-LDS limit only when it grows
+  if (lds > lds_set) {
+    MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h),
                      h->ew.p, h->tabB.p, h->lut.p, h->partA.p);
 }
@@ -193,7 +197,11 @@ template <bool W, bool GL, bool TL>
 void launch_passB_t(msw_core *h, int cond) {
   const size_t lds = pass_lds_bytes(GL, TL, h->G, h->n_lut, false);
   auto k = k_passB<W, GL, TL>;
-  MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, cond,
                      sell_view(h), h->e.p, h->tabB.p, h->lut.p, h->partAcc.p, h->partS.p, h->Acc.p);
 }
@@ -266,17 +274,17 @@ void launch_passB(msw_core *h, int cond) {
   // column sums across workgroups + N_g / lgamma / digamma, spread over G/64 workgroups
   const bool partials = (h->flavor == 1) || h->glds;
   const int nb = h->flavor == 0 ? h->nblk : h->nblk_dense;
-  hipLaunchKernelGGL(k_redfin, dim3((h->G + 63) / 64), dim3(256), 0, h->stream, h->sc.p, cond, (int)h->G,
+  hipLaunchKernelGGL(k_redfin, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, cond, (int)h->G,
                      partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->e.p, h->u.p,
-                     h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->partR.p);
+                     h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p);
 }
 
 void launch_fin(msw_core *h, int mode) {
   TraceDev tr{h->tr_bound.p, h->tr_newnorm.p, h->tr_beta.p, h->tr_theta.p, h->tr_reset.p};
   const int nb = h->flavor == 0 ? h->nblk : h->nblk_dense;
   hipLaunchKernelGGL(k_fin, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G, (int)h->n_lut,
-                     nb, (int)((h->G + 63) / 64), h->partS.p, h->partR.p, h->Nc.p, h->w.p, h->u.p,
-                     h->os_u.p, h->step_u.p, h->lut.p, h->e.p, h->tabB.p, h->ew.p, tr);
+                     nb, (int)((h->G + 63) / 64), h->partS.p, h->partR.p, h->Nc.p, h->u.p, h->os_u.p,
+                     h->step_u.p, h->lut.p, h->e.p, h->tabB.p, tr);
 }
 
 void poll(msw_core *h) {
@@ -328,10 +336,14 @@ void run_rcg(msw_core *h, size_t max_iters) {
   h->timing.passB_launches--;  // the initial evaluation is not an iteration
   if (h->profiling && h->evB_used) h->evB_used--;
   launch_fin(h, 2);
-  size_t enq = 0;
   const int nbA = h->flavor == 0 ? h->nblk : h->nblk_dense;
-  while (enq < max_iters) {
-    const size_t batch = std::min<size_t>(kIterBatch, max_iters - enq);
+  // Slots (state_kernels.hpp): one per iteration plus one per rejected step.  Enqueue as many as
+  // iterations are still missing, poll, repeat; nothing is launched for branches not taken.
+  size_t iters_done = 0;
+  for (;;) {
+    // fixed-iteration runs know how many slots are missing; otherwise poll every kIterBatch
+    const size_t batch = h->fixed_iters ? std::min<size_t>(256, max_iters - iters_done)
+                                        : std::min<size_t>(kIterBatch, max_iters - iters_done);
     for (size_t b = 0; b < batch; ++b) {
       launch_passA(h);
       hipLaunchKernelGGL(k_step, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, nbA,
@@ -339,13 +351,11 @@ void run_rcg(msw_core *h, size_t max_iters) {
                          h->tabB.p);
       launch_passB(h, 0);
       launch_fin(h, 0);
-      launch_passB(h, 1);
-      launch_fin(h, 1);
     }
     MSW_HIP(hipGetLastError());
-    enq += batch;
     poll(h);
-    if (h->sc_host->done) break;
+    iters_done = (size_t)h->sc_host->iter;
+    if (h->sc_host->done || iters_done >= max_iters) break;
   }
 }
 

@@ -3,8 +3,10 @@
 // 5k groups on ONE CU cost more than a sweep), ELBO + reset / convergence decision, and the
 // gradient preparation for the next pass A.
 //
-// Per iteration:  k_passA -> k_step -> k_passB -> k_redfin -> k_fin(0)
-//                 [-> k_passB(cond) -> k_redfin(cond) -> k_fin(1)]   (only after a rejected step)
+// One "slot" = k_passA -> k_step -> k_passB -> k_redfin -> k_fin.  A slot normally is one
+// iteration; after a rejected step (bound < oldbound) k_fin sets reset_pending and the NEXT slot
+// skips pass A / the step and only re-evaluates the reverted state, so a solve needs
+// iterations + resets slots and no launch is spent on a branch that is not taken.
 #pragma once
 #include "device_util.hpp"
 
@@ -49,39 +51,6 @@ __global__ __launch_bounds__(1024) void k_prepB(Scalars *sc, int G, int n_lut, c
   prepB_block(sc, a, G, n_lut, u, lut, e, X, sh);
 }
 
-// Gradient preparation for pass A from w_g = digamma(N_g) - 1 - u_g (k_redfin) and e_g:
-// centring constant kappa, {e_g, w_g - kappa} pairs, V1c = sum e*s0, V2c = sum e*s0^2 with
-// s0_g = (1-a)*logzi + w_g - kappa.  No transcendentals.
-__device__ inline void prepA_block(Scalars *sc, double a, int G, const double *w, const double *e,
-                                   double2 *ew, double *sh) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const double oma = 1.0 - a, logzi = sc->logzi;
-  double su = 0.0, sv = 0.0;
-  for (int g = tid; g < G; g += nt) {
-    const double eg = e[g];
-    su += eg;
-    sv += eg * (oma * logzi + w[g]);
-  }
-  const double U = block_sum(su, sh);
-  const double V1 = block_sum(sv, sh);
-  const double kappa = V1 / U;  // a per-EC shift leaves the variance unchanged
-  double s1 = 0.0, s2 = 0.0;
-  for (int g = tid; g < G; g += nt) {
-    const double wcg = w[g] - kappa;
-    const double eg = e[g];
-    ew[g] = make_double2(eg, wcg);
-    const double s0 = oma * logzi + wcg;
-    s1 += eg * s0;
-    s2 += eg * s0 * s0;
-  }
-  const double V1c = block_sum(s1, sh);
-  const double V2c = block_sum(s2, sh);
-  if (tid == 0) {
-    sc->V1c = V1c;
-    sc->V2c = V2c;
-  }
-}
-
 // Fletcher-Reeves step (rcgpar rcg_optl_mat: beta_FR, oldstep scaling, gamma += step) on
 // the (a, u) state, followed by the pass-B preparation.
 __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, int n_partA,
@@ -89,7 +58,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
                                               double *os_u, double *step_u, const double *lut,
                                               double *e, double *X) {
   __shared__ double sh[32];
-  if (sc->done) return;
+  if (sc->done || sc->reset_pending) return;  // a pending re-evaluation skips pass A and the step
   const int tid = threadIdx.x, nt = blockDim.x;
   const double a = sc->a, oldnorm = sc->oldnorm, bound = sc->bound;
   double os_a = sc->os_a;
@@ -133,40 +102,48 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
 }
 
 // Column sums across workgroups (fixed order) fused with the per-group math that follows them:
-// Nc_g, N_g, lgamma(N_g), (M - u_g) * Nc_g and w_g = digamma(N_g) - 1 - u_g.  One workgroup per
-// 64 groups so that the lgamma / digamma evaluations spread over ~G/64 CUs.
+// Nc_g, N_g, lgamma(N_g), (M - u_g) * Nc_g, w_g = digamma(N_g) - 1 - u_g and the pass-A gradient
+// preparation {e_g, w_g - kappa} with its sums S0 = sum e, S1 = sum e*s0, S2 = sum e*s0^2
+// (s0_g = (1-a)*logzi + w_g - kappa; kappa = lagged centring constant, see k_fin).  One
+// 1024-thread workgroup per 64 groups: 16 wavefronts split the partial rows, so the lgamma /
+// digamma evaluations spread over ~G/64 CUs instead of one.
 //   nblk > 0: sum partAcc[b*G + g] over b;  nblk == 0: Acc already holds the totals.
-__global__ __launch_bounds__(256) void k_redfin(const Scalars *sc, int cond_reset, int G, int nblk,
-                                               int npartS, const double *partAcc, const double *Acc,
-                                               const double *partS, const double *e, const double *u,
-                                               const double *alpha0, double *Nc, double *N, double *w,
-                                               double *partR) {
+constexpr int kRedfinParts = 5;
+__global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int cond_reset, int G, int nblk,
+                                                int npartS, const double *partAcc, const double *Acc,
+                                                const double *partS, const double *e, const double *u,
+                                                const double *alpha0, double *Nc, double *N, double *w,
+                                                double2 *ew, double *partR) {
   __shared__ double sh[32];
-  __shared__ double accs[4][64];
+  __shared__ double accs[16][64];
   if (sc->done) return;
   if (cond_reset && !sc->reset_pending) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = blockIdx.x * 64 + lane;
   // W = sum_j r_j : every workgroup forms it in the same fixed order
   double pw = 0.0;
-  for (int b = tid; b < npartS; b += 256) pw += partS[4 * b + 2];
+  for (int b = tid; b < npartS; b += 1024) pw += partS[4 * b + 2];
   const double W = block_sum(pw, sh);
   double s = 0.0;
   if (g < G) {
     if (nblk > 0) {
-      for (int b = wv; b < nblk; b += 4) s += partAcc[(size_t)b * G + g];
+      for (int b = wv; b < nblk; b += 16) s += partAcc[(size_t)b * G + g];
     } else if (wv == 0) {
       s = Acc[g];
     }
   }
   accs[wv][lane] = s;
   __syncthreads();
-  double lgv = 0.0, muv = 0.0;
-  if (wv == 0 && g < G) {
-    const double A = ((accs[0][lane] + accs[1][lane]) + accs[2][lane]) + accs[3][lane];
+  if (wv != 0) return;
+  double lgv = 0.0, muv = 0.0, s0v = 0.0, s1v = 0.0, s2v = 0.0;
+  if (g < G) {
+    double A = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) A += accs[i][lane];
     double nc;
     const double ug = u[g];
-    if (sc->flavor == 0) {
+    const int flavor = sc->flavor;
+    if (flavor == 0) {
       nc = e[g] * (sc->p0 * W + A);
       muv = (sc->M - ug) * nc;
     } else {
@@ -176,56 +153,77 @@ __global__ __launch_bounds__(256) void k_redfin(const Scalars *sc, int cond_rese
     Nc[g] = nc;
     N[g] = n;
     lgv = lgamma(n);
-    w[g] = digamma_ref(n) - 1.0 - ug;
-  }
-  if (wv == 0) {
-    lgv = wave_sum(lgv);
-    muv = wave_sum(muv);
-    if (lane == 0) {
-      partR[2 * blockIdx.x] = lgv;
-      partR[2 * blockIdx.x + 1] = muv;
+    const double wg = digamma_ref(n) - 1.0 - ug;
+    w[g] = wg;
+    if (flavor == 0) {
+      const double eg = e[g], wc = wg - sc->kappa;
+      const double s0 = (1.0 - sc->a) * sc->logzi + wc;
+      ew[g] = make_double2(eg, wc);
+      s0v = eg;
+      s1v = eg * s0;
+      s2v = eg * s0 * s0;
     }
+  }
+  lgv = wave_sum(lgv);
+  muv = wave_sum(muv);
+  s0v = wave_sum(s0v);
+  s1v = wave_sum(s1v);
+  s2v = wave_sum(s2v);
+  if (lane == 0) {
+    double *o = partR + kRedfinParts * blockIdx.x;
+    o[0] = lgv;
+    o[1] = muv;
+    o[2] = s0v;
+    o[3] = s1v;
+    o[4] = s2v;
   }
 }
 
 // ELBO (rcgpar ELBO_rcg_mat + bound_const), the bound < oldbound steepest-descent retry
-// (revert_step), the convergence test and the gradient preparation for the next pass A.
-//   mode 2: initial update_N_k only;  mode 0: first evaluation of an iteration;
-//   mode 1: re-evaluation after a reset (runs only when reset_pending).
+// (revert_step) and the convergence test.
+//   mode 2: initial update_N_k only;  otherwise a first evaluation of an iteration, or -- when
+//   reset_pending is set -- the re-evaluation after a rejected step.
+// kappa (centring constant of the pass-A step values) advances to the e-weighted mean just
+// measured: kappa += S1 / S0.
 __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int n_lut, int npartS,
                                              int npartR, const double *partS, const double *partR,
-                                             const double *Nc, const double *w, double *u,
-                                             double *os_u, const double *step_u, const double *lut,
-                                             double *e, double *X, double2 *ew, TraceDev tr) {
+                                             const double *Nc, double *u, double *os_u,
+                                             const double *step_u, const double *lut, double *e,
+                                             double *X, TraceDev tr) {
   __shared__ double sh[32];
   if (sc->done) return;
-  if (mode == 1 && !sc->reset_pending) return;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int flavor = sc->flavor;
+  const int reeval = sc->reset_pending;
   const double a = sc->a, oldbound = sc->oldbound;
-  const double beta = sc->beta, tol = sc->tol, csum = sc->csum;
-  double p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
+  const double beta = sc->beta, tol = sc->tol, csum = sc->csum, kappa = sc->kappa;
+  double p1 = 0.0, p2 = 0.0, q[kRedfinParts] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int b = tid; b < npartS; b += nt) {
     p1 += partS[4 * b];
     p2 += partS[4 * b + 1];
   }
-  for (int b = tid; b < npartR; b += nt) {
-    p3 += partR[2 * b];
-    p4 += partR[2 * b + 1];
-  }
+  for (int b = tid; b < npartR; b += nt)
+    for (int i = 0; i < kRedfinParts; ++i) q[i] += partR[kRedfinParts * b + i];
   const double s_clogZ = block_sum(p1, sh);
   const double s_rH = block_sum(p2, sh);
-  const double lg = block_sum(p3, sh);
-  const double mu = block_sum(p4, sh);
+  const double lg = block_sum(q[0], sh);
+  const double mu = block_sum(q[1], sh);
+  const double S0 = block_sum(q[2], sh);
+  const double S1 = block_sum(q[3], sh);
+  const double S2 = block_sum(q[4], sh);
   if (mode == 2) {
-    if (flavor == 0) prepA_block(sc, a, G, w, e, ew, sh);
+    if (tid == 0 && flavor == 0) {
+      sc->V1c = S1;
+      sc->V2c = S2;
+      sc->kappa = kappa + S1 / S0;
+    }
     return;
   }
   const double coef = (flavor == 0) ? (1.0 - a) : 1.0;
   const double bound = sc->bound_const + s_clogZ + coef * s_rH + mu + lg;
-  int didreset = sc->didreset;
+  const int didreset = sc->didreset;
   __syncthreads();
-  if (mode == 0 && bound < oldbound) {
+  if (!reeval && bound < oldbound) {
     // bad step: revert to steepest descent (gamma += oldm; gamma -= oldstep) and re-evaluate
     double a2 = a;
     if (beta > 0) {
@@ -242,7 +240,7 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
     if (flavor == 0) prepB_block(sc, a2, G, n_lut, u, lut, e, X, sh);
     return;
   }
-  if (mode == 0) {
+  if (!reeval) {
     // oldstep = step
     for (int g = tid; g < G; g += nt) os_u[g] = step_u[g];
   }
@@ -255,9 +253,14 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
   if (it + 1 >= sc->max_iters) done = 1;
   __syncthreads();
   if (tid == 0) {
-    if (mode == 0) sc->os_a = sc->step_a;
+    if (!reeval) sc->os_a = sc->step_a;
     sc->bound = bound;
     sc->reset_pending = 0;
+    if (flavor == 0) {
+      sc->V1c = S1;
+      sc->V2c = S2;
+      sc->kappa = kappa + S1 / S0;
+    }
     if (it < kMaxTrace) {
       tr.bound[it] = bound;
       tr.newnorm[it] = sc->newnorm;
@@ -267,7 +270,6 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
     sc->iter = it + 1;
     sc->done = done;
   }
-  if (!done && flavor == 0) prepA_block(sc, a, G, w, e, ew, sh);
 }
 
 // ---------------------------------------------------------------------------------------

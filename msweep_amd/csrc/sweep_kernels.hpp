@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
   using RT = typename R::T;
-  if (sc->done) return;
+  if (sc->done || sc->reset_pending) return;  // a pending re-evaluation skips pass A
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t G = S.n_groups, n_lut = S.n_lut;
   double *sh = reinterpret_cast<double *>(smem);
@@ -251,8 +251,11 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
 #pragma unroll
         for (int k = 0; k < kRegCells; k += 2) {
           if ((uint32_t)k < len) {
-            atomicAdd(&acc[R::grp(b[k])], rj * xc[k]);
-            atomicAdd(&acc[R::grp(b[k + 1])], rj * xc[k + 1]);
+            // padding records (group id == G) all target one address: skip them instead of
+            // serialising up to 64 same-address LDS atomics per step
+            const uint32_t g0 = R::grp(b[k]), g1 = R::grp(b[k + 1]);
+            if (g0 != G) atomicAdd(&acc[g0], rj * xc[k]);
+            if (g1 != G) atomicAdd(&acc[g1], rj * xc[k + 1]);
           }
         }
       }

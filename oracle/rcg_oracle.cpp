@@ -80,6 +80,21 @@ struct Dense {
   const double *logc;
   const double *alpha0;
 
+  static size_t nthreads() {
+#ifdef _OPENMP
+    return (size_t)omp_get_max_threads();
+#else
+    return 1;
+#endif
+  }
+  static size_t tid() {
+#ifdef _OPENMP
+    return (size_t)omp_get_thread_num();
+#else
+    return 0;
+#endif
+  }
+
   // rcgpar logsumexp(gamma_Z, m): m_j = logsumexp over groups; gamma -= m
   void logsumexp(double *gamma, double *m) const {
 #pragma omp parallel
@@ -105,6 +120,7 @@ struct Dense {
     std::vector<double> dg(G);
     for (size_t g = 0; g < G; ++g) dg[g] = orc_digamma(N[g]) - 1.0;
     double newnorm = 0.0;
+    std::vector<double> part(nthreads(), 0.0);
 #pragma omp parallel
     {
       for (size_t g = 0; g < G; ++g) {
@@ -125,29 +141,35 @@ struct Dense {
           local += t;
         }
       }
-#pragma omp atomic
-      newnorm += local;
+      part[tid()] = local;
     }
+    // combine the per-thread partial sums in thread order (run-to-run reproducible)
+    for (double v : part) newnorm += v;
     return newnorm;
   }
 
   void update_N(const double *gamma, double *N) const {
-    for (size_t g = 0; g < G; ++g) N[g] = 0.0;
+    const size_t nt = nthreads();
+    std::vector<double> part(nt * G, 0.0);
 #pragma omp parallel
     {
       for (size_t g = 0; g < G; ++g) {
         double acc = 0.0;
 #pragma omp for schedule(static) nowait
         for (size_t j = 0; j < E; ++j) acc += std::exp(gamma[g * E + j] + logc[j]);
-#pragma omp atomic
-        N[g] += acc;
+        part[tid() * G + g] = acc;
       }
     }
-    for (size_t g = 0; g < G; ++g) N[g] += alpha0[g];
+    for (size_t g = 0; g < G; ++g) {
+      double acc = 0.0;
+      for (size_t t = 0; t < nt; ++t) acc += part[t * G + g];
+      N[g] = acc + alpha0[g];
+    }
   }
 
   long double elbo(const double *gamma, const double *N, long double bound_const) const {
     long double bound = bound_const;
+    std::vector<long double> part(nthreads(), 0.0L);
 #pragma omp parallel
     {
       long double acc = 0.0L;
@@ -160,9 +182,9 @@ struct Dense {
           acc += (w == 0.0) ? 0.0 : w * (L[g * E + j] - gz);
         }
       }
-#pragma omp critical
-      bound += acc;
+      part[tid()] = acc;
     }
+    for (long double v : part) bound += v;
     for (size_t g = 0; g < G; ++g) bound += std::lgamma(N[g]);
     return bound;
   }
@@ -264,16 +286,24 @@ void orc_mixture_components(const double *gamma, size_t G, size_t E, const doubl
                             double *theta) {
   double total = 0.0;
   for (size_t j = 0; j < E; ++j) total += std::exp(logc[j]);
-  for (size_t g = 0; g < G; ++g) theta[g] = 0.0;
+  const size_t nt = (size_t)orc_num_threads();
+  std::vector<double> part(nt * G, 0.0);
 #pragma omp parallel
   for (size_t g = 0; g < G; ++g) {
     double acc = 0.0;
 #pragma omp for schedule(static) nowait
     for (size_t j = 0; j < E; ++j) acc += std::exp(gamma[g * E + j] + logc[j]);
-#pragma omp atomic
-    theta[g] += acc;
+#ifdef _OPENMP
+    part[(size_t)omp_get_thread_num() * G + g] = acc;
+#else
+    part[g] = acc;
+#endif
   }
-  for (size_t g = 0; g < G; ++g) theta[g] /= total;
+  for (size_t g = 0; g < G; ++g) {
+    double acc = 0.0;
+    for (size_t t = 0; t < nt; ++t) acc += part[t * G + g];
+    theta[g] = acc / total;
+  }
 }
 
 }  // extern "C"
@@ -289,6 +319,10 @@ namespace {
 struct StructState {
   double a = 0.0;
   std::vector<double> u;
+  // centring constant of the pass-A step values.  Any constant is valid (a per-EC shift leaves
+  // the variance unchanged); the e-weighted mean of the PREVIOUS pass A is used so that the
+  // centred values can be formed in the same sweep that produces w (no extra global reduction).
+  mutable double kappa = 0.0;
 };
 
 // Abstract "L" access for the two structured variants.
@@ -362,16 +396,14 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
   for (size_t g = 0; g < G; ++g) M = std::max(M, st.u[g]);
   const double a = st.a, oma = 1.0 - a;
   const double p0 = std::exp(a * S.logzi);
-  std::vector<double> e(G), s0(G);
-  double U = 0.0, V1 = 0.0;
+  std::vector<double> e(G);
+  double U = 0.0;
   for (size_t g = 0; g < G; ++g) {
     e[g] = std::exp(st.u[g] - M);
-    s0[g] = oma * S.logzi + w[g];
     U += e[g];
-    V1 += e[g] * s0[g];
   }
-  // centre the step values (a per-column shift leaves the variance unchanged)
-  const double kappa = V1 / U;
+  // centre the step values with the lagged constant (see StructState::kappa)
+  const double kappa = st.kappa;
   double V1c = 0.0, V2c = 0.0;
   std::vector<double> wc(G);
   for (size_t g = 0; g < G; ++g) {
@@ -380,6 +412,7 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
     V1c += e[g] * s0c;
     V2c += e[g] * s0c * s0c;
   }
+  st.kappa = kappa + V1c / U;
   std::vector<double> xm(S.n_lut), A1(S.n_lut), A2(S.n_lut);
   for (size_t i = 0; i < S.n_lut; ++i) {
     const double T = S.lut[i];
