@@ -160,6 +160,16 @@ def main():
         msB = tm["passB_ms"] / max(tm["passB_launches"], 1)
         dom, ms_dom, b_dom = ("k_passB", msB, tm["bytes_passB"]) if msB >= msA else ("k_passA", msA, tm["bytes_passA"])
         achieved = b_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+        # collected offline on this exact workload and committed under profiles/
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")))
+            wl = tj["workload"]
+            if (wl["reads"], wl["groups"], wl["seed"]) == (a.reads, G, a.seed) and n_gpus == 1:
+                traffic = next(v["hbm_bytes_per_launch"] for k, v in tj["raw"].items() if dom in k)
+        except Exception:
+            traffic = None
         line = {
             "metric": "EM iters/sec + reads×groups cells/sec, 10M reads × 5k groups",
             "value": cells / dt, "unit": "cells/s",
@@ -176,7 +186,7 @@ def main():
             "kernels": {"k_passA_ms": msA, "k_passB_ms": msB, "passA_launches": tm["passA_launches"],
                         "passB_launches": tm["passB_launches"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_dom, "avg_launch_ms": ms_dom},
             "setup_s": {"generate": t_gen},
         }
