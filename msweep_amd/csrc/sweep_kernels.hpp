@@ -7,6 +7,8 @@
 // is the only HBM traffic; everything else is gathered from LDS).  Slice bounds are wave-uniform
 // and kept in SGPRs (readfirstlane) so the cell loops are scalar branches, not exec-mask loops.
 #pragma once
+#include <type_traits>
+
 #include "device_util.hpp"
 #include "sell.hpp"
 
@@ -106,16 +108,39 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   auto process = [&](uint32_t sl, RT(&b)[kRegCells], uint32_t o, uint32_t len) {
     AccA c = {0.0, 0.0, 0.0};
     if (len <= (uint32_t)kRegCells) {
+      // straight-line code per slice length (len is wave-uniform and even): all LDS gathers of
+      // the slice can be in flight together instead of one scalar-branched pair at a time
+      auto fixed = [&](auto LEN) {
+        constexpr int L = decltype(LEN)::value;
+        constexpr int B = 4;  // cells gathered together (register budget: 128 VGPRs at 16 waves/CU)
 #pragma unroll
-      for (int k = 0; k < kRegCells; k += 2) {
-        if ((uint32_t)k < len) {
-          const uint32_t g0 = R::grp(b[k]), g1 = R::grp(b[k + 1]);
-          const uint32_t i0 = R::idx(b[k]), i1 = R::idx(b[k + 1]);
-          const double e0 = E_(g0), e1 = E_(g1), w0 = W_(g0), w1 = W_(g1);
-          const double x0 = X[i0], x1 = X[i1], T0 = T[i0], T1 = T[i1];
-          cellA(c, cst, e0, w0, x0, T0);
-          cellA(c, cst, e1, w1, x1, T1);
+        for (int k0 = 0; k0 < L; k0 += B) {
+          double ev[B], wv[B], xv[B], tv[B];
+#pragma unroll
+          for (int k = 0; k < B; ++k) {
+            if (k0 + k < L) {
+              const uint32_t g = R::grp(b[k0 + k]), i = R::idx(b[k0 + k]);
+              ev[k] = E_(g);
+              wv[k] = W_(g);
+              xv[k] = X[i];
+              tv[k] = T[i];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < B; ++k)
+            if (k0 + k < L) cellA(c, cst, ev[k], wv[k], xv[k], tv[k]);
         }
+      };
+      switch (len) {
+        case 0: break;
+        case 2: fixed(std::integral_constant<int, 2>{}); break;
+        case 4: fixed(std::integral_constant<int, 4>{}); break;
+        case 6: fixed(std::integral_constant<int, 6>{}); break;
+        case 8: fixed(std::integral_constant<int, 8>{}); break;
+        case 10: fixed(std::integral_constant<int, 10>{}); break;
+        case 12: fixed(std::integral_constant<int, 12>{}); break;
+        case 14: fixed(std::integral_constant<int, 14>{}); break;
+        default: fixed(std::integral_constant<int, 16>{}); break;
       }
     } else {
       const size_t base = (size_t)o * 64 + lane;
@@ -225,22 +250,45 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
   auto process = [&](RT(&b)[kRegCells], uint32_t o, uint32_t len, double c) {
     double zs = 0.0, hs = 0.0;
     if (len <= (uint32_t)kRegCells) {
-      double xc[kRegCells];
+      // row sums: straight-line code per slice length (wave-uniform, even); x - p0 of every cell
+      // stays in registers for the scatter
+      double xv[kRegCells];
+      auto fixed = [&](auto LEN) {
+        constexpr int L = decltype(LEN)::value;
+        constexpr int B = 4;
 #pragma unroll
-      for (int k = 0; k < kRegCells; k += 2) {
-        if ((uint32_t)k < len) {
-          const uint32_t g0 = R::grp(b[k]), g1 = R::grp(b[k + 1]);
-          const uint32_t i0 = R::idx(b[k]), i1 = R::idx(b[k + 1]);
-          const double e0 = e_l[g0], e1 = e_l[g1];
-          const double x0 = X[i0], x1 = X[i1], T0 = T[i0], T1 = T[i1];
-          const double m0 = x0 - p0, m1 = x1 - p0;
-          zs += e0 * m0;
-          hs += e0 * (x0 * T0 - p0l);
-          zs += e1 * m1;
-          hs += e1 * (x1 * T1 - p0l);
-          xc[k] = m0;
-          xc[k + 1] = m1;
+        for (int k0 = 0; k0 < L; k0 += B) {
+          double ev[B], tv[B];
+#pragma unroll
+          for (int k = 0; k < B; ++k) {
+            if (k0 + k < L) {
+              const uint32_t g = R::grp(b[k0 + k]), i = R::idx(b[k0 + k]);
+              ev[k] = e_l[g];
+              xv[k0 + k] = X[i];
+              tv[k] = T[i];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < B; ++k) {
+            if (k0 + k < L) {
+              const double x = xv[k0 + k], m = x - p0;
+              zs += ev[k] * m;
+              hs += ev[k] * (x * tv[k] - p0l);
+              xv[k0 + k] = m;
+            }
+          }
         }
+      };
+      switch (len) {
+        case 0: break;
+        case 2: fixed(std::integral_constant<int, 2>{}); break;
+        case 4: fixed(std::integral_constant<int, 4>{}); break;
+        case 6: fixed(std::integral_constant<int, 6>{}); break;
+        case 8: fixed(std::integral_constant<int, 8>{}); break;
+        case 10: fixed(std::integral_constant<int, 10>{}); break;
+        case 12: fixed(std::integral_constant<int, 12>{}); break;
+        case 14: fixed(std::integral_constant<int, 14>{}); break;
+        default: fixed(std::integral_constant<int, 16>{}); break;
       }
       if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
@@ -254,8 +302,8 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
             // padding records (group id == G) all target one address: skip them instead of
             // serialising up to 64 same-address LDS atomics per step
             const uint32_t g0 = R::grp(b[k]), g1 = R::grp(b[k + 1]);
-            if (g0 != G) atomicAdd(&acc[g0], rj * xc[k]);
-            if (g1 != G) atomicAdd(&acc[g1], rj * xc[k + 1]);
+            if (g0 != G) atomicAdd(&acc[g0], rj * xv[k]);
+            if (g1 != G) atomicAdd(&acc[g1], rj * xv[k + 1]);
           }
         }
       }
