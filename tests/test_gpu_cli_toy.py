@@ -1,0 +1,118 @@
+"""GPU: config[0] -- a toy Themisto plaintext alignment through the command line
+(`python -m msweep_amd`, the flags of docs/example.md:43-51) against the oracle's restatement of
+the same pipeline (Likelihood.hpp counts + LUT + dense matrix, rcgpar loop, bootstrap stream)."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from msweep_amd.__main__ import main
+from msweep_amd.alignment import Alignment
+from msweep_amd.reference import read_reference
+from test_gpu_rcg import assert_theta
+
+pytestmark = pytest.mark.gpu
+
+
+def _toy(tmp_path, n_reads=1500, seed=3):
+    """4 clusters x ~10 reference sequences, paired-end reads drawn from theta = (.5,.3,.15,.05)."""
+    rng = np.random.default_rng(seed)
+    sizes = [12, 9, 10, 8]
+    names = [f"clust{k + 1}" for k in range(4)]
+    indicators = [names[k] for k in range(4) for _ in range(sizes[k])]
+    order = rng.permutation(len(indicators))
+    indicators = [indicators[i] for i in order]            # group members scattered over target ids
+    members = {n: [i for i, x in enumerate(indicators) if x == n] for n in names}
+    theta = [0.5, 0.3, 0.15, 0.05]
+    l1, l2 = [], []
+    for r in range(n_reads):
+        g = rng.choice(4, p=theta)
+        hit = set(rng.choice(members[names[g]], max(1, rng.binomial(sizes[g], 0.65)), replace=False).tolist())
+        for o in range(4):
+            if o != g and rng.random() < 0.3:
+                hit |= set(rng.choice(members[names[o]], max(1, rng.binomial(sizes[o], 0.15)), replace=False).tolist())
+        h1 = sorted(hit | ({int(rng.integers(0, len(indicators)))} if rng.random() < 0.1 else set()))
+        h2 = sorted(hit) if rng.random() > 0.05 else []
+        l1.append(" ".join(map(str, [r] + h1)))
+        l2.append(" ".join(map(str, [r] + h2)))
+    (tmp_path / "toy_1.txt").write_text("\n".join(l1) + "\n")
+    (tmp_path / "toy_2.txt").write_text("\n".join(l2) + "\n")
+    (tmp_path / "clustering.txt").write_text("\n".join(indicators) + "\n")
+    return names
+
+
+def _oracle_pipeline(oracle, tmp_path, min_hits=0):
+    grouping = read_reference(open(tmp_path / "clustering.txt"))
+    aln = Alignment(len(grouping.group_indicators))
+    aln.read("intersection", [open(tmp_path / "toy_1.txt"), open(tmp_path / "toy_2.txt")])
+    aln.collapse()
+    counts = oracle.group_counts(aln.ec_tptr, aln.ec_targets, grouping.group_indicators, grouping.get_n_groups())
+    L, mask = oracle.fill_ll_mat(counts, aln.ec_counts, grouping.get_sizes(), min_hits=min_hits)
+    logc = oracle.fill_ec_counts(aln.ec_counts)
+    return grouping, aln, L, mask, logc
+
+
+def _parse(path):
+    head, rows = {}, []
+    for ln in open(path):
+        ln = ln.rstrip("\n")
+        if ln.startswith("#"):
+            k, _, v = ln.partition("\t")
+            head[k] = v
+        else:
+            p = ln.split("\t")
+            rows.append((p[0], [float(x) for x in p[1:]]))
+    return head, rows
+
+
+def test_toy_cli_plain(tmp_path, oracle):
+    _toy(tmp_path)
+    prefix = str(tmp_path / "toy")
+    rc = main(["--themisto-1", str(tmp_path / "toy_1.txt"), "--themisto-2", str(tmp_path / "toy_2.txt"),
+               "-i", str(tmp_path / "clustering.txt"), "-t", "1", "-o", prefix])
+    assert rc == 0
+    grouping, aln, L, mask, logc = _oracle_pipeline(oracle, tmp_path)
+    ref = oracle.rcg_optl_dense(L, logc, np.ones(L.shape[0]))
+    theta = oracle.mixture_components(ref["gamma"], logc)
+    head, rows = _parse(prefix + "_abundances.txt")
+    assert head["#num_reads:"] == str(aln.n_reads()) and head["#num_aligned:"] == str(int(aln.ec_counts.sum()))
+    assert [r[0] for r in rows] == grouping.get_names()
+    got = np.array([r[1][0] for r in rows])
+    np.testing.assert_allclose(got, theta, rtol=6e-6)          # the file holds 6 significant digits
+    assert got[np.argmax(theta)] > 0.3
+
+
+def test_toy_cli_bootstrap_and_min_hits(tmp_path, oracle):
+    _toy(tmp_path)
+    prefix = str(tmp_path / "boot")
+    rc = main(["--themisto", f"{tmp_path / 'toy_1.txt'},{tmp_path / 'toy_2.txt'}", "-i", str(tmp_path / "clustering.txt"),
+               "-o", prefix, "--iters", "3", "--seed", "42", "--min-hits", "1"])
+    assert rc == 0
+    grouping, aln, L, mask, logc = _oracle_pipeline(oracle, tmp_path, min_hits=1)
+    head, rows = _parse(prefix + "_abundances.txt")
+    assert head["#bootstrap_iters:"] == "3"
+    est = [n for n, m in zip(grouping.get_names(), mask) if m]
+    assert [r[0] for r in rows][:len(est)] == est
+    alpha = np.ones(L.shape[0])
+    base = oracle.mixture_components(oracle.rcg_optl_dense(L, logc, alpha)["gamma"], logc)
+    w = aln.ec_counts.astype(np.uint32)
+    counts = oracle.bootstrap_counts(w, 42, int(w.sum()), 3)
+    cols = [base]
+    for b in range(3):
+        with np.errstate(divide="ignore"):
+            lc = np.log(counts[b].astype(float))
+        cols.append(oracle.mixture_components(oracle.rcg_optl_dense(L, lc, alpha)["gamma"], lc))
+    got = np.array([r[1] for r in rows[:len(est)]])
+    np.testing.assert_allclose(got, np.array(cols).T, rtol=7e-6, atol=1e-12)
+
+
+def test_cli_error_paths(tmp_path, capsys):
+    _toy(tmp_path)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("0 1 x\n")
+    rc = main(["--themisto-1", str(bad), "-i", str(tmp_path / "clustering.txt")])
+    assert rc == 1 and "Reading the pseudoalignments failed" in capsys.readouterr().err
+    rc = main(["--themisto-1", str(tmp_path / "toy_1.txt"), "-i", str(tmp_path / "clustering.txt"),
+               "--alphas", "1,2"])
+    assert rc == 1
