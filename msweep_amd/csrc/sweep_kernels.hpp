@@ -65,28 +65,20 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   const uint32_t G = S.n_groups, n_lut = S.n_lut;
   double *sh = reinterpret_cast<double *>(smem);
   double *p = sh + 32;
-  // group vectors as two 8-byte arrays in LDS (bank rule of the upload scheduler: group id mod 32)
-  const double *X = X_g, *T = T_g;
-  double *e_l = p, *w_l = p + (G + 1);
+  // {e_g, w_g} and {X_i, T_i} as 16-byte entries: one ds_read_b128 per lookup.  A wave can have
+  // at most 16 LDS operations in flight (lgkmcnt is 4 bits), so wide reads double the cells whose
+  // gathers overlap with arithmetic.
+  double2 *ew_l = reinterpret_cast<double2 *>(p);
   if (GLDS) {
     p += 2 * ((size_t)G + 1);
-    for (uint32_t g = tid; g <= G; g += kPassThreads) {
-      const double2 v = ew_g[g];
-      e_l[g] = v.x;
-      w_l[g] = v.y;
-    }
+    for (uint32_t g = tid; g <= G; g += kPassThreads) ew_l[g] = ew_g[g];
   }
+  double2 *xt_l = reinterpret_cast<double2 *>(p);
   if (TLDS) {
-    double *xl = p, *tl = p + n_lut;
-    for (uint32_t i = tid; i < n_lut; i += kPassThreads) {
-      xl[i] = X_g[i];
-      tl[i] = T_g[i];
-    }
-    X = xl;
-    T = tl;
+    for (uint32_t i = tid; i < n_lut; i += kPassThreads) xt_l[i] = make_double2(X_g[i], T_g[i]);
   }
-  auto E_ = [&](uint32_t g) -> double { return GLDS ? e_l[g] : ew_g[g].x; };
-  auto W_ = [&](uint32_t g) -> double { return GLDS ? w_l[g] : ew_g[g].y; };
+  auto EW_ = [&](uint32_t g) -> double2 { return GLDS ? ew_l[g] : ew_g[g]; };
+  auto XT_ = [&](uint32_t i) -> double2 { return TLDS ? xt_l[i] : make_double2(X_g[i], T_g[i]); };
   const double p0 = sc->p0, U = sc->U, logzi = sc->logzi, oma = 1.0 - sc->a;
   const CstA cst = {p0, oma, oma * oma, p0 * logzi, p0 * logzi * logzi};
   const double zbase = p0 * U, b1 = p0 * sc->V1c, b2 = p0 * sc->V2c;
@@ -112,23 +104,20 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
       // the slice can be in flight together instead of one scalar-branched pair at a time
       auto fixed = [&](auto LEN) {
         constexpr int L = decltype(LEN)::value;
-        constexpr int B = 4;  // cells gathered together (register budget: 128 VGPRs at 16 waves/CU)
+        constexpr int B = 8;  // cells gathered together: 16 x ds_read_b128 in flight
 #pragma unroll
         for (int k0 = 0; k0 < L; k0 += B) {
-          double ev[B], wv[B], xv[B], tv[B];
+          double2 ewv[B], xtv[B];
 #pragma unroll
           for (int k = 0; k < B; ++k) {
             if (k0 + k < L) {
-              const uint32_t g = R::grp(b[k0 + k]), i = R::idx(b[k0 + k]);
-              ev[k] = E_(g);
-              wv[k] = W_(g);
-              xv[k] = X[i];
-              tv[k] = T[i];
+              ewv[k] = EW_(R::grp(b[k0 + k]));
+              xtv[k] = XT_(R::idx(b[k0 + k]));
             }
           }
 #pragma unroll
           for (int k = 0; k < B; ++k)
-            if (k0 + k < L) cellA(c, cst, ev[k], wv[k], xv[k], tv[k]);
+            if (k0 + k < L) cellA(c, cst, ewv[k].x, ewv[k].y, xtv[k].x, xtv[k].y);
         }
       };
       switch (len) {
@@ -147,8 +136,10 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
       for (uint32_t k = 0; k < len; k += 2) {
         const RT r0 = R::load(S.rec, base + (size_t)k * 64);
         const RT r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
-        cellA(c, cst, E_(R::grp(r0)), W_(R::grp(r0)), X[R::idx(r0)], T[R::idx(r0)]);
-        cellA(c, cst, E_(R::grp(r1)), W_(R::grp(r1)), X[R::idx(r1)], T[R::idx(r1)]);
+        const double2 a0 = EW_(R::grp(r0)), a1 = EW_(R::grp(r1));
+        const double2 x0 = XT_(R::idx(r0)), x1 = XT_(R::idx(r1));
+        cellA(c, cst, a0.x, a0.y, x0.x, x0.y);
+        cellA(c, cst, a1.x, a1.y, x1.x, x1.y);
       }
     }
     if (sl * 64 + lane < n_sell) {
@@ -175,7 +166,8 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
     AccA c = {0.0, 0.0, 0.0};
     for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
       const RT rc = R::load(S.rec_long, k);
-      cellA(c, cst, E_(R::grp(rc)), W_(R::grp(rc)), X[R::idx(rc)], T[R::idx(rc)]);
+      const double2 a0 = EW_(R::grp(rc)), x0 = XT_(R::idx(rc));
+      cellA(c, cst, a0.x, a0.y, x0.x, x0.y);
     }
     const double zs = block_sum(c.zs, sh), t1 = block_sum(c.t1, sh), t2 = block_sum(c.t2, sh);
     if (tid == 0) {
@@ -209,7 +201,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
   const uint32_t G = S.n_groups, n_lut = S.n_lut;
   double *sh = reinterpret_cast<double *>(smem);
   double *p = sh + 32;
-  const double *e_l = e_g, *X = X_g, *T = T_g;
+  const double *e_l = e_g;
   double *acc = accGlobal;
   if (GLDS) {
     double *el = p;
@@ -221,15 +213,11 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
     }
     e_l = el;
   }
+  double2 *xt_l = reinterpret_cast<double2 *>(p);  // {X_i, T_i}: one ds_read_b128 per lookup
   if (TLDS) {
-    double *xl = p, *tl = p + n_lut;
-    for (uint32_t i = tid; i < n_lut; i += kPassThreads) {
-      xl[i] = X_g[i];
-      tl[i] = T_g[i];
-    }
-    X = xl;
-    T = tl;
+    for (uint32_t i = tid; i < n_lut; i += kPassThreads) xt_l[i] = make_double2(X_g[i], T_g[i]);
   }
+  auto XT_ = [&](uint32_t i) -> double2 { return TLDS ? xt_l[i] : make_double2(X_g[i], T_g[i]); };
   const double p0 = sc->p0, U = sc->U, logzi = sc->logzi;
   const double p0l = p0 * logzi;
   const double zbase = p0 * U, hbase = p0l * U;
@@ -258,22 +246,21 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
         constexpr int B = 4;
 #pragma unroll
         for (int k0 = 0; k0 < L; k0 += B) {
-          double ev[B], tv[B];
+          double ev[B];
+          double2 xt[B];
 #pragma unroll
           for (int k = 0; k < B; ++k) {
             if (k0 + k < L) {
-              const uint32_t g = R::grp(b[k0 + k]), i = R::idx(b[k0 + k]);
-              ev[k] = e_l[g];
-              xv[k0 + k] = X[i];
-              tv[k] = T[i];
+              ev[k] = e_l[R::grp(b[k0 + k])];
+              xt[k] = XT_(R::idx(b[k0 + k]));
             }
           }
 #pragma unroll
           for (int k = 0; k < B; ++k) {
             if (k0 + k < L) {
-              const double x = xv[k0 + k], m = x - p0;
+              const double m = xt[k].x - p0;
               zs += ev[k] * m;
-              hs += ev[k] * (x * tv[k] - p0l);
+              hs += ev[k] * (xt[k].x * xt[k].y - p0l);
               xv[k0 + k] = m;
             }
           }
@@ -313,12 +300,11 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
         const RT r0 = R::load(S.rec, base + (size_t)k * 64);
         const RT r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
         const double e0 = e_l[R::grp(r0)], e1 = e_l[R::grp(r1)];
-        const double x0 = X[R::idx(r0)], x1 = X[R::idx(r1)];
-        const double T0 = T[R::idx(r0)], T1 = T[R::idx(r1)];
-        zs += e0 * (x0 - p0);
-        hs += e0 * (x0 * T0 - p0l);
-        zs += e1 * (x1 - p0);
-        hs += e1 * (x1 * T1 - p0l);
+        const double2 t0 = XT_(R::idx(r0)), t1 = XT_(R::idx(r1));
+        zs += e0 * (t0.x - p0);
+        hs += e0 * (t0.x * t0.y - p0l);
+        zs += e1 * (t1.x - p0);
+        hs += e1 * (t1.x * t1.y - p0l);
       }
       if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
@@ -328,7 +314,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
         s_W += rj;
         for (uint32_t k = 0; k < len; ++k) {
           const RT r = R::load(S.rec, base + (size_t)k * 64);
-          atomicAdd(&acc[R::grp(r)], rj * (X[R::idx(r)] - p0));
+          atomicAdd(&acc[R::grp(r)], rj * (XT_(R::idx(r)).x - p0));
         }
       }
     }
@@ -351,9 +337,9 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
     for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
       const RT rc = R::load(S.rec_long, k);
       const double eg = e_l[R::grp(rc)];
-      const double x = X[R::idx(rc)];
-      zs += eg * (x - p0);
-      hs += eg * (x * T[R::idx(rc)] - p0l);
+      const double2 t = XT_(R::idx(rc));
+      zs += eg * (t.x - p0);
+      hs += eg * (t.x * t.y - p0l);
     }
     zs = block_sum(zs, sh);
     hs = block_sum(hs, sh);
@@ -368,7 +354,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
       }
       for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
         const RT rc = R::load(S.rec_long, k);
-        atomicAdd(&acc[R::grp(rc)], rj * (X[R::idx(rc)] - p0));
+        atomicAdd(&acc[R::grp(rc)], rj * (XT_(R::idx(rc)).x - p0));
       }
     }
   }
