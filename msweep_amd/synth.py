@@ -23,7 +23,10 @@ def make_csr_problem(n_reads, n_groups, seed=2, max_other=15, dirichlet=0.05, th
     rng = np.random.Generator(np.random.PCG64(seed))
     G = int(n_groups)
     sizes = _group_sizes(rng, G)
+    sup = None
     if theta_support is not None and theta_support < G:
+        # cfg5: reads (source AND spurious hits) only touch `theta_support` groups, so that
+        # --min-hits 1 prunes the rest
         sup = np.sort(rng.choice(G, int(theta_support), replace=False))
         theta = np.zeros(G)
         theta[sup] = rng.dirichlet(np.full(len(sup), dirichlet))
@@ -41,7 +44,8 @@ def make_csr_problem(n_reads, n_groups, seed=2, max_other=15, dirichlet=0.05, th
         cols = np.empty((n, W), np.int64)
         cols[:, 0] = src
         if max_other:
-            cols[:, 1:] = rng.integers(0, G, (n, max_other))
+            oth = rng.integers(0, G if sup is None else len(sup), (n, max_other))
+            cols[:, 1:] = oth if sup is None else sup[oth]
             cols[:, 1:][np.arange(max_other)[None, :] >= K[:, None]] = SENT
         valid = cols < SENT
         nsz = np.where(valid, sizes[np.minimum(cols, G - 1)].astype(np.int64), 1)

@@ -78,3 +78,25 @@ def test_cfg3_csr_10M_x_5k(gpu_core):
     resid = (((acc + 1.0) - N).abs() / N).max().item()
     assert resid < 5e-3
     print(f"cfg3: iters {res['iters']}, fixed-point residual {resid:.2e}")
+
+
+def test_cfg5_scaled_sparse_min_hits(gpu_core):
+    """cfg5 scaled to one test box: sparse 3M reads x 20k groups, theta supported on 2 000 groups,
+    <= 8 listed groups per read, --min-hits 1 pruning through the device likelihood build."""
+    from msweep_amd.likelihood import from_alignment
+    p = synth.make_csr_problem(3_000_000, 20_000, seed=3, max_other=7, theta_support=2000)
+    aln = synth.csr_to_targets(p)
+    lik = from_alignment(gpu_core, aln["ec_tptr"], aln["ec_targets"], aln["target_group"], p["group_sizes"],
+                         p["ec_counts"], min_hits=1)
+    hit = np.zeros(20_000, bool)
+    hit[p["grp"]] = True
+    np.testing.assert_array_equal(lik.groups_considered(), hit)        # groups with >= 1 aligned read
+    G2 = lik.n_groups
+    assert G2 == int(hit.sum()) and 1900 <= G2 <= 2000            # ~90 % of the groups pruned
+    res = gpu_core.solve(lik.log_counts(), np.ones(G2))
+    assert res["iters"] < 5000 and res["theta"].sum() == pytest.approx(1.0, abs=1e-11)
+    # mass concentrates on the true support
+    kept = np.nonzero(hit)[0]
+    on_support = p["theta_true"][kept] > 0
+    assert res["theta"][on_support].sum() > 0.99
+    print(f"cfg5-scaled: {G2} of 20000 groups kept, iters {res['iters']}")
