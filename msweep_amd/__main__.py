@@ -9,7 +9,7 @@ import numpy as np
 from . import parallel
 from .alignment import Alignment
 from .core import ALGO_EM, ALGO_RCG, PREC_DOUBLE, PREC_FLOAT, Core, MswError
-from .likelihood import from_alignment
+from .likelihood import from_alignment, from_dense
 from .reference import read_reference
 from .sample import BootstrapSample, PlainSample
 
@@ -35,25 +35,82 @@ def parse(argv):
     ap.add_argument("--alphas")
     ap.add_argument("--zero-inflation", type=float, default=0.01)
     ap.add_argument("--min-hits", type=int, default=0)
+    ap.add_argument("--run-rate", action="store_true")
+    ap.add_argument("--write-probs", action="store_true")
+    ap.add_argument("--print-probs", action="store_true")
+    ap.add_argument("--write-likelihood", action="store_true")
+    ap.add_argument("--read-likelihood")
+    ap.add_argument("--no-fit-model", action="store_true")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args(argv)
 
 
+def read_likelihood_file(path, n_groups):
+    counts, cols = [], []
+    with open(path) as f:
+        for line in f:
+            parts = line.rstrip("\n").split("\t")
+            if len(parts) != n_groups + 1:
+                raise RuntimeError("Could not read from the likelihoods file.")
+            counts.append(int(parts[0]))
+            cols.append([float(x) for x in parts[1:]])
+    return np.array(counts, np.uint64), np.ascontiguousarray(np.array(cols).T)
+
+
+def write_likelihood_file(f, ec_counts, L):
+    for j in range(L.shape[1]):
+        f.write(str(int(ec_counts[j])) + "\t" + "\t".join("%g" % x for x in L[:, j]) + "\n")
+
+
+def write_probs(of, names, zero_names, probs):
+    of.write("ec_id\t" + "\t".join(list(names) + list(zero_names)) + "\n")
+    for j in range(probs.shape[1]):
+        of.write(str(j) + "\t" + "\t".join(["%g" % x for x in probs[:, j]] + ["0"] * len(zero_names)) + "\n")
+    of.write("\n")
+    of.flush()
+
+
+def _digamma(x):      # src/Sample.cpp:87-97
+    r = 0.0
+    while x < 7:
+        r -= 1 / x
+        x += 1
+    x -= 0.5
+    xx = 1.0 / x
+    xx2 = xx * xx
+    xx4 = xx2 * xx2
+    return r + np.log(x) + (1. / 24.) * xx2 - (7.0 / 960.0) * xx4 + (31.0 / 8064.0) * xx4 * xx2 - (127.0 / 30720.0) * xx4 * xx4
+
+
+def dirichlet_kld_rate(alphas):
+    """Sample::dirichlet_kld + get_rates (src/Sample.cpp:99-152).  alphas_i = sum_j c_j exp(gamma_ij) is the
+    column sum the solve already reduced on the device (theta_i * sum c)."""
+    from math import lgamma
+    a0 = float(np.sum(alphas))
+    log_kld = np.array([np.log(max(lgamma(a0) - lgamma(a0 - aj) - lgamma(aj) + aj * (_digamma(aj) - _digamma(a0)), 1e-16))
+                        for aj in map(float, alphas)])
+    mx = max(0.0, float(log_kld.max()))
+    lsum = np.log(np.exp(log_kld - mx).sum()) + mx
+    return np.exp(log_kld), np.exp(log_kld - lsum)
+
+
 def main(argv=None):
     a = parse(sys.argv[1:] if argv is None else argv)
+    aln = None
     try:
         with open(a.indicators) as f:
             grouping = read_reference(f)
-        files = a.themisto.split(",") if a.themisto else [x for x in (a.themisto_1, a.themisto_2) if x]
-        if not files:
-            raise RuntimeError("no pseudoalignment files given")
-        aln = Alignment(len(grouping.group_indicators))
-        streams = [open(p) for p in files]
-        aln.read(a.themisto_mode, streams)
-        for s in streams:
-            s.close()
-        aln.collapse()
+        if not a.read_likelihood:
+            files = a.themisto.split(",") if a.themisto else [x for x in (a.themisto_1, a.themisto_2) if x]
+            if not files:
+                raise RuntimeError("no pseudoalignment files given")
+            aln = Alignment(len(grouping.group_indicators))
+            streams = [open(p) for p in files]
+            aln.read(a.themisto_mode, streams)
+            for s in streams:
+                s.close()
+            aln.collapse()
     except (RuntimeError, OSError) as ex:
         sys.stderr.write(f"Reading the pseudoalignments failed:\n  {ex}\nexiting\n")
         return 1
@@ -64,11 +121,26 @@ def main(argv=None):
     prec = PREC_FLOAT if a.emprecision == "float" else PREC_DOUBLE
     try:
         core = Core(a.device)
-        lik = from_alignment(core, aln.ec_tptr, aln.ec_targets, grouping.group_indicators, grouping.get_sizes(),
-                             aln.ec_counts, a.q, a.e, a.zero_inflation, a.min_hits)
-    except MswError as ex:
+        if a.read_likelihood:
+            # --read-likelihood (include/Likelihood.hpp:224-253): "count \t L(0,j) ... L(G-1,j)" per EC
+            ec_counts, L = read_likelihood_file(a.read_likelihood, grouping.get_n_groups())
+            lik = from_dense(core, L, np.log(ec_counts.astype(np.float64)))
+            n_reads = total_reads = int(ec_counts.sum())
+        else:
+            lik = from_alignment(core, aln.ec_tptr, aln.ec_targets, grouping.group_indicators, grouping.get_sizes(),
+                                 aln.ec_counts, a.q, a.e, a.zero_inflation, a.min_hits)
+            ec_counts = aln.ec_counts
+            n_reads = aln.n_reads()
+    except (MswError, RuntimeError, OSError, ValueError) as ex:
         sys.stderr.write(f"Building the log-likelihood array failed:\n  {ex}\nexiting\n")
         return 1
+    if a.write_likelihood:
+        # --write-likelihood (include/Likelihood.hpp:255-273), default ostream precision
+        with open(f"{a.prefix}_likelihoods.txt" if a.prefix else "likelihoods.txt", "w") as f:
+            write_likelihood_file(f, ec_counts, lik.log_mat())
+    if a.no_fit_model:
+        core.close()
+        return 0
     G = lik.n_groups
     prior = np.ones(G)
     if a.alphas:
@@ -76,8 +148,8 @@ def main(argv=None):
         if len(prior) != G:
             sys.stderr.write("Error: --alphas must have the same number of values as there are groups.")
             return 1
-    total = int(aln.ec_counts.sum())
-    sample = BootstrapSample(aln.n_reads(), total, a.iters) if a.iters > 0 else PlainSample(aln.n_reads(), total)
+    total = int(ec_counts.sum())
+    sample = BootstrapSample(n_reads, total, a.iters) if a.iters > 0 else PlainSample(n_reads, total)
     try:
         res = core.solve(lik.log_counts(), prior, a.tol, a.max_iters, algo, prec)
         if a.verbose:
@@ -93,7 +165,7 @@ def main(argv=None):
             # ConstructSample quirk (src/Sample.cpp:38-39): --bootstrap-count without --bin-reads
             # passes the number of ITERATIONS as the count
             draws = a.iters if a.bootstrap_count > 0 else total
-            w = aln.ec_counts.astype(np.uint32)
+            w = ec_counts.astype(np.uint32)
             thetas, _ = core.bootstrap(w, seed, draws, 0, a.iters, prior, a.tol, a.max_iters, algo, prec)
             for row in thetas:
                 sample.store_abundances(row)
@@ -104,8 +176,26 @@ def main(argv=None):
     mask = lik.groups_considered()
     est = [n for n, m in zip(names, mask) if m]
     zero = [n for n, m in zip(names, mask) if not m]
+    if a.write_probs or a.print_probs:
+        # Sample::write_probs (src/Sample.cpp:63-85): header ec_id + group names, one row per EC of exp(gamma)
+        probs = np.exp(core.gamma())
+        for dst in ([open(f"{a.prefix}_probs.tsv", "w")] if a.write_probs and a.prefix else []) + \
+                   ([sys.stdout] if a.print_probs or (a.write_probs and not a.prefix) else []):
+            write_probs(dst, est, zero if a.min_hits > 0 else [], probs)
+            if dst is not sys.stdout:
+                dst.close()
     out = open(f"{a.prefix}_abundances.txt", "w") if a.prefix else sys.stdout
-    if a.min_hits > 0:
+    if a.run_rate:
+        # experimental RATE / KLD (src/Sample.cpp:99-152, table written at src/mSWEEP.cpp:529-545)
+        kld, rate = dirichlet_kld_rate(np.asarray(sample.get_abundances()) * total)
+        sample._header(out)
+        out.write("#c_id\tmean_theta\tRATE\tKLD\n")
+        for n, t, r, k in zip(est, sample.get_abundances(), rate, kld):
+            out.write(f"{n}\t{t:g}\t{r:g}\t{k:g}\n")
+        for n in zero:
+            out.write(f"{n}\t0\t0\t0\n")
+        out.flush()
+    elif a.min_hits > 0:
         sample.write_abundances2(est, zero, out)
     else:
         sample.write_abundances(est, out)

@@ -116,3 +116,33 @@ def test_cli_error_paths(tmp_path, capsys):
     rc = main(["--themisto-1", str(tmp_path / "toy_1.txt"), "-i", str(tmp_path / "clustering.txt"),
                "--alphas", "1,2"])
     assert rc == 1
+
+
+def test_cli_likelihood_roundtrip_probs_and_rate(tmp_path, oracle, capsys):
+    """--write-likelihood -> --read-likelihood round trip (include/Likelihood.hpp:224-273), --write-probs
+    (src/Sample.cpp:63-85) and --run-rate (src/Sample.cpp:99-152, src/mSWEEP.cpp:529-545)."""
+    _toy(tmp_path, n_reads=600)
+    pre = str(tmp_path / "rt")
+    base = ["--themisto-1", str(tmp_path / "toy_1.txt"), "--themisto-2", str(tmp_path / "toy_2.txt"),
+            "-i", str(tmp_path / "clustering.txt"), "-o", pre]
+    assert main(base + ["--write-likelihood", "--no-fit-model"]) == 0
+    assert not os.path.exists(pre + "_abundances.txt")
+    grouping, aln, L, mask, logc = _oracle_pipeline(oracle, tmp_path)
+    rows = [ln.split("\t") for ln in open(pre + "_likelihoods.txt").read().splitlines()]
+    assert len(rows) == aln.n_ecs() and [int(r[0]) for r in rows] == aln.ec_counts.tolist()
+    np.testing.assert_allclose(np.array([[float(x) for x in r[1:]] for r in rows]).T, L, rtol=1e-5)
+    # estimate from the written (6-digit) likelihood through the dense path
+    pre2 = str(tmp_path / "rt2")
+    assert main(["--read-likelihood", pre + "_likelihoods.txt", "-i", str(tmp_path / "clustering.txt"), "-o", pre2,
+                 "--write-probs", "--run-rate"]) == 0
+    assert main(base) == 0
+    _, rows_direct = _parse(pre + "_abundances.txt")
+    head2, rows_rt = _parse(pre2 + "_abundances.txt")
+    assert head2["#c_id"] == "mean_theta\tRATE\tKLD"
+    np.testing.assert_allclose([r[1][0] for r in rows_rt], [r[1][0] for r in rows_direct], rtol=2e-4)
+    rate = np.array([r[1][1] for r in rows_rt])
+    assert rate.sum() == pytest.approx(1.0, rel=1e-4) and np.all(rate >= 0)
+    probs = [ln.split("\t") for ln in open(pre2 + "_probs.tsv").read().splitlines() if ln]
+    assert probs[0] == ["ec_id"] + grouping.get_names() and len(probs) == aln.n_ecs() + 1
+    P = np.array([[float(x) for x in r[1:]] for r in probs[1:]])
+    np.testing.assert_allclose(P.sum(1), 1.0, rtol=1e-4)
