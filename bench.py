@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ecs", type=int, default=50000)
     ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed / RCCL even with one rank (exercises the N > 1 code path)")
     return ap.parse_args()
 
 
@@ -70,6 +72,26 @@ def cpu_baseline(prob, lut, n_ecs, iters):
                       f"{dt:.1f} s; iters/s on the sample = {r['iters'] / dt:.3f}"}
 
 
+def cpu_baseline_structured(prob, lut, iters):
+    """Second CPU line (apples to apples): the oracle's structured CSR restatement -- the same
+    O(nnz) algorithm the GPU runs -- single-threaded on the FULL workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    from oracle import Oracle
+    O = Oracle()
+    G = len(prob["group_sizes"])
+    E = len(prob["rowptr"]) - 1
+    lutidx = (prob["grp"].astype(np.uint32) * lut.shape[1] + prob["cnt"]).astype(np.uint32)
+    logc = np.log(prob["ec_counts"].astype(float))
+    t0 = time.perf_counter()
+    r = O.rcg_optl_csr(prob["rowptr"], prob["grp"], lutidx, lut, np.log(0.01), G, logc, np.ones(G), tol=-1.0,
+                       max_iters=iters)
+    dt = time.perf_counter() - t0
+    return {"value": float(E) * G * r["iters"] / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": f"full cfg3 workload, {r['iters']} iterations of the structured CSR restatement "
+                      f"(oracle/rcg_oracle.cpp orc_rcg_optl_csr), {dt:.1f} s; iters/s = {r['iters'] / dt:.3f}"}
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -81,11 +103,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if a.gpus != world and world > 1 and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     n_gpus = world
@@ -107,7 +131,7 @@ def main():
     lik = from_grouped_counts(core, prob["rowptr"], prob["grp"], prob["cnt"], prob["ec_counts"],
                               prob["group_sizes"])
     alpha0 = np.ones(G)
-    if world > 1:
+    if dist is not None:
         # replicate `rank` of the bootstrap, drawn on the device from the reference's ONE sequential
         # mt19937_64(--seed 42) stream (src/BootstrapSample.cpp:60-73): rank r owns draws
         # [r * n_reads, (r + 1) * n_reads), exactly what a single-GPU run would give replicate r
@@ -198,6 +222,11 @@ def main():
             except Exception as ex:  # the baseline is reporting only
                 line["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {ex}"}
+            try:
+                line["cpu_baseline_structured"] = cpu_baseline_structured(prob, precalc_lls(prob["group_sizes"]), 3)
+            except Exception as ex:
+                line["cpu_baseline_structured"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port",
+                                                   "sample": f"failed: {ex}"}
         print(json.dumps(line), flush=True)
     core.close()
     if dist is not None:
