@@ -162,3 +162,138 @@ __global__ __launch_bounds__(256) void k_transpose(const double *src, size_t ld,
 
 
 }  // namespace msw
+
+// ---------------------------------------------------------------------------------------
+// Dense sweeps for 1024 < G <= 8192 groups: an EC's G values no longer fit a wavefront's
+// registers, so each EC is swept twice (the second read is served by L2): an online-softmax
+// sweep for the row statistics, then a sweep that adds the normalised responsibilities into the
+// lane-owned column-sum registers.  u / w are read through L2 (shared by all waves).
+// ---------------------------------------------------------------------------------------
+namespace msw {
+
+template <int NREG>
+__global__ __launch_bounds__(256) void k_dense_big_passA(const Scalars *sc, const double *Lt, int G,
+                                                        uint32_t E, const double *u, const double *w,
+                                                        double *partA) {
+  __shared__ double sh[32];
+  if (sc->done || sc->reset_pending) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
+  const double a = sc->a, oma = 1.0 - a;
+  double nn = 0.0;
+  for (uint32_t j = gw; j < E; j += nw) {
+    const double *row = Lt + (size_t)j * G;
+    // sweep 1: running max m, S0 = sum exp(y - m), S1 = sum exp(y - m) * s
+    double m = -INFINITY, S0 = 0.0, S1 = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < NREG; ++i) {
+      const int g = lane + 64 * i;
+      if (g < G) {
+        const double x = row[g];
+        const double y = a * x + u[g], s = oma * x + w[g];
+        if (y > m) {
+          const double f = exp(m - y);
+          S0 = S0 * f + 1.0;
+          S1 = S1 * f + s;
+          m = y;
+        } else {
+          const double p = exp(y - m);
+          S0 += p;
+          S1 += p * s;
+        }
+      }
+    }
+    const double mw = wave_max(m);
+    const double f = (m == -INFINITY) ? 0.0 : exp(m - mw);
+    const double Z = wave_sum(S0 * f), sbar = wave_sum(S1 * f) / Z;
+    // sweep 2: variance about the mean
+    double v = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < NREG; ++i) {
+      const int g = lane + 64 * i;
+      if (g < G) {
+        const double x = row[g];
+        const double d = oma * x + w[g] - sbar;
+        v += exp(a * x + u[g] - mw) * d * d;
+      }
+    }
+    nn += wave_sum(v) / Z;
+  }
+  double t = (lane == 0) ? nn : 0.0;
+  t = block_sum(t, sh);
+  if (threadIdx.x == 0) partA[blockIdx.x] = t;
+}
+
+template <int NREG>
+__global__ __launch_bounds__(256) void k_dense_big_passB(const Scalars *sc, int cond_reset,
+                                                        const double *Lt, int G, uint32_t E,
+                                                        const double *cvec, const double *u,
+                                                        double *partAcc, double *partS) {
+  __shared__ double sh[32];
+  if (sc->done) return;
+  if (cond_reset && !sc->reset_pending) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
+  const double a = sc->a;
+  double acc[NREG];
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) acc[i] = 0.0;
+  double s_clogZ = 0.0, s_rH = 0.0;
+  for (uint32_t j = gw; j < E; j += nw) {
+    const double c = cvec[j];
+    if (c == 0.0) continue;  // wave-uniform: a zero-count EC contributes nothing to pass B
+    const double *row = Lt + (size_t)j * G;
+    double m = -INFINITY, S0 = 0.0, S1 = 0.0;  // S1 = sum exp(y - m) * (x - y)
+#pragma unroll 4
+    for (int i = 0; i < NREG; ++i) {
+      const int g = lane + 64 * i;
+      if (g < G) {
+        const double x = row[g];
+        const double y = a * x + u[g];
+        if (y > m) {
+          const double f = exp(m - y);
+          S0 = S0 * f + 1.0;
+          S1 = S1 * f + (x - y);
+          m = y;
+        } else {
+          const double p = exp(y - m);
+          S0 += p;
+          S1 += p * (x - y);
+        }
+      }
+    }
+    const double mw = wave_max(m);
+    const double f = (m == -INFINITY) ? 0.0 : exp(m - mw);
+    const double Z = wave_sum(S0 * f);
+    const double hs = wave_sum(S1 * f) + mw * Z;  // sum p * (x - (y - mw))
+    const double rj = c / Z;
+    s_clogZ += c * log(Z);
+    s_rH += rj * hs;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int g = lane + 64 * i;
+      if (g < G) acc[i] += rj * exp(a * row[g] + u[g] - mw);
+    }
+  }
+  // per-wave partial rows: partAcc has 4 rows per workgroup (k_redfin sums rows in fixed order)
+  double *dst = partAcc + ((size_t)blockIdx.x * 4 + wv) * G;
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const int g = lane + 64 * i;
+    if (g < G) dst[g] = acc[i];
+  }
+  double t1 = (lane == 0) ? s_clogZ : 0.0, t2 = (lane == 0) ? s_rH : 0.0;
+  t1 = block_sum(t1, sh);
+  t2 = block_sum(t2, sh);
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 4; ++q) {  // one partS slot per partial row keeps npartS == number of rows
+      double *o = partS + 4 * ((size_t)blockIdx.x * 4 + q);
+      o[0] = q == 0 ? t1 : 0.0;
+      o[1] = q == 0 ? t2 : 0.0;
+      o[2] = 0.0;
+      o[3] = 0.0;
+    }
+  }
+}
+
+}  // namespace msw

@@ -47,6 +47,8 @@ struct msw_core {
   int nblk = 0;      // persistent workgroups of the CSR sweeps
   int nblk_dense = 0;
   int nreg = 0;
+  // rows of per-workgroup (or per-wave) column-sum partials pass B leaves for k_redfin
+  int npart_rows() const { return flavor == 0 ? nblk : (nreg >= 32 ? 4 * nblk_dense : nblk_dense); }
 
   // ---- solve state ---------------------------------------------------------------------
   DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc, tabB;
@@ -162,7 +164,7 @@ void alloc_solve_state(msw_core *h) {
   h->cvec.alloc(E);
   h->logc_d.alloc(E);
   h->tabB.alloc((size_t)std::max<uint32_t>(h->n_lut, 1));
-  const int nb = std::max(h->nblk, h->nblk_dense);
+  const int nb = std::max(h->nblk, std::max(h->nblk_dense, h->npart_rows()));
   h->partA.alloc(std::max(nb, 1024));
   h->partS.alloc(4 * (size_t)std::max(nb, 1024));
   h->partR.alloc(kRedfinParts * ((size_t)G / 64 + 2));
@@ -232,14 +234,27 @@ void launch_dense_B(msw_core *h, int cond) {
   hipLaunchKernelGGL(k_dense_passB<NREG>, dim3(h->nblk_dense), dim3(256), lds, h->stream, h->sc.p,
                      cond, h->Lt.p, (int)h->G, h->E, h->cvec.p, h->u.p, h->partAcc.p, h->partS.p);
 }
-#define MSW_DISPATCH_NREG(fn, ...)                       \
+template <int NREG>
+void launch_dense_big_A(msw_core *h) {
+  hipLaunchKernelGGL(k_dense_big_passA<NREG>, dim3(h->nblk_dense), dim3(256), 0, h->stream, h->sc.p,
+                     h->Lt.p, (int)h->G, h->E, h->u.p, h->w.p, h->partA.p);
+}
+template <int NREG>
+void launch_dense_big_B(msw_core *h, int cond) {
+  hipLaunchKernelGGL(k_dense_big_passB<NREG>, dim3(h->nblk_dense), dim3(256), 0, h->stream, h->sc.p,
+                     cond, h->Lt.p, (int)h->G, h->E, h->cvec.p, h->u.p, h->partAcc.p, h->partS.p);
+}
+#define MSW_DISPATCH_NREG(fn, fnbig, ...)                \
   do {                                                   \
     switch (h->nreg) {                                   \
       case 1: fn<1>(__VA_ARGS__); break;                 \
       case 2: fn<2>(__VA_ARGS__); break;                 \
       case 4: fn<4>(__VA_ARGS__); break;                 \
       case 8: fn<8>(__VA_ARGS__); break;                 \
-      default: fn<16>(__VA_ARGS__); break;               \
+      case 16: fn<16>(__VA_ARGS__); break;               \
+      case 32: fnbig<32>(__VA_ARGS__); break;            \
+      case 64: fnbig<64>(__VA_ARGS__); break;            \
+      default: fnbig<128>(__VA_ARGS__); break;           \
     }                                                    \
   } while (0)
 
@@ -250,7 +265,7 @@ void launch_passA(msw_core *h) {
     MSW_HIP(hipEventRecord(ev->first, h->stream));
   }
   if (h->flavor == 0) MSW_DISPATCH3(launch_passA_t, h);
-  else MSW_DISPATCH_NREG(launch_dense_A, h);
+  else MSW_DISPATCH_NREG(launch_dense_A, launch_dense_big_A, h);
   MSW_HIP(hipGetLastError());
   if (ev) MSW_HIP(hipEventRecord(ev->second, h->stream));
   h->timing.passA_launches++;
@@ -266,14 +281,14 @@ void launch_passB(msw_core *h, int cond) {
     if (!h->glds) MSW_HIP(hipMemsetAsync(h->Acc.p, 0, ((size_t)h->G + 1) * sizeof(double), h->stream));
     MSW_DISPATCH3(launch_passB_t, h, cond);
   } else {
-    MSW_DISPATCH_NREG(launch_dense_B, h, cond);
+    MSW_DISPATCH_NREG(launch_dense_B, launch_dense_big_B, h, cond);
   }
   MSW_HIP(hipGetLastError());
   if (ev) MSW_HIP(hipEventRecord(ev->second, h->stream));
   if (!cond) h->timing.passB_launches++;
   // column sums across workgroups + N_g / lgamma / digamma, spread over G/64 workgroups
   const bool partials = (h->flavor == 1) || h->glds;
-  const int nb = h->flavor == 0 ? h->nblk : h->nblk_dense;
+  const int nb = h->npart_rows();
   hipLaunchKernelGGL(k_redfin, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, cond, (int)h->G,
                      partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->e.p, h->u.p,
                      h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p);
@@ -281,7 +296,7 @@ void launch_passB(msw_core *h, int cond) {
 
 void launch_fin(msw_core *h, int mode) {
   TraceDev tr{h->tr_bound.p, h->tr_newnorm.p, h->tr_beta.p, h->tr_theta.p, h->tr_reset.p};
-  const int nb = h->flavor == 0 ? h->nblk : h->nblk_dense;
+  const int nb = h->npart_rows();
   hipLaunchKernelGGL(k_fin, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G, (int)h->n_lut,
                      nb, (int)((h->G + 63) / 64), h->partS.p, h->partR.p, h->Nc.p, h->u.p, h->os_u.p,
                      h->step_u.p, h->lut.p, h->e.p, h->tabB.p, tr);

@@ -268,3 +268,21 @@ def test_error_behaviour(gpu_core):
         gpu_core.solve(np.zeros(1), np.ones(2), algo=7)
     with pytest.raises(MswError):
         Core(99)
+
+
+@pytest.mark.parametrize("E,G,seed", [(1500, 1500, 7), (400, 5000, 8)])
+def test_dense_path_many_groups(gpu_core, oracle, E, G, seed):
+    """1024 < G <= 8192: the two-sweep dense kernels (an EC no longer fits a wavefront's registers)."""
+    p = synth.make_dense_problem(E, G, seed=seed)
+    alpha0 = np.ones(G)
+    from_dense(gpu_core, p["logl"], p["logc"])
+    gpu_core.set_trace_theta(15)
+    res = gpu_core.solve(p["logc"], alpha0)
+    tr = gpu_core.trace(15, with_theta=True)
+    s = oracle.rcg_optl_dense_structured(p["logl"], p["logc"], alpha0, trace=15, want_gamma=True)
+    lockstep(tr, s["trace"], 15, rel=1e-8)
+    assert abs(res["iters"] - s["iters"]) <= 3
+    assert_theta(res["theta"], s["theta"])
+    np.testing.assert_allclose(np.exp(gpu_core.gamma()), np.exp(s["gamma"]), atol=1e-6)
+    with pytest.raises(MswError, match="n_groups <= 8192"):
+        gpu_core.set_dense_logl(np.zeros((8193, 2)))
