@@ -68,12 +68,10 @@ struct Scalars {
   double bound, oldbound, bound_const;
   double tol, csum;
   // per-pass shared quantities
-  double M, U, p0, V1c, V2c, W, kappa;
+  double M, U, p0, V1c, V2c, kappa;
   double logzi;
   int32_t didreset, reset_pending, done, iter;
   int32_t max_iters, fixed_iters, trace_theta, flavor;  // flavor: 0 csr, 1 dense
-  int32_t n_flagged;  // rows whose background term cancelled badly (diagnostic)
-  int32_t pad;
 };
 
 }  // namespace msw

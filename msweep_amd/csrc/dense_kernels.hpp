@@ -67,15 +67,13 @@ __global__ __launch_bounds__(256) void k_dense_passA(const Scalars *sc, const do
 }
 
 template <int NREG>
-__global__ __launch_bounds__(256) void k_dense_passB(const Scalars *sc, int cond_reset,
-                                                    const double *Lt, int G, uint32_t E,
+__global__ __launch_bounds__(256) void k_dense_passB(const Scalars *sc, const double *Lt, int G, uint32_t E,
                                                     const double *cvec, const double *u,
                                                     double *partAcc, double *partS) {
   extern __shared__ __align__(16) unsigned char smem[];
   double *sh = reinterpret_cast<double *>(smem);
   double *accl = sh + 32;  // [4][G]
   if (sc->done) return;
-  if (cond_reset && !sc->reset_pending) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
   const double a = sc->a;
@@ -225,13 +223,11 @@ __global__ __launch_bounds__(256) void k_dense_big_passA(const Scalars *sc, cons
 }
 
 template <int NREG>
-__global__ __launch_bounds__(256) void k_dense_big_passB(const Scalars *sc, int cond_reset,
-                                                        const double *Lt, int G, uint32_t E,
+__global__ __launch_bounds__(256) void k_dense_big_passB(const Scalars *sc, const double *Lt, int G, uint32_t E,
                                                         const double *cvec, const double *u,
                                                         double *partAcc, double *partS) {
   __shared__ double sh[32];
   if (sc->done) return;
-  if (cond_reset && !sc->reset_pending) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
   const double a = sc->a;

@@ -196,7 +196,7 @@ void launch_passA_t(msw_core *h) {
                      h->ew.p, h->tabB.p, h->lut.p, h->partA.p);
 }
 template <bool W, bool GL, bool TL>
-void launch_passB_t(msw_core *h, int cond) {
+void launch_passB_t(msw_core *h) {
   const size_t lds = pass_lds_bytes(GL, TL, h->G, h->n_lut, false);
   auto k = k_passB<W, GL, TL>;
   static size_t lds_set = 0;
@@ -204,8 +204,7 @@ void launch_passB_t(msw_core *h, int cond) {
     MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
-  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, cond,
-                     sell_view(h), h->e.p, h->tabB.p, h->lut.p, h->partAcc.p, h->partS.p, h->Acc.p);
+  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h), h->e.p, h->tabB.p, h->lut.p, h->partAcc.p, h->partS.p, h->Acc.p);
 }
 
 #define MSW_DISPATCH3(fn, ...)                                                       \
@@ -229,10 +228,10 @@ void launch_dense_A(msw_core *h) {
                      h->Lt.p, (int)h->G, h->E, h->u.p, h->w.p, h->partA.p);
 }
 template <int NREG>
-void launch_dense_B(msw_core *h, int cond) {
+void launch_dense_B(msw_core *h) {
   const size_t lds = (32 + 4 * (size_t)h->G) * sizeof(double);
   hipLaunchKernelGGL(k_dense_passB<NREG>, dim3(h->nblk_dense), dim3(256), lds, h->stream, h->sc.p,
-                     cond, h->Lt.p, (int)h->G, h->E, h->cvec.p, h->u.p, h->partAcc.p, h->partS.p);
+                     h->Lt.p, (int)h->G, h->E, h->cvec.p, h->u.p, h->partAcc.p, h->partS.p);
 }
 template <int NREG>
 void launch_dense_big_A(msw_core *h) {
@@ -240,9 +239,9 @@ void launch_dense_big_A(msw_core *h) {
                      h->Lt.p, (int)h->G, h->E, h->u.p, h->w.p, h->partA.p);
 }
 template <int NREG>
-void launch_dense_big_B(msw_core *h, int cond) {
+void launch_dense_big_B(msw_core *h) {
   hipLaunchKernelGGL(k_dense_big_passB<NREG>, dim3(h->nblk_dense), dim3(256), 0, h->stream, h->sc.p,
-                     cond, h->Lt.p, (int)h->G, h->E, h->cvec.p, h->u.p, h->partAcc.p, h->partS.p);
+                     h->Lt.p, (int)h->G, h->E, h->cvec.p, h->u.p, h->partAcc.p, h->partS.p);
 }
 #define MSW_DISPATCH_NREG(fn, fnbig, ...)                \
   do {                                                   \
@@ -271,25 +270,25 @@ void launch_passA(msw_core *h) {
   h->timing.passA_launches++;
 }
 
-void launch_passB(msw_core *h, int cond) {
+void launch_passB(msw_core *h) {
   std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
-  if (h->profiling && !cond) {
+  if (h->profiling) {
     ev = &next_pair(h->evB, h->evB_used);
     MSW_HIP(hipEventRecord(ev->first, h->stream));
   }
   if (h->flavor == 0) {
     if (!h->glds) MSW_HIP(hipMemsetAsync(h->Acc.p, 0, ((size_t)h->G + 1) * sizeof(double), h->stream));
-    MSW_DISPATCH3(launch_passB_t, h, cond);
+    MSW_DISPATCH3(launch_passB_t, h);
   } else {
-    MSW_DISPATCH_NREG(launch_dense_B, launch_dense_big_B, h, cond);
+    MSW_DISPATCH_NREG(launch_dense_B, launch_dense_big_B, h);
   }
   MSW_HIP(hipGetLastError());
   if (ev) MSW_HIP(hipEventRecord(ev->second, h->stream));
-  if (!cond) h->timing.passB_launches++;
+  h->timing.passB_launches++;
   // column sums across workgroups + N_g / lgamma / digamma, spread over G/64 workgroups
   const bool partials = (h->flavor == 1) || h->glds;
   const int nb = h->npart_rows();
-  hipLaunchKernelGGL(k_redfin, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, cond, (int)h->G,
+  hipLaunchKernelGGL(k_redfin, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, (int)h->G,
                      partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->e.p, h->u.p,
                      h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p);
 }
@@ -347,7 +346,7 @@ void run_rcg(msw_core *h, size_t max_iters) {
   // initial update_N_k on gamma = log(1/G)
   hipLaunchKernelGGL(k_prepB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->u.p, h->lut.p,
                      h->e.p, h->tabB.p);
-  launch_passB(h, 0);
+  launch_passB(h);
   h->timing.passB_launches--;  // the initial evaluation is not an iteration
   if (h->profiling && h->evB_used) h->evB_used--;
   launch_fin(h, 2);
@@ -364,7 +363,7 @@ void run_rcg(msw_core *h, size_t max_iters) {
       hipLaunchKernelGGL(k_step, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, nbA,
                          h->partA.p, h->w.p, h->u.p, h->os_u.p, h->step_u.p, h->lut.p, h->e.p,
                          h->tabB.p);
-      launch_passB(h, 0);
+      launch_passB(h);
       launch_fin(h, 0);
     }
     MSW_HIP(hipGetLastError());

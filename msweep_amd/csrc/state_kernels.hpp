@@ -109,7 +109,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
 // digamma evaluations spread over ~G/64 CUs instead of one.
 //   nblk > 0: sum partAcc[b*G + g] over b;  nblk == 0: Acc already holds the totals.
 constexpr int kRedfinParts = 5;
-__global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int cond_reset, int G, int nblk,
+__global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int nblk,
                                                 int npartS, const double *partAcc, const double *Acc,
                                                 const double *partS, const double *e, const double *u,
                                                 const double *alpha0, double *Nc, double *N, double *w,
@@ -117,7 +117,6 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int cond_res
   __shared__ double sh[32];
   __shared__ double accs[16][64];
   if (sc->done) return;
-  if (cond_reset && !sc->reset_pending) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = blockIdx.x * 64 + lane;
   // W = sum_j r_j : every workgroup forms it in the same fixed order

@@ -187,8 +187,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
 // between the row sum and the scatter.
 // ---------------------------------------------------------------------------------------
 template <bool WIDE, bool GLDS, bool TLDS>
-__global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int cond_reset,
-                                                       SellDev S, const double *e_g,
+__global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
                                                        const double *X_g, const double *T_g,
                                                        double *partAcc, double *partS,
                                                        double *accGlobal) {
@@ -196,7 +195,6 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, int c
   using R = Rec<WIDE>;
   using RT = typename R::T;
   if (sc->done) return;
-  if (cond_reset && !sc->reset_pending) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t G = S.n_groups, n_lut = S.n_lut;
   double *sh = reinterpret_cast<double *>(smem);
