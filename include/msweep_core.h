@@ -140,6 +140,27 @@ int msw_core_resample_counts(msw_handle h, const uint32_t *ec_counts, size_t n_e
                              int32_t seed, size_t bootstrap_count, size_t rep_begin,
                              size_t rep_end, uint32_t *counts_out);
 
+/* ---- EC-sharded single solve over several GPUs --------------------------------------
+ * The reference scales one solve only by OpenMP threads; rcgpar's MPI variant partitions the ECs
+ * (columns) over ranks and all-reduces N, |g|^2 and the bound every iteration.
+ * Here every rank holds a handle with a contiguous block of ECs (set_csr / build_likelihood /
+ * set_dense_logl on the LOCAL ECs; all ranks pass the same groups and alpha0).  After
+ * msw_core_set_comm, msw_core_solve / _prepare / _run take the local logc, exchange one scalar
+ * and one (G + 4)-vector per iteration and return the SAME theta / iteration count on every rank.
+ *   msw_comm_create_rccl : one process per GPU, RCCL over xGMI; `id` from msw_comm_unique_id on
+ *                          rank 0, distributed by the caller (e.g. torch.distributed broadcast).
+ *   msw_comm_create_local: the ranks are host threads of ONE process; out[] receives nranks
+ *                          communicators (host-staged exchange, summed in rank order). */
+typedef struct msw_comm *msw_comm_t;
+int msw_comm_unique_id(unsigned char id_out[128]);
+int msw_comm_create_rccl(const unsigned char id[128], int rank, int nranks, int device, msw_comm_t *out);
+int msw_comm_create_local(int nranks, msw_comm_t *out);
+void msw_comm_destroy(msw_comm_t c);
+/* comm == NULL detaches.  The communicator must outlive the solves that use it. */
+int msw_core_set_comm(msw_handle h, msw_comm_t comm);
+/* last error text of the msw_comm_* calls of this thread */
+const char *msw_comm_last_error(void);
+
 /* ---- measurement hooks (used by bench.py; no effect on results) ---------------------- */
 /* Device time (ms, HIP events on the solve stream) and launch counts of the dominant
  * kernels during the last solve: pass A (gradient norm sweep) and pass B (softmax /

@@ -23,7 +23,8 @@ EXPORTS = [
     "msw_core_gamma",
     "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
-    "msw_core_set_fixed_iters",
+    "msw_core_set_fixed_iters", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
+    "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error",
 ]
 
 
@@ -73,6 +74,13 @@ def load_library():
     L.msw_core_set_profiling.argtypes = [vp, C.c_int]
     L.msw_core_set_fixed_iters.argtypes = [vp, C.c_int]
     L.msw_core_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.msw_comm_unique_id.argtypes = [vp]
+    L.msw_comm_create_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.msw_comm_create_local.argtypes = [C.c_int, C.POINTER(vp)]
+    L.msw_comm_destroy.argtypes = [vp]
+    L.msw_comm_destroy.restype = None
+    L.msw_core_set_comm.argtypes = [vp, vp]
+    L.msw_comm_last_error.restype = C.c_char_p
     _lib = L
     return L
 
@@ -248,6 +256,12 @@ class Core:
                                                      _ptr(out)))
         return out
 
+    # ---- EC-sharded solve -------------------------------------------------------------------
+    def set_comm(self, comm):
+        """Attach a communicator (Comm) -- this handle then holds one rank's block of ECs."""
+        self._check(self._L.msw_core_set_comm(self._h, comm._c if comm is not None else None))
+        self._comm = comm      # keep it alive
+
     # ---- measurement ------------------------------------------------------------------------
     def set_profiling(self, on):
         self._check(self._L.msw_core_set_profiling(self._h, int(bool(on))))
@@ -259,3 +273,49 @@ class Core:
         t = Timing()
         self._check(self._L.msw_core_last_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+
+class Comm:
+    """Communicator of the EC-sharded solve (include/msweep_core.h, "EC-sharded single solve")."""
+
+    def __init__(self, c, owner=True):
+        self._L = load_library()
+        self._c = c
+        self._owner = owner
+
+    @staticmethod
+    def unique_id():
+        L = load_library()
+        buf = (C.c_ubyte * 128)()
+        if L.msw_comm_unique_id(buf) != 0:
+            raise MswError(L.msw_comm_last_error().decode())
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, uid, rank, nranks, device):
+        L = load_library()
+        out = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        if L.msw_comm_create_rccl(buf, int(rank), int(nranks), int(device), C.byref(out)) != 0:
+            raise MswError(L.msw_comm_last_error().decode())
+        return cls(out)
+
+    @classmethod
+    def local(cls, nranks):
+        """nranks communicators for nranks host threads of this process."""
+        L = load_library()
+        arr = (C.c_void_p * nranks)()
+        if L.msw_comm_create_local(int(nranks), arr) != 0:
+            raise MswError(L.msw_comm_last_error().decode())
+        return [cls(C.c_void_p(arr[i])) for i in range(nranks)]
+
+    def close(self):
+        if self._c and self._owner:
+            self._L.msw_comm_destroy(self._c)
+        self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

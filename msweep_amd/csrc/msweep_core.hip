@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "comm.hpp"
 #include "likelihood_kernels.hpp"
 #include "bootstrap_kernels.hpp"
 #include "em_kernels.hpp"
@@ -54,6 +55,9 @@ struct msw_core {
   DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc, tabB;
   DevBuf<double2> ew;
   DevBuf<double> partA, partS, partAcc, partC, partR;
+  // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
+  msw_comm *comm = nullptr;
+  DevBuf<double> commA, commB;  // 1 and G + 4 doubles
   DevBuf<Scalars> sc;
   Scalars *sc_host = nullptr;  // pinned
   DevBuf<double> tr_bound, tr_newnorm, tr_beta, tr_theta;
@@ -168,6 +172,8 @@ void alloc_solve_state(msw_core *h) {
   h->partA.alloc(std::max(nb, 1024));
   h->partS.alloc(4 * (size_t)std::max(nb, 1024));
   h->partR.alloc(kRedfinParts * ((size_t)G / 64 + 2));
+  h->commA.alloc(1);
+  h->commB.alloc((size_t)G + 4);
   h->partAcc.alloc((size_t)std::max(nb, 1) * G);
   h->partC.alloc(1024);
   h->sc.alloc(1);
@@ -288,16 +294,29 @@ void launch_passB(msw_core *h) {
   // column sums across workgroups + N_g / lgamma / digamma, spread over G/64 workgroups
   const bool partials = (h->flavor == 1) || h->glds;
   const int nb = h->npart_rows();
+  if (h->comm) {
+    // EC-sharded: local column sums + ELBO terms -> one all-reduce -> k_redfin on the totals
+    hipLaunchKernelGGL(k_colsum, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, (int)h->G,
+                       partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->commB.p);
+    h->comm->allreduce(h->commB.p, (size_t)h->G + 4, h->stream);
+    hipLaunchKernelGGL(k_redfin, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, (int)h->G, 0, 1,
+                       h->partAcc.p, h->commB.p, h->commB.p + h->G, h->e.p, h->u.p, h->alpha0.p, h->Nc.p,
+                       h->N.p, h->w.p, h->ew.p, h->partR.p);
+    return;
+  }
   hipLaunchKernelGGL(k_redfin, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, (int)h->G,
                      partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->e.p, h->u.p,
                      h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p);
 }
 
+// partS as seen by k_fin / k_em_fin: the all-reduced totals when sharded
+const double *fin_partS(msw_core *h) { return h->comm ? h->commB.p + h->G : h->partS.p; }
+int fin_npartS(msw_core *h) { return h->comm ? 1 : h->npart_rows(); }
+
 void launch_fin(msw_core *h, int mode) {
   TraceDev tr{h->tr_bound.p, h->tr_newnorm.p, h->tr_beta.p, h->tr_theta.p, h->tr_reset.p};
-  const int nb = h->npart_rows();
   hipLaunchKernelGGL(k_fin, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G, (int)h->n_lut,
-                     nb, (int)((h->G + 63) / 64), h->partS.p, h->partR.p, h->Nc.p, h->u.p, h->os_u.p,
+                     fin_npartS(h), (int)((h->G + 63) / 64), fin_partS(h), h->partR.p, h->Nc.p, h->u.p, h->os_u.p,
                      h->step_u.p, h->lut.p, h->e.p, h->tabB.p, tr);
 }
 
@@ -335,8 +354,17 @@ void begin_solve(msw_core *h, double tol, size_t max_iters) {
     throw Fail("max_iters out of range");
   const uint32_t G = h->G;
   if (h->trace_theta) h->tr_theta.alloc(h->trace_theta * G);
-  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1024), 0, h->stream, h->sc.p, (int)G, kCvecBlocks,
-                     h->partC.p, h->alpha0.p, h->u.p, h->os_u.p, h->step_u.p, tol, (int)max_iters,
+  const double *cpart = h->partC.p;
+  int ncpart = kCvecBlocks;
+  if (h->comm) {  // global sum of the EC counts (bound constant, theta normalisation)
+    hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(1024), 0, h->stream, h->sc.p, 0, kCvecBlocks, h->partC.p,
+                       h->commA.p);
+    h->comm->allreduce(h->commA.p, 1, h->stream);
+    cpart = h->commA.p;
+    ncpart = 1;
+  }
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1024), 0, h->stream, h->sc.p, (int)G, ncpart,
+                     cpart, h->alpha0.p, h->u.p, h->os_u.p, h->step_u.p, tol, (int)max_iters,
                      h->fixed_iters ? 1 : 0, (int)h->trace_theta, h->flavor, h->logzi, kInitBound);
   MSW_HIP(hipGetLastError());
 }
@@ -360,8 +388,17 @@ void run_rcg(msw_core *h, size_t max_iters) {
                                         : std::min<size_t>(kIterBatch, max_iters - iters_done);
     for (size_t b = 0; b < batch; ++b) {
       launch_passA(h);
-      hipLaunchKernelGGL(k_step, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, nbA,
-                         h->partA.p, h->w.p, h->u.p, h->os_u.p, h->step_u.p, h->lut.p, h->e.p,
+      const double *pA = h->partA.p;
+      int npA = nbA;
+      if (h->comm) {  // |g|^2 summed over the EC shards
+        hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(1024), 0, h->stream, h->sc.p, 1, nbA, h->partA.p,
+                           h->commA.p);
+        h->comm->allreduce(h->commA.p, 1, h->stream);
+        pA = h->commA.p;
+        npA = 1;
+      }
+      hipLaunchKernelGGL(k_step, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, npA,
+                         pA, h->w.p, h->u.p, h->os_u.p, h->step_u.p, h->lut.p, h->e.p,
                          h->tabB.p);
       launch_passB(h);
       launch_fin(h, 0);
@@ -587,6 +624,53 @@ int msw_core_resample_counts(msw_handle h, const uint32_t *ec_counts, size_t n_e
   return guarded(h, [&] {
     resample_impl(h, ec_counts, n_ecs, seed, bootstrap_count, rep_begin, rep_end, counts_out);
   });
+}
+
+const char *msw_comm_last_error(void) { return g_create_error.c_str(); }
+
+int msw_comm_unique_id(unsigned char id_out[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  const ncclResult_t rc = ncclGetUniqueId(&id);
+  if (rc != ncclSuccess) {
+    g_create_error = std::string("ncclGetUniqueId: ") + ncclGetErrorString(rc);
+    return 1;
+  }
+  std::memcpy(id_out, &id, 128);
+  return 0;
+}
+
+int msw_comm_create_rccl(const unsigned char id[128], int rank, int nranks, int device, msw_comm_t *out) {
+  if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) {
+    g_create_error = "msw_comm_create_rccl: bad arguments";
+    return 1;
+  }
+  try {
+    MSW_HIP(hipSetDevice(device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, 128);
+    *out = new RcclComm(uid, rank, nranks);
+    return 0;
+  } catch (const std::exception &ex) {
+    g_create_error = ex.what();
+    return 1;
+  }
+}
+
+int msw_comm_create_local(int nranks, msw_comm_t *out) {
+  if (!out || nranks < 1) {
+    g_create_error = "msw_comm_create_local: bad arguments";
+    return 1;
+  }
+  auto grp = std::make_shared<LocalGroup>(nranks);
+  for (int r = 0; r < nranks; ++r) out[r] = new LocalComm(grp, r);
+  return 0;
+}
+
+void msw_comm_destroy(msw_comm_t c) { delete c; }
+
+int msw_core_set_comm(msw_handle h, msw_comm_t comm) {
+  return guarded(h, [&] { h->comm = comm; });
 }
 
 int msw_core_set_profiling(msw_handle h, int enabled) {

@@ -272,6 +272,65 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
 }
 
 // ---------------------------------------------------------------------------------------
+// EC-sharded solve (comm.hpp): local sums packed for the two all-reduces of an iteration.
+// ---------------------------------------------------------------------------------------
+// out[0] = sum of part[0..n) (fixed order).  `gate` = 1: skipped like pass A / k_step.
+__global__ __launch_bounds__(1024) void k_sum_scalar(const Scalars *sc, int gate, int n, const double *part,
+                                                    double *out) {
+  __shared__ double sh[32];
+  if (gate && (sc->done || sc->reset_pending)) return;
+  double p = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p += part[i];
+  p = block_sum(p, sh);
+  if (threadIdx.x == 0) out[0] = p;
+}
+
+// out[g] = column sum of this rank's ECs (g < G); out[G .. G+3] = {sum c log Z, sum r H, sum r, 0}
+// in the layout of one partS entry, so that k_redfin / k_fin consume `out` as totals.
+__global__ __launch_bounds__(1024) void k_colsum(const Scalars *sc, int G, int nrows, int npartS,
+                                                const double *partAcc, const double *Acc,
+                                                const double *partS, double *out) {
+  __shared__ double sh[32];
+  __shared__ double accs[16][64];
+  if (sc->done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g = blockIdx.x * 64 + lane;
+  if (blockIdx.x == 0) {
+    double p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    for (int b = tid; b < npartS; b += 1024) {
+      p1 += partS[4 * b];
+      p2 += partS[4 * b + 1];
+      p3 += partS[4 * b + 2];
+    }
+    p1 = block_sum(p1, sh);
+    p2 = block_sum(p2, sh);
+    p3 = block_sum(p3, sh);
+    if (tid == 0) {
+      out[G] = p1;
+      out[G + 1] = p2;
+      out[G + 2] = p3;
+      out[G + 3] = 0.0;
+    }
+  }
+  double s = 0.0;
+  if (g < G) {
+    if (nrows > 0) {
+      for (int b = wv; b < nrows; b += 16) s += partAcc[(size_t)b * G + g];
+    } else if (wv == 0) {
+      s = Acc[g];
+    }
+  }
+  accs[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && g < G) {
+    double A = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) A += accs[i][lane];
+    out[g] = A;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Solve set-up: c_j = exp(logc_j) (or the bootstrap counts) gathered into the permuted EC
 // order, sum of counts, bound constant (rcgpar calc_bound_const), initial gamma = log(1/G).
 // perm == nullptr: identity (dense flavour).

@@ -51,3 +51,29 @@ def bootstrap_sharded(solve_slice, n_replicates, n_groups, dist=None, device=Non
     b, e = replicate_slice(n_replicates, rank, world)
     local = solve_slice(b, e) if e > b else np.zeros((0, n_groups))
     return all_gather_rows(np.asarray(local).reshape(e - b, n_groups), n_replicates, dist, device)
+
+
+def shard_ecs(rowptr, n_shards):
+    """Contiguous EC blocks balanced by cell count for the EC-sharded single solve: returns
+    n_shards + 1 EC boundaries ('contiguous EC blocks balanced by nnz')."""
+    rp = np.asarray(rowptr, dtype=np.int64)
+    E = len(rp) - 1
+    # weight = cells + 1 per EC so that empty ECs are spread too
+    w = rp[1:] - rp[:-1] + 1
+    cw = np.concatenate([[0], np.cumsum(w)])
+    targets = cw[-1] * np.arange(1, n_shards) / n_shards
+    cuts = np.searchsorted(cw, targets, side="left")
+    b = np.concatenate([[0], np.minimum(cuts, E), [E]]).astype(np.int64)
+    return np.maximum.accumulate(b)
+
+
+def csr_block(prob, e0, e1):
+    """The ECs [e0, e1) of a CSR-of-ECs problem dict as a problem of their own."""
+    rp = np.asarray(prob["rowptr"], dtype=np.int64)
+    k0, k1 = rp[e0], rp[e1]
+    out = dict(prob)
+    out["rowptr"] = (rp[e0:e1 + 1] - k0).astype(np.uint64)
+    out["grp"] = prob["grp"][k0:k1]
+    out["cnt"] = prob["cnt"][k0:k1]
+    out["ec_counts"] = prob["ec_counts"][e0:e1]
+    return out
