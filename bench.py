@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ecs", type=int, default=50000)
     ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--mode", choices=["replicates", "shard"], default="replicates",
+                    help="N > 1: 'replicates' = one bootstrap replicate per GPU (weak scaling, default); "
+                         "'shard' = ONE solve with the ECs sharded over the GPUs, RCCL all-reduce of the "
+                         "column sums every iteration (strong scaling)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed / RCCL even with one rank (exercises the N > 1 code path)")
     return ap.parse_args()
@@ -128,10 +132,25 @@ def main():
     log(f"generated cfg3: E={E} nnz={nnz} in {t_gen:.1f}s")
 
     core = Core(local_rank)
-    lik = from_grouped_counts(core, prob["rowptr"], prob["grp"], prob["cnt"], prob["ec_counts"],
-                              prob["group_sizes"])
+    shard = dist is not None and a.mode == "shard"
+    comm = None
+    if shard:
+        from msweep_amd.core import Comm
+        from msweep_amd.parallel import csr_block, shard_ecs
+        uid = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = Comm.rccl(uid[0], rank, world, local_rank)
+        b = shard_ecs(prob["rowptr"], world)
+        blk = csr_block(prob, b[rank], b[rank + 1])
+        lik = from_grouped_counts(core, blk["rowptr"], blk["grp"], blk["cnt"], blk["ec_counts"], prob["group_sizes"])
+        core.set_comm(comm)
+    else:
+        lik = from_grouped_counts(core, prob["rowptr"], prob["grp"], prob["cnt"], prob["ec_counts"],
+                                  prob["group_sizes"])
     alpha0 = np.ones(G)
-    if dist is not None:
+    if shard:
+        logc = lik.log_counts()
+    elif dist is not None:
         # replicate `rank` of the bootstrap, drawn on the device from the reference's ONE sequential
         # mt19937_64(--seed 42) stream (src/BootstrapSample.cpp:60-73): rank r owns draws
         # [r * n_reads, (r + 1) * n_reads), exactly what a single-GPU run would give replicate r
@@ -154,7 +173,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     res = core.run(max_iters=a.steps)         # exactly K steps
-    if dist is not None:
+    if dist is not None and not shard:
         import torch
         th = torch.from_numpy(res["theta"]).cuda()
         out = [torch.empty_like(th) for _ in range(world)]
@@ -179,7 +198,7 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        cells = float(E) * G * a.steps * n_gpus
+        cells = float(E) * G * a.steps * (1 if shard else n_gpus)
         msA = tm["passA_ms"] / max(tm["passA_launches"], 1)
         msB = tm["passB_ms"] / max(tm["passB_launches"], 1)
         dom, ms_dom, b_dom = ("k_passB", msB, tm["bytes_passB"]) if msB >= msA else ("k_passA", msA, tm["bytes_passA"])
@@ -198,14 +217,16 @@ def main():
             "metric": "EM iters/sec + reads×groups cells/sec, 10M reads × 5k groups",
             "value": cells / dt, "unit": "cells/s",
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg3: synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB "
                                    "(--algorithm rcggpu), fixed iteration count",
                        "reads": a.reads, "groups": G, "ecs": E, "nnz": nnz, "seed": a.seed,
-                       "sharding": "single solve" if n_gpus == 1 else f"bootstrap replicates, 1 per GPU x {n_gpus}"},
-            "iters_per_sec": a.steps * n_gpus / dt,
-            "reads_x_groups_cells_per_sec": float(a.reads) * G * a.steps * n_gpus / dt,
+                       "sharding": "single solve" if n_gpus == 1 else (
+                           f"one solve, ECs sharded over {n_gpus} GPUs, RCCL all-reduce of (G+4) fp64 per iteration"
+                           if shard else f"bootstrap replicates, 1 per GPU x {n_gpus}")},
+            "iters_per_sec": a.steps * (1 if shard else n_gpus) / dt,
+            "reads_x_groups_cells_per_sec": float(a.reads) * G * a.steps * (1 if shard else n_gpus) / dt,
             "device_ms_per_step": tm0["solve_ms"] / a.steps,
             "kernels": {"k_passA_ms": msA, "k_passB_ms": msB, "passA_launches": tm["passA_launches"],
                         "passB_launches": tm["passB_launches"]},
