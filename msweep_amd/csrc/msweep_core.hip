@@ -56,6 +56,7 @@ struct msw_core {
   DevBuf<double2> ew;
   DevBuf<double> partA, partS, partAcc, partC, partR;
   // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
+  size_t lds_attr[2][8] = {};  // dynamic-LDS limit already granted per sweep instantiation
   msw_comm *comm = nullptr;
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
   DevBuf<Scalars> sc;
@@ -193,8 +194,8 @@ template <bool W, bool GL, bool TL>
 void launch_passA_t(msw_core *h) {
   const size_t lds = pass_lds_bytes(GL, TL, h->G, h->n_lut, true);
   auto k = k_passA<W, GL, TL>;
-  static size_t lds_set = 0;  // per instantiation: raise the dynamic-LDS limit only when it grows
-  if (lds > lds_set) {
+  size_t &lds_set = h->lds_attr[0][(W ? 4 : 0) | (GL ? 2 : 0) | (TL ? 1 : 0)];
+  if (lds > lds_set) {  // raise the dynamic-LDS limit of this instantiation only when it grows
     MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
@@ -205,7 +206,7 @@ template <bool W, bool GL, bool TL>
 void launch_passB_t(msw_core *h) {
   const size_t lds = pass_lds_bytes(GL, TL, h->G, h->n_lut, false);
   auto k = k_passB<W, GL, TL>;
-  static size_t lds_set = 0;
+  size_t &lds_set = h->lds_attr[1][(W ? 4 : 0) | (GL ? 2 : 0) | (TL ? 1 : 0)];
   if (lds > lds_set) {
     MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
