@@ -3,8 +3,8 @@
 //
 // The reference draws ALL replicates from ONE sequential Mersenne-Twister stream, so replicate
 // b starts at draw b * bootstrap_count.  k_mt64 advances that stream on the device (one
-// wavefront; the 312-word recurrence has 156-wide parallelism per phase) and emits tempered
-// words; k_resample maps every word to an EC exactly as libstdc++ does
+// workgroup, 156 words per step) and emits tempered words on a second stream underneath the
+// previous replicate's solve; k_resample maps every word to an EC exactly as libstdc++ does
 // (generate_canonical<double,53> = double(x) * 2^-64 clamped below 1, then lower_bound on the
 // normalised partial sums) and counts with integer atomics (order independent).
 #pragma once
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64) void k_mt64_seed(MtState *st, uint64_t seed) {
       x = 6364136223846793005ULL * (x ^ (x >> 62)) + (uint64_t)i;
       st->mt[i] = x;
     }
-    st->idx = kMtN;
+    st->idx = 0;
     st->produced = 0;
   }
 }
@@ -47,66 +47,42 @@ __device__ __forceinline__ uint64_t mt_twist(uint64_t hi, uint64_t lo, uint64_t 
 }
 
 // Skips `skip` words, then writes `n` tempered words to out (out may be null when n == 0).
-// One wavefront; the state lives in LDS while the kernel runs.
-__global__ __launch_bounds__(64) void k_mt64(MtState *st, uint64_t skip, uint64_t n, uint64_t *out) {
-  __shared__ uint64_t mt[kMtN];
-  const int lane = threadIdx.x;
-  for (int i = lane; i < kMtN; i += 64) mt[i] = st->mt[i];
-  uint32_t idx = st->idx;
-  const uint64_t produced0 = st->produced;
+// Stream form of the recurrence: with x_0..x_311 the seeded state and x_k the k-th state word ever
+// produced, x_{k+312} = x_{k+156} ^ twist(x_k, x_{k+1}); every new word depends only on words at
+// least 156 positions back, so 156 words are produced per step with ONE barrier (the textbook
+// in-place refill needs three dependent phases per 312 words).  Output word j = temper(x_{312+j}).
+// st->mt holds the last 312 state words; the ring lives in LDS while the kernel runs.
+constexpr int kMtRing = 1024, kMtStep = 156;
+__global__ __launch_bounds__(256) void k_mt64(MtState *st, uint64_t skip, uint64_t n, uint64_t *out) {
+  __shared__ uint64_t ring[kMtRing];
+  const int t = threadIdx.x;
+  for (int i = t; i < kMtN; i += 256) ring[i] = st->mt[i];
+  uint32_t p = kMtN;  // ring position (mod kMtRing) of the next word
   __syncthreads();
   uint64_t todo_skip = skip, todo = n, written = 0;
   while (todo_skip + todo > 0) {
-    if (idx >= (uint32_t)kMtN) {
-      // refill: phase 1 (i < 156: old inputs), phase 2 (156 <= i < 311: new mt[i-156]), phase 3 (i = 311)
-      uint64_t nv[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int i = lane + 64 * c;
-        if (i < kMtM) nv[c] = mt_twist(mt[i], mt[i + 1], mt[i + kMtM]);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int i = lane + 64 * c;
-        if (i < kMtM) mt[i] = nv[c];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int i = kMtM + lane + 64 * c;
-        if (i < kMtN - 1) nv[c] = mt_twist(mt[i], mt[i + 1], mt[i - kMtM]);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int i = kMtM + lane + 64 * c;
-        if (i < kMtN - 1) mt[i] = nv[c];
-      }
-      __syncthreads();
-      if (lane == 0) mt[kMtN - 1] = mt_twist(mt[kMtN - 1], mt[0], mt[kMtM - 1]);
-      __syncthreads();
-      idx = 0;
+    const bool skipping = todo_skip > 0;
+    const uint64_t rem = skipping ? todo_skip : todo;
+    const uint32_t cnt = rem < (uint64_t)kMtStep ? (uint32_t)rem : (uint32_t)kMtStep;
+    if ((uint32_t)t < cnt) {
+      const uint64_t a = ring[(p - 312 + t) & (kMtRing - 1)];
+      const uint64_t b = ring[(p - 311 + t) & (kMtRing - 1)];
+      const uint64_t c = ring[(p - 156 + t) & (kMtRing - 1)];
+      const uint64_t v = mt_twist(a, b, c);
+      ring[(p + t) & (kMtRing - 1)] = v;  // never a slot read in this step (window 312 < ring - step)
+      if (!skipping) out[written + t] = mt_temper(v);
     }
-    const uint64_t avail = (uint64_t)(kMtN - idx);
-    if (todo_skip > 0) {
-      const uint64_t s = todo_skip < avail ? todo_skip : avail;
-      idx += (uint32_t)s;
-      todo_skip -= s;
-      continue;
+    __syncthreads();
+    p += cnt;
+    if (skipping) {
+      todo_skip -= cnt;
+    } else {
+      todo -= cnt;
+      written += cnt;
     }
-    const uint64_t take = todo < avail ? todo : avail;
-    for (uint64_t i = lane; i < take; i += 64) out[written + i] = mt_temper(mt[idx + i]);
-    idx += (uint32_t)take;
-    written += take;
-    todo -= take;
   }
-  __syncthreads();
-  for (int i = lane; i < kMtN; i += 64) st->mt[i] = mt[i];
-  if (lane == 0) {
-    st->idx = idx;
-    st->produced = produced0 + skip + n;
-  }
+  for (int i = t; i < kMtN; i += 256) st->mt[i] = ring[(p - 312 + i) & (kMtRing - 1)];
+  if (t == 0) st->produced += skip + n;
 }
 
 // counts[lower_bound(cp, p)] += 1 for every word (std::discrete_distribution::operator()).

@@ -73,8 +73,11 @@ struct msw_core {
   // ---- bootstrap -------------------------------------------------------------------------
   DevBuf<double> cp;
   DevBuf<uint64_t> mtwords;
-  DevBuf<uint32_t> bcounts;
+  DevBuf<uint32_t> bcounts, bcounts2;
   DevBuf<MtState> mt;
+  hipStream_t stream2 = nullptr;  // resampling of the next replicate, under the current solve
+  hipEvent_t ev_counts[2] = {nullptr, nullptr};
+  uint32_t one_count = 0;
   bool mt_valid = false;
   int32_t mt_seed = 0;
   uint64_t mt_pos = 0;
@@ -92,6 +95,9 @@ struct msw_core {
     if (ev1) (void)hipEventDestroy(ev1);
     for (auto &p : evA) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : evB) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &e : ev_counts)
+      if (e) (void)hipEventDestroy(e);
+    if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
