@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsweep_core.so")
+# MSWEEP_CORE_LIB: developer override for A/B timing of two builds in one job
+LIB_PATH = os.environ.get("MSWEEP_CORE_LIB") or os.path.join(_HERE, "libmsweep_core.so")
 
 ALGO_RCG, ALGO_EM = 0, 1
 PREC_DOUBLE, PREC_FLOAT = 0, 1
