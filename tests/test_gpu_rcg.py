@@ -286,3 +286,31 @@ def test_dense_path_many_groups(gpu_core, oracle, E, G, seed):
     np.testing.assert_allclose(np.exp(gpu_core.gamma()), np.exp(s["gamma"]), atol=1e-6)
     with pytest.raises(MswError, match="n_groups <= 8192"):
         gpu_core.set_dense_logl(np.zeros((8193, 2)))
+
+
+def test_mid_length_ecs_streaming_path(gpu_core, oracle):
+    """ECs with 17..256 cells: slices too long for the register buffers take the streaming branch of
+    both sweeps (and odd lengths exercise the padding to an even slice length)."""
+    rng = np.random.default_rng(17)
+    G = 700
+    sizes = (1 + rng.poisson(4, G)).astype(np.uint64)
+    lut = precalc_lls(sizes)
+    lens = np.concatenate([rng.integers(17, 257, 300), rng.integers(0, 17, 500), [255, 256, 17, 33]])
+    rng.shuffle(lens)
+    cols = [np.sort(rng.choice(G, int(n), replace=False)) for n in lens]
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    grp = np.concatenate(cols).astype(np.uint32)
+    cnt = rng.integers(1, sizes[grp] + 1).astype(np.uint32)
+    E = len(lens)
+    logc = np.log(rng.integers(1, 30, E).astype(float))
+    alpha0 = rng.uniform(0.5, 2.0, G)
+    gpu_core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
+    gpu_core.set_trace_theta(15)
+    res = gpu_core.solve(logc, alpha0)
+    tr = gpu_core.trace(15, with_theta=True)
+    lutidx = (grp * lut.shape[1] + cnt).astype(np.uint32)
+    ref = oracle.rcg_optl_csr(rowptr, grp, lutidx, lut, np.log(0.01), G, logc, alpha0, trace=15, want_gamma=True)
+    lockstep(tr, ref["trace"], 15)
+    assert res["iters"] == ref["iters"]
+    assert_theta(res["theta"], ref["theta"])
+    np.testing.assert_allclose(np.exp(gpu_core.gamma()), np.exp(ref["gamma"]), atol=1e-7)
