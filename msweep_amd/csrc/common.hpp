@@ -59,6 +59,13 @@ struct DevBuf {
   }
 };
 
+// Per-pass slot tables (n_lut 16-byte entries each), rebuilt by prepB_block whenever `a` moves:
+//   A[i] = {x_i, D_i}            x_i = exp(a*T_i), D_i = (1-a)*(T_i - logzi)      (pass A)
+//   B[i] = {x_i - p0, x_i*T_i - p0*logzi}              p0 = exp(a*logzi)           (pass B)
+struct TabDev {
+  double2 *A, *B;
+};
+
 // Scalar state of one solve; lives in device memory, mirrored to pinned host memory when
 // the host polls.  Kept POD.
 struct Scalars {

@@ -10,7 +10,7 @@
 namespace msw {
 
 __global__ __launch_bounds__(1024) void k_em_init(Scalars *sc, int G, int n_lut, double *u,
-                                                 const double *lut, double *e, double *X) {
+                                                 const double *lut, double *e, TabDev X) {
   __shared__ double sh[32];
   const int tid = threadIdx.x, nt = blockDim.x;
   const double l = log(1.0 / (double)G);
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(1024) void k_em_init(Scalars *sc, int G, int n_lut,
 __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, int npartS,
                                                 const double *partS, const double *Nc,
                                                 const double *alpha0, double *u, double *theta,
-                                                const double *lut, double *e, double *X, TraceDev tr) {
+                                                const double *lut, double *e, TabDev X, TraceDev tr) {
   __shared__ double sh[32];
   if (sc->done) return;
   const int tid = threadIdx.x, nt = blockDim.x;

@@ -13,7 +13,6 @@ namespace msw {
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_lse_sell(SellDev S, double a, double logzi, const double *u,
                                                  const double *lut, double *lse /*original order*/) {
-  using R = Rec<WIDE>;
   __shared__ double sh[32];
   const int tid = threadIdx.x;
   double m = -INFINITY;
@@ -25,9 +24,7 @@ __global__ __launch_bounds__(256) void k_lse_sell(SellDev S, double a, double lo
   const double p0 = exp(a * logzi);
   for (uint32_t p = blockIdx.x * blockDim.x + tid; p < S.n_ecs; p += gridDim.x * blockDim.x) {
     double zs = 0.0;
-    for_each_cell<WIDE>(S, p, [&](typename R::T r) {
-      zs += exp(u[R::grp(r)] - M) * (exp(a * lut[R::idx(r)]) - p0);
-    });
+    for_each_cell<WIDE>(S, p, [&](uint32_t g, uint32_t i) { zs += exp(u[g] - M) * (exp(a * lut[i]) - p0); });
     lse[S.perm[p]] = M + log(p0 * U + zs);
   }
 }
@@ -46,15 +43,13 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void k_gamma_scatter(SellDev S, double *out, size_t ld, int g_begin,
                                                       int g_end, double a, const double *u,
                                                       const double *lut, const double *lse) {
-  using R = Rec<WIDE>;
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= S.n_ecs) return;
   const uint32_t j = S.perm[p];
   const double l = lse ? lse[j] : 0.0;
-  for_each_cell<WIDE>(S, p, [&](typename R::T r) {
-    const int g = (int)R::grp(r);
-    if (g >= g_begin && g < g_end)
-      out[(size_t)(g - g_begin) * ld + j] = a * lut[R::idx(r)] + u[g] - l;
+  for_each_cell<WIDE>(S, p, [&](uint32_t gu, uint32_t i) {
+    const int g = (int)gu;
+    if (g >= g_begin && g < g_end) out[(size_t)(g - g_begin) * ld + j] = a * lut[i] + u[g] - l;
   });
 }
 

@@ -42,6 +42,10 @@ struct msw_core {
   uint32_t G = 0, E = 0, n_lut = 0, nslices = 0, n_long = 0;
   uint64_t nnz = 0, nslots = 0;
   bool wide = false, glds = true, tlds = true;
+  int gmodeB = 1;  // k_passB GMODE (sweep_kernels.hpp)
+  uint32_t enc_shift = 0, enc_mask = 0, enc_bhi = 0;  // record encoding (sell.hpp)
+  uint32_t n_area = 0;                                  // 16-byte entries of the slot area
+  DevBuf<uint32_t> area_slot;
   double logzi = 0.0;
   DevBuf<uint32_t> rec, slice_off, long_ptr, rec_long, perm;
   DevBuf<double> lut, Lt;
@@ -52,11 +56,12 @@ struct msw_core {
   int npart_rows() const { return flavor == 0 ? nblk : (nreg >= 32 ? 4 * nblk_dense : nblk_dense); }
 
   // ---- solve state ---------------------------------------------------------------------
-  DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc, tabB;
-  DevBuf<double2> ew;
+  DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc;
+  DevBuf<double2> ew, tabA, tabB;  // group table of pass A; per-slot tables of both sweeps (TabDev)
+  TabDev tabs() const { return TabDev{tabA.p, tabB.p}; }
   DevBuf<double> partA, partS, partAcc, partC, partR;
   // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
-  size_t lds_attr[2][8] = {};  // dynamic-LDS limit already granted per sweep instantiation
+  size_t lds_attr[2][12] = {};  // dynamic-LDS limit already granted per sweep instantiation
   msw_comm *comm = nullptr;
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
   DevBuf<Scalars> sc;
@@ -146,34 +151,68 @@ SellDev sell_view(msw_core *h) {
   S.n_ecs = h->E;
   S.n_groups = h->G;
   S.n_lut = h->n_lut;
+  S.n_area = h->n_area;
+  S.area_slot = h->area_slot.p;
+  S.shift = h->enc_shift;
+  S.mask = h->enc_mask;
+  S.bhi = h->enc_bhi;
   return S;
 }
 
 void choose_lds_mode(msw_core *h) {
   const bool opts[4][2] = {{true, true}, {true, false}, {false, true}, {false, false}};
   for (auto &o : opts) {
-    const size_t a = pass_lds_bytes(o[0], o[1], h->G, h->n_lut, true);
-    const size_t b = pass_lds_bytes(o[0], o[1], h->G, h->n_lut, false);
+    const int gm = o[0] ? 1 : 0;
+    const size_t a = pass_lds_bytes(gm, o[1], h->G, h->n_area, true);
+    const size_t b = pass_lds_bytes(gm, o[1], h->G, h->n_area, false);
     if (std::max(a, b) <= kLdsMax) {
       h->glds = o[0];
       h->tlds = o[1];
+      // column sums at the fixed immediate distance when e_g fits below it and the image still fits
+      h->gmodeB = gm;
+      if (o[0] && 8ull * (h->G + kSentinels) <= kAccFixed &&
+          pass_lds_bytes(2, o[1], h->G, h->n_area, false) <= kLdsMax)
+        h->gmodeB = 2;
       return;
     }
   }
   throw Fail("internal: no LDS configuration fits");
 }
 
+// LDS mode, then the record encoding that goes with it (sell.hpp): the narrowest split of a
+// 32-bit record that holds both byte offsets, else 8-byte records.  Runs before the SELL packing.
+void choose_layout(msw_core *h) {
+  choose_lds_mode(h);
+  h->enc_bhi = sell_bhi(h->tlds, h->n_area);
+  const uint64_t lo_end = 16ull * std::max<uint32_t>(h->n_area, 1);              // lo < lo_end
+  const uint64_t hi_end = (uint64_t)h->enc_bhi + 8ull * ((uint64_t)h->G + kSentinels);  // hi < hi_end
+  h->wide = true;
+  h->enc_shift = 0;
+  h->enc_mask = 0xffffffffu;
+  for (uint32_t s = 5; s <= 31; ++s) {
+    if (lo_end <= (1ull << (s - 1)) && hi_end <= (1ull << (32 - s))) {
+      h->wide = false;
+      h->enc_shift = s;
+      h->enc_mask = (1u << (s - 1)) - 1u;
+      break;
+    }
+  }
+  if (h->wide && (hi_end > (1ull << 31) || lo_end > (1ull << 32)))
+    throw Fail("likelihood too large: group / lookup-table offsets exceed the 8-byte record fields");
+}
+
 void alloc_solve_state(msw_core *h) {
   const uint32_t G = h->G, E = h->E;
   for (DevBuf<double> *b : {&h->alpha0, &h->u, &h->os_u, &h->step_u, &h->w, &h->e, &h->N, &h->Nc,
                             &h->Acc, &h->logth})
-    b->alloc((size_t)G + 1);
-  h->ew.alloc((size_t)G + 1);
-  // slot G of e / ew is the sentinel group of SELL padding records: zero, never rewritten
+    b->alloc((size_t)G + kSentinels);
+  h->ew.alloc((size_t)G + kSentinels);
+  // entries G.. of e / ew are the sentinel groups of SELL padding records: zero, never rewritten
   h->e.zero(h->stream);
   h->ew.zero(h->stream);
   h->cvec.alloc(E);
   h->logc_d.alloc(E);
+  h->tabA.alloc((size_t)std::max<uint32_t>(h->n_lut, 1));
   h->tabB.alloc((size_t)std::max<uint32_t>(h->n_lut, 1));
   const int nb = std::max(h->nblk, std::max(h->nblk_dense, h->npart_rows()));
   h->partA.alloc(std::max(nb, 1024));
@@ -196,28 +235,33 @@ void alloc_solve_state(msw_core *h) {
 }
 
 // ---- launch helpers for the templated sweeps ----------------------------------------------
-template <bool W, bool GL, bool TL>
-void launch_passA_t(msw_core *h) {
-  const size_t lds = pass_lds_bytes(GL, TL, h->G, h->n_lut, true);
-  auto k = k_passA<W, GL, TL>;
-  size_t &lds_set = h->lds_attr[0][(W ? 4 : 0) | (GL ? 2 : 0) | (TL ? 1 : 0)];
+// The sweeps address their LDS image by absolute ds addresses taken from the records: the image
+// must start at LDS address 0, i.e. the kernels must not own static __shared__ memory.
+template <class K>
+void prepare_sweep(K k, size_t lds, size_t &lds_set) {
   if (lds > lds_set) {  // raise the dynamic-LDS limit of this instantiation only when it grows
+    hipFuncAttributes fa;
+    MSW_HIP(hipFuncGetAttributes(&fa, (const void *)k));
+    if (fa.sharedSizeBytes != 0) throw Fail("internal: sweep kernel owns static LDS");
     MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
-  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h),
-                     h->ew.p, h->tabB.p, h->lut.p, h->partA.p);
 }
 template <bool W, bool GL, bool TL>
+void launch_passA_t(msw_core *h) {
+  const size_t lds = pass_lds_bytes(GL ? 1 : 0, TL, h->G, h->n_area, true);
+  auto k = k_passA<W, GL, TL>;
+  prepare_sweep(k, lds, h->lds_attr[0][(W ? 4 : 0) | (GL ? 2 : 0) | (TL ? 1 : 0)]);
+  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h),
+                     h->ew.p, h->tabA.p, h->partA.p);
+}
+template <bool W, int GM, bool TL>
 void launch_passB_t(msw_core *h) {
-  const size_t lds = pass_lds_bytes(GL, TL, h->G, h->n_lut, false);
-  auto k = k_passB<W, GL, TL>;
-  size_t &lds_set = h->lds_attr[1][(W ? 4 : 0) | (GL ? 2 : 0) | (TL ? 1 : 0)];
-  if (lds > lds_set) {
-    MSW_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set = lds;
-  }
-  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h), h->e.p, h->tabB.p, h->lut.p, h->partAcc.p, h->partS.p, h->Acc.p);
+  const size_t lds = pass_lds_bytes(GM, TL, h->G, h->n_area, false);
+  auto k = k_passB<W, GM, TL>;
+  prepare_sweep(k, lds, h->lds_attr[1][(W ? 6 : 0) + 2 * GM + (TL ? 1 : 0)]);
+  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
+                     h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p);
 }
 
 #define MSW_DISPATCH3(fn, ...)                                                       \
@@ -232,6 +276,24 @@ void launch_passB_t(msw_core *h) {
       case 5: fn<true, false, true>(__VA_ARGS__); break;                             \
       case 6: fn<true, true, false>(__VA_ARGS__); break;                             \
       default: fn<true, true, true>(__VA_ARGS__); break;                             \
+    }                                                                                \
+  } while (0)
+#define MSW_DISPATCH_B(fn, ...)                                                      \
+  do {                                                                               \
+    const int key = (h->wide ? 6 : 0) + 2 * h->gmodeB + (h->tlds ? 1 : 0);           \
+    switch (key) {                                                                   \
+      case 0: fn<false, 0, false>(__VA_ARGS__); break;                               \
+      case 1: fn<false, 0, true>(__VA_ARGS__); break;                                \
+      case 2: fn<false, 1, false>(__VA_ARGS__); break;                               \
+      case 3: fn<false, 1, true>(__VA_ARGS__); break;                                \
+      case 4: fn<false, 2, false>(__VA_ARGS__); break;                               \
+      case 5: fn<false, 2, true>(__VA_ARGS__); break;                                \
+      case 6: fn<true, 0, false>(__VA_ARGS__); break;                                \
+      case 7: fn<true, 0, true>(__VA_ARGS__); break;                                 \
+      case 8: fn<true, 1, false>(__VA_ARGS__); break;                                \
+      case 9: fn<true, 1, true>(__VA_ARGS__); break;                                 \
+      case 10: fn<true, 2, false>(__VA_ARGS__); break;                               \
+      default: fn<true, 2, true>(__VA_ARGS__); break;                                \
     }                                                                                \
   } while (0)
 
@@ -290,8 +352,8 @@ void launch_passB(msw_core *h) {
     MSW_HIP(hipEventRecord(ev->first, h->stream));
   }
   if (h->flavor == 0) {
-    if (!h->glds) MSW_HIP(hipMemsetAsync(h->Acc.p, 0, ((size_t)h->G + 1) * sizeof(double), h->stream));
-    MSW_DISPATCH3(launch_passB_t, h);
+    if (!h->glds) MSW_HIP(hipMemsetAsync(h->Acc.p, 0, ((size_t)h->G + kSentinels) * sizeof(double), h->stream));
+    MSW_DISPATCH_B(launch_passB_t, h);
   } else {
     MSW_DISPATCH_NREG(launch_dense_B, launch_dense_big_B, h);
   }
@@ -324,7 +386,7 @@ void launch_fin(msw_core *h, int mode) {
   TraceDev tr{h->tr_bound.p, h->tr_newnorm.p, h->tr_beta.p, h->tr_theta.p, h->tr_reset.p};
   hipLaunchKernelGGL(k_fin, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G, (int)h->n_lut,
                      fin_npartS(h), (int)((h->G + 63) / 64), fin_partS(h), h->partR.p, h->Nc.p, h->u.p, h->os_u.p,
-                     h->step_u.p, h->lut.p, h->e.p, h->tabB.p, tr);
+                     h->step_u.p, h->lut.p, h->e.p, h->tabs(), tr);
 }
 
 void poll(msw_core *h) {
@@ -380,7 +442,7 @@ void run_rcg(msw_core *h, size_t max_iters) {
   const int G = (int)h->G, n_lut = (int)h->n_lut;
   // initial update_N_k on gamma = log(1/G)
   hipLaunchKernelGGL(k_prepB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->u.p, h->lut.p,
-                     h->e.p, h->tabB.p);
+                     h->e.p, h->tabs());
   launch_passB(h);
   h->timing.passB_launches--;  // the initial evaluation is not an iteration
   if (h->profiling && h->evB_used) h->evB_used--;
@@ -406,7 +468,7 @@ void run_rcg(msw_core *h, size_t max_iters) {
       }
       hipLaunchKernelGGL(k_step, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, npA,
                          pA, h->w.p, h->u.p, h->os_u.p, h->step_u.p, h->lut.p, h->e.p,
-                         h->tabB.p);
+                         h->tabs());
       launch_passB(h);
       launch_fin(h, 0);
     }

@@ -10,10 +10,21 @@ namespace msw {
 //   swept by a whole workgroup), then all others sorted by descending cell count and cut into
 //   slices of 64 consecutive ECs.  A slice stores its records column-major
 //   (rec[(off + k) * 64 + lane] = k-th cell of the slice's lane-th EC), padded to the slice's
-//   longest EC with a sentinel record (group id == n_groups, whose e_g is 0).  A wavefront
+//   longest EC with sentinel records (group id n_groups + lane, whose e_g is 0).  A wavefront
 //   sweeps one slice: lane l streams EC l's cells with perfectly coalesced loads.
-//   A record is (lutidx << 16 | grp) when both fit 16 bits, else {grp, lutidx}.
+//
+//   A record carries the two table positions of its cell as ready-made BYTE OFFSETS, so the
+//   sweeps spend one shift / one mask per lookup instead of unpack + scale + base:
+//     hi = bhi + 8 * group   (byte offset of e_g in pass B's LDS image; pass A doubles it:
+//                             2 * hi = 2 * bhi + 16 * group addresses its 16-byte {e, w} entries)
+//     lo = 16 * entry        (byte offset of the cell's 16-byte entry in the SLOT AREA: the LUT
+//                             slots some cell refers to, compacted, followed by 8 bank-private
+//                             replicas of the hottest ones -- see upload_sell)
+//   narrow record (4 B): hi << shift | lo, with lo < 2^(shift-1) so that rec >> (shift-1) == 2*hi;
+//   wide record (8 B): {hi, lo}.
 // ---------------------------------------------------------------------------------------
+constexpr uint32_t kSentinels = 64;  // one sentinel group per lane: padding never shares an address
+
 struct SellDev {
   const uint32_t *rec;        // SELL records
   const uint32_t *slice_off;  // [nslices + 1], in units of 64 records
@@ -21,7 +32,9 @@ struct SellDev {
   const uint32_t *rec_long;   // records of the long ECs (CSR)
   const uint32_t *perm;       // [E] permuted position -> original EC index
   const double *cvec;         // [E] EC multiplicities, permuted order
-  uint32_t nslices, n_long, n_ecs, n_groups, n_lut;
+  const uint32_t *area_slot;  // [n_area] LUT slot held by each 16-byte entry of the slot area
+  uint32_t nslices, n_long, n_ecs, n_groups, n_lut, n_area;
+  uint32_t shift, mask, bhi;  // record encoding (narrow: shift / lo mask; both: bhi)
 };
 
 constexpr int kLongRow = 256;  // ECs with more cells than this take the workgroup path
@@ -32,8 +45,9 @@ template <>
 struct Rec<false> {
   using T = uint32_t;
   static __device__ __forceinline__ T load(const uint32_t *p, size_t i) { return p[i]; }
-  static __device__ __forceinline__ uint32_t grp(T r) { return r & 0xffffu; }
-  static __device__ __forceinline__ uint32_t idx(T r) { return r >> 16; }
+  static __device__ __forceinline__ uint32_t hi(T r, uint32_t shift) { return r >> shift; }
+  static __device__ __forceinline__ uint32_t hi2(T r, uint32_t shift) { return r >> (shift - 1); }
+  static __device__ __forceinline__ uint32_t lo(T r, uint32_t mask) { return r & mask; }
 };
 template <>
 struct Rec<true> {
@@ -41,37 +55,65 @@ struct Rec<true> {
   static __device__ __forceinline__ T load(const uint32_t *p, size_t i) {
     return reinterpret_cast<const uint2 *>(p)[i];
   }
-  static __device__ __forceinline__ uint32_t grp(T r) { return r.x; }
-  static __device__ __forceinline__ uint32_t idx(T r) { return r.y; }
+  static __device__ __forceinline__ uint32_t hi(T r, uint32_t) { return r.x; }
+  static __device__ __forceinline__ uint32_t hi2(T r, uint32_t) { return r.x << 1; }
+  static __device__ __forceinline__ uint32_t lo(T r, uint32_t) { return r.y; }
 };
+// group id / LUT slot of a record (utility kernels; the sweeps never form them)
+template <bool WIDE>
+__device__ __forceinline__ uint32_t rec_grp(const SellDev &S, typename Rec<WIDE>::T r) {
+  return (Rec<WIDE>::hi(r, S.shift) - S.bhi) >> 3;
+}
+template <bool WIDE>
+__device__ __forceinline__ uint32_t rec_idx(const SellDev &S, typename Rec<WIDE>::T r) {
+  return S.area_slot[Rec<WIDE>::lo(r, S.mask) >> 4];
+}
 
 // Visit the cells of the EC at permuted position p (utility kernels only).
 template <bool WIDE, class F>
 __device__ __forceinline__ void for_each_cell(const SellDev &S, uint32_t p, F f) {
   using R = Rec<WIDE>;
   if (p < S.n_long) {
-    for (uint32_t k = S.long_ptr[p]; k < S.long_ptr[p + 1]; ++k) f(R::load(S.rec_long, k));
+    for (uint32_t k = S.long_ptr[p]; k < S.long_ptr[p + 1]; ++k) {
+      const typename R::T r = R::load(S.rec_long, k);
+      f(rec_grp<WIDE>(S, r), rec_idx<WIDE>(S, r));
+    }
   } else {
     const uint32_t q = p - S.n_long, s = q >> 6, lane = q & 63;
     const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;
     for (uint32_t k = 0; k < len; ++k) {
       const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + lane);
-      if (R::grp(r) != S.n_groups) f(r);
+      const uint32_t g = rec_grp<WIDE>(S, r);
+      if (g < S.n_groups) f(g, rec_idx<WIDE>(S, r));
     }
   }
 }
 
-// LDS bytes of the sweeps.  Pass A keeps {e_g, wc_g} pairs, pass B keeps e_g and the column-sum
-// accumulators; both keep the per-pass table X[i] = exp(a*T_i) and the static table T[i] as two
-// separate 8-byte arrays (consecutive slots in consecutive bank pairs: the 32-byte AoS entries
-// of the first version mapped the hot slots onto 8 bank octets and cost 5x in LDS conflicts).
-__host__ __device__ inline size_t pass_lds_bytes(bool glds, bool tlds, uint32_t G, uint32_t n_lut,
+// LDS image of the sweeps (byte offsets; bhi = sell_bhi()):
+//   [0, 16 * n_area)                    slot area: 16-byte per-slot entries of the pass (tlds)
+//   pass A: [2 * bhi, 2 * bhi + 16 * Gp)  {e_g, wc_g}                         (glds)
+//   pass B: [bhi, bhi + 8 * Gp) e_g,  column sums pass_acc_off() bytes behind      (glds)
+//   then 32 doubles of reduction scratch and 8 KB of slice geometry.   Gp = G + kSentinels
+__host__ __device__ inline uint32_t sell_bhi(bool tlds, uint32_t n_area) {
+  return tlds ? ((16u * n_area + 255u) & ~255u) : 0u;
+}
+constexpr uint32_t kGeoStride = 66 * 8;  // bytes of slice geometry per wavefront
+constexpr uint32_t kAccFixed = 65528;  // largest 8-byte-aligned ds immediate offset
+// byte distance from e_g to the column sum of the same group in pass B's LDS image
+__host__ __device__ inline uint32_t pass_acc_off(int gmode, uint32_t G) {
+  return gmode == 2 ? kAccFixed : 8u * (G + kSentinels);
+}
+__host__ __device__ inline size_t pass_scratch_off(int gmode, bool tlds, uint32_t G, uint32_t n_area,
+                                                   bool passA) {
+  const size_t bhi = sell_bhi(tlds, n_area), Gp = (size_t)G + kSentinels;
+  if (gmode == 0) return bhi;
+  if (passA) return 2 * bhi + 16 * Gp;
+  return bhi + pass_acc_off(gmode, G) + 8 * Gp;
+}
+__host__ __device__ inline size_t pass_lds_bytes(int gmode, bool tlds, uint32_t G, uint32_t n_area,
                                                  bool passA) {
-  (void)passA;
-  size_t b = 32 * sizeof(double);  // reduction scratch
-  if (glds) b += 2 * ((size_t)G + 1) * sizeof(double);
-  if (tlds) b += 2 * (size_t)n_lut * sizeof(double);
-  return b;
+  // + per-wave slice geometry (sweep_kernels.hpp SliceStream): 16 waves x (64 + 2) pairs
+  return pass_scratch_off(gmode, tlds, G, n_area, passA) + 32 * sizeof(double) + 16 * kGeoStride;
 }
 
 }  // namespace msw

@@ -17,10 +17,11 @@ struct TraceDev {
   int32_t *didreset;
 };
 
-// From (a, u): M = max u, e_g = exp(u_g - M), U = sum e, p0 = exp(a*logzi) and the table
-// X[i] = exp(a*T_i).  One 1024-thread workgroup.  Index G of e is the sentinel slot (zero).
+// From (a, u): M = max u, e_g = exp(u_g - M), U = sum e, p0 = exp(a*logzi) and the per-slot
+// tables of both sweeps (common.hpp TabDev).  One 1024-thread workgroup.  Entries G.. of e are
+// the sentinel groups of SELL padding (zero, never rewritten).
 __device__ inline void prepB_block(Scalars *sc, double a, int G, int n_lut, const double *u,
-                                   const double *lut, double *e, double *X, double *sh) {
+                                   const double *lut, double *e, TabDev X, double *sh) {
   const int tid = threadIdx.x, nt = blockDim.x;
   double m = -INFINITY;
   for (int g = tid; g < G; g += nt) m = fmax(m, u[g]);
@@ -32,8 +33,13 @@ __device__ inline void prepB_block(Scalars *sc, double a, int G, int n_lut, cons
     su += eg;
   }
   const double U = block_sum(su, sh);
-  const double p0 = exp(a * sc->logzi);
-  for (int i = tid; i < n_lut; i += nt) X[i] = exp(a * lut[i]);
+  const double logzi = sc->logzi, oma = 1.0 - a;
+  const double p0 = exp(a * logzi);
+  for (int i = tid; i < n_lut; i += nt) {
+    const double T = lut[i], x = exp(a * T);
+    X.A[i] = make_double2(x, oma * (T - logzi));
+    X.B[i] = make_double2(x - p0, x * T - p0 * logzi);
+  }
   if (tid == 0) {
     sc->M = M;
     sc->U = U;
@@ -42,7 +48,7 @@ __device__ inline void prepB_block(Scalars *sc, double a, int G, int n_lut, cons
 }
 
 __global__ __launch_bounds__(1024) void k_prepB(Scalars *sc, int G, int n_lut, const double *u,
-                                               const double *lut, double *e, double *X) {
+                                               const double *lut, double *e, TabDev X) {
   __shared__ double sh[32];
   if (sc->done) return;
   if (sc->flavor != 0) return;  // dense flavour needs no tables
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(1024) void k_prepB(Scalars *sc, int G, int n_lut, c
 __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, int n_partA,
                                               const double *partA, const double *w, double *u,
                                               double *os_u, double *step_u, const double *lut,
-                                              double *e, double *X) {
+                                              double *e, TabDev X) {
   __shared__ double sh[32];
   if (sc->done || sc->reset_pending) return;  // a pending re-evaluation skips pass A and the step
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -104,7 +110,8 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
 // Column sums across workgroups (fixed order) fused with the per-group math that follows them:
 // Nc_g, N_g, lgamma(N_g), (M - u_g) * Nc_g, w_g = digamma(N_g) - 1 - u_g and the pass-A gradient
 // preparation {e_g, w_g - kappa} with its sums S0 = sum e, S1 = sum e*s0, S2 = sum e*s0^2
-// (s0_g = (1-a)*logzi + w_g - kappa; kappa = lagged centring constant, see k_fin).  One
+// (s0_g = w_g - kappa: the step value of a background cell relative to which pass A measures the
+// listed cells; kappa = lagged centring constant, see k_fin).  One
 // 1024-thread workgroup per 64 groups: 16 wavefronts split the partial rows, so the lgamma /
 // digamma evaluations spread over ~G/64 CUs instead of one.
 //   nblk > 0: sum partAcc[b*G + g] over b;  nblk == 0: Acc already holds the totals.
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
     w[g] = wg;
     if (flavor == 0) {
       const double eg = e[g], wc = wg - sc->kappa;
-      const double s0 = (1.0 - sc->a) * sc->logzi + wc;
+      const double s0 = wc;
       ew[g] = make_double2(eg, wc);
       s0v = eg;
       s1v = eg * s0;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
                                              int npartR, const double *partS, const double *partR,
                                              const double *Nc, double *u, double *os_u,
                                              const double *step_u, const double *lut, double *e,
-                                             double *X, TraceDev tr) {
+                                             TabDev X, TraceDev tr) {
   __shared__ double sh[32];
   if (sc->done) return;
   const int tid = threadIdx.x, nt = blockDim.x;

@@ -6,6 +6,12 @@
 // being processed the records of the wave's next slice are already in flight (the record stream
 // is the only HBM traffic; everything else is gathered from LDS).  Slice bounds are wave-uniform
 // and kept in SGPRs (readfirstlane) so the cell loops are scalar branches, not exec-mask loops.
+//
+// The sweeps are bound by VALU issue + LDS gathers, not by HBM, so the per-cell
+// instruction count is what is optimised here: records carry ready-made LDS byte offsets
+// (sell.hpp: one shift + one mask per cell), every per-slot quantity that does not depend on the
+// group is tabulated once per pass by prepB_block (state_kernels.hpp), and padding records point
+// at per-lane sentinel groups so that no per-cell test is needed.
 #pragma once
 #include <type_traits>
 
@@ -15,11 +21,41 @@
 namespace msw {
 
 constexpr int kRegCells = 16;  // cells per EC a wave keeps in registers (longer slices stream)
+// record buffers per wave (SliceStream): measured on MI355X, two are as fast as three -- the
+// stream already runs at the achievable HBM rate -- and leave registers for pass B's x - p0
+#ifndef MSW_DEPTH_A
+#define MSW_DEPTH_A 2
+#endif
+#ifndef MSW_DEPTH_B
+#define MSW_DEPTH_B 2
+#endif
+#ifndef MSW_B_KEEPX
+#define MSW_B_KEEPX (MSW_DEPTH_B == 2)
+#endif
+#ifndef MSW_PASSA_BATCH
+#define MSW_PASSA_BATCH 4
+#endif
+#ifndef MSW_PASSB_BATCH
+#define MSW_PASSB_BATCH 4
+#endif
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// Issue the loads of one slice (<= kRegCells cells per EC, even count) into registers.
+// One slice held in registers (<= kRegCells cells per EC): records, geometry and -- pass B -- the
+// EC's multiplicity.
 template <bool WIDE>
+struct SliceBuf {
+  typename Rec<WIDE>::T r[kRegCells];
+  uint32_t sl, o, len;
+  double c;
+};
+
+// Issue the loads of one slice into registers: ALWAYS kRegCells loads.  Rows past the slice's
+// length re-read (part of) its first row (an L1 hit, value unused), so that the number of vector loads per
+// slice is a compile-time constant: the compiler's waitcnt analysis is path-insensitive, and only
+// with a fixed count can it (and the manual counted wait below) tell that an older slice has
+// landed while newer ones are still in flight.
+template <bool WIDE, bool FIXED>
 __device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uint32_t len,
                                            typename Rec<WIDE>::T (&r)[kRegCells]) {
 #pragma unroll
@@ -27,97 +63,223 @@ __device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uin
     if ((uint32_t)k < len) {
       r[k] = Rec<WIDE>::load(rec, base + (size_t)k * 64);
       r[k + 1] = Rec<WIDE>::load(rec, base + (size_t)(k + 1) * 64);
+    } else if (FIXED) {
+      // distinct addresses inside the first row (+ the allocation's spare row): identical loads
+      // would be merged into one load + register copies, which have to wait for the data
+      r[k] = Rec<WIDE>::load(rec, base + 1 + k);
+      r[k + 1] = Rec<WIDE>::load(rec, base + 2 + k);
     }
   }
 }
 
+// s_waitcnt vmcnt(N) with the gfx9 field layout (vmcnt = imm[3:0] | imm[15:14] << 4).  Vector
+// loads return in order: "at most N outstanding" = everything but the N most recent has landed.
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+// The record stream of one wavefront: its slices s_first, s_first + nw, ... go through THREE
+// register buffers, so the records of two slices are in flight while a third is processed (the
+// sweeps run at one workgroup per CU: bytes in flight per CU, not arithmetic, bound a
+// double-buffered version).  The slice geometry (slice_off pairs) of 64 slices at a time is
+// fetched with one gather per lane and parked in LDS: no dependent global load sits between two
+// slices.  EXTRA = vector loads per slice that `issue` adds besides the records.
+template <bool WIDE, int EXTRA, int DEPTH>
+struct SliceStream {
+  const SellDev &S;
+  uint32_t s_first, nw, n_mine, lane;
+  uint32_t geo;  // LDS byte offset of this wave's 64 (+2 dummy) {slice_off[s], slice_off[s+1]} pairs
+  uint2 pend = make_uint2(0, 0);
+  __device__ __forceinline__ SliceStream(const SellDev &S_, uint32_t first, uint32_t nw_, uint32_t lane_,
+                                         uint32_t geo_)
+      : S(S_), s_first(first), nw(nw_), lane(lane_), geo(geo_) {
+    n_mine = first < S.nslices ? (S.nslices - first + nw_ - 1) / nw_ : 0;
+    gather_offs(0);
+  }
+  // geometry of the wave's slices [64 * chunk, 64 * chunk + 64): one gather per lane, parked in LDS
+  // (a register copy would make every later use wait for ALL outstanding vector loads)
+  __device__ __forceinline__ void gather_offs(uint32_t chunk) {
+    const uint32_t i = chunk * 64 + lane;
+    pend = make_uint2(0, 0);  // past the wave's last slice: the dummy geometry
+    if (i < n_mine) {
+      const uint32_t sl = s_first + i * nw;
+      pend = make_uint2(S.slice_off[sl], S.slice_off[sl + 1]);
+    }
+  }
+  __device__ __forceinline__ void commit_offs() {
+    typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2u_t lds_u2_t;
+    v2u_t v = {pend.x, pend.y}, z = {0u, 0u};
+    *(lds_u2_t *)(size_t)(geo + lane * 8) = v;
+    if (lane < 2) *(lds_u2_t *)(size_t)(geo + (64 + lane) * 8) = z;  // dummies
+  }
+  static constexpr int kLoads = kRegCells + EXTRA;  // vector loads per fetched slice
+  // j = position inside the current 64-slice chunk; j >= n_chunk fetches the dummy geometry
+  template <class Issue>
+  __device__ __forceinline__ void fetch(uint32_t base, uint32_t j, SliceBuf<WIDE> &b, Issue &issue) {
+    typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const v2u_t lds_cu2_t;
+    const v2u_t oe = *(lds_cu2_t *)(size_t)(geo + j * 8);
+    b.sl = s_first + (base + j) * nw;
+    b.o = uniform(oe.x);
+    b.len = uniform(oe.y) - b.o;
+    load_slice<WIDE, DEPTH == 3>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r);
+    issue(b);
+  }
+  // Every step does exactly one fetch (past the last slice a dummy one: geometry {0, 0}, sixteen
+  // L1 hits) so that the stream has ONE static shape -- fetch, fetch, [wait, fetch, process]* --
+  // in which the counted wait provably covers the buffer about to be processed; anything
+  // conditional between two fetches (even a rarely taken reload of the geometry) makes the
+  // compiler fall back to vmcnt(0).  The geometry is therefore renewed between 64-slice chunks,
+  // with the stream drained.
+  template <class Issue, class Process>
+  __device__ __forceinline__ void run(Issue issue, Process process) {
+    for (uint32_t base = 0; base == 0 || base < n_mine; base += 64) {
+      if (base) gather_offs(base >> 6);
+      commit_offs();
+      const uint32_t n_chunk = n_mine > base ? (n_mine - base < 64u ? n_mine - base : 64u) : 0u;
+      SliceBuf<WIDE> A = {}, B = {}, C = {};
+      uint32_t j = 0;
+      if constexpr (DEPTH == 2) {  // two buffers, variable load count, full drains
+        fetch(base, 0, A, issue);
+        for (;;) {
+          if (j >= n_chunk) break;
+          wait_vm<0>();
+          fetch(base, j + 1, B, issue);
+          process(A);
+          if (++j >= n_chunk) break;
+          wait_vm<0>();
+          fetch(base, j + 1, A, issue);
+          process(B);
+          ++j;
+        }
+        wait_vm<0>();
+        continue;
+      }
+      fetch(base, 0, A, issue);
+      fetch(base, 1, B, issue);
+      for (;;) {
+        if (j >= n_chunk) break;
+        wait_vm<kLoads>();  // A has landed; B may still be in flight
+        fetch(base, j + 2, C, issue);
+        process(A);
+        if (++j >= n_chunk) break;
+        wait_vm<kLoads>();
+        fetch(base, j + 2, A, issue);
+        process(B);
+        if (++j >= n_chunk) break;
+        wait_vm<kLoads>();
+        fetch(base, j + 2, B, issue);
+        process(C);
+        ++j;
+      }
+      wait_vm<0>();
+    }
+  }
+};
+
+// 16-byte / 8-byte table entries at a byte offset, from the LDS image or from global memory.
+// The LDS image starts at LDS address 0 (the sweeps have no static __shared__; checked on the
+// host before the first launch), so a record field IS the ds address: building the pointer from
+// the integer keeps the compiler from adding the dynamic-LDS base symbol to every gather.
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const v2d_t lds_cd2_t;
+typedef __attribute__((address_space(3))) const double lds_cd_t;
+typedef __attribute__((address_space(3))) double lds_d_t;
+template <bool INLDS>
+__device__ __forceinline__ double2 tab16(const unsigned char *glob, uint32_t off) {
+  if constexpr (INLDS) {
+    const v2d_t v = *(lds_cd2_t *)(size_t)off;
+    return make_double2(v.x, v.y);
+  }
+  else return *reinterpret_cast<const double2 *>(glob + off);
+}
+template <bool INLDS>
+__device__ __forceinline__ double tab8(const unsigned char *glob, uint32_t off) {
+  if constexpr (INLDS) return *(lds_cd_t *)(size_t)off;
+  else return *reinterpret_cast<const double *>(glob + off);
+}
+
 // ---------------------------------------------------------------------------------------
-// Pass A: newnorm = sum_j Var_{q_j}(step_.j), q_j = softmax_g(a*L + u),
-// step_gj = (1-a)*L_gj + w_g  (+ an irrelevant per-EC constant).
+// Pass A: newnorm = sum_j Var_{q_j}(step_.j), q_j = softmax_g(a*L + u).  The variance is
+// invariant to a per-EC shift of the step values, so they are taken relative to the background
+// cell of the same EC:  s_gj = D_i + wc_g on a listed cell (D_i = (1-a)*(T_i - logzi), slot
+// table {x_i, D_i}), s_gj = wc_g elsewhere (group table {e_g, wc_g}).  10 fp64 operations per cell.
 // ---------------------------------------------------------------------------------------
 struct AccA {
   double zs, t1, t2;
 };
-struct CstA {
-  double p0, oma, oma2, p0l, p0l2;  // p0, (1-a), (1-a)^2, p0*logzi, p0*logzi^2
-};
-__device__ __forceinline__ void cellA(AccA &c, const CstA &k, const double e, const double w,
-                                      const double x, const double T) {
-  const double xm = x - k.p0;
-  const double xT = x * T;
-  const double A1 = k.oma * (xT - k.p0l);
-  const double A2 = k.oma2 * (xT * T - k.p0l2);
+__device__ __forceinline__ void cellA(AccA &c, const double p0, const double e, const double w,
+                                      const double x, const double D) {
+  const double xm = x - p0;
+  const double xD = x * D;
   const double wx = w * xm;
-  c.zs += e * xm;
-  c.t1 += e * (A1 + wx);
-  c.t2 += e * (A2 + w * (2.0 * A1 + wx));
+  c.zs = fma(e, xm, c.zs);
+  c.t1 = fma(e, xD + wx, c.t1);
+  c.t2 = fma(e, fma(xD, D, w * fma(2.0, xD, wx)), c.t2);
 }
 
 template <bool WIDE, bool GLDS, bool TLDS>
 __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellDev S,
-                                                       const double2 *ew_g, const double *X_g,
-                                                       const double *T_g, double *partA) {
+                                                       const double2 *ew_g, const double2 *tabA_g,
+                                                       double *partA) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
   using RT = typename R::T;
   if (sc->done || sc->reset_pending) return;  // a pending re-evaluation skips pass A
   const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t G = S.n_groups, n_lut = S.n_lut;
-  double *sh = reinterpret_cast<double *>(smem);
-  double *p = sh + 32;
-  // {e_g, w_g} and {X_i, T_i} as 16-byte entries: one ds_read_b128 per lookup.  A wave can have
-  // at most 16 LDS operations in flight (lgkmcnt is 4 bits), so wide reads double the cells whose
-  // gathers overlap with arithmetic.
-  double2 *ew_l = reinterpret_cast<double2 *>(p);
-  if (GLDS) {
-    p += 2 * ((size_t)G + 1);
-    for (uint32_t g = tid; g <= G; g += kPassThreads) ew_l[g] = ew_g[g];
-  }
-  double2 *xt_l = reinterpret_cast<double2 *>(p);
+  const uint32_t G = S.n_groups, n_lut = S.n_area, Gp = G + kSentinels;  // n_lut: entries of the slot area
+  const uint32_t shift = S.shift, mask = S.mask, bhi2 = 2 * S.bhi;
+  double *sh = reinterpret_cast<double *>(smem + pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true));
+  // slice geometry of this wave: the gather is in flight while the LDS image is filled
+  SliceStream<WIDE, 0, MSW_DEPTH_A> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
+                              gridDim.x * (kPassThreads / 64), (uint32_t)lane,
+                              (uint32_t)pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true) + 256u +
+                                  uniform(tid >> 6) * kGeoStride);
   if (TLDS) {
-    for (uint32_t i = tid; i < n_lut; i += kPassThreads) xt_l[i] = make_double2(X_g[i], T_g[i]);
+    double2 *t = reinterpret_cast<double2 *>(smem);
+    for (uint32_t i = tid; i < n_lut; i += kPassThreads) t[i] = tabA_g[S.area_slot[i]];
   }
-  auto EW_ = [&](uint32_t g) -> double2 { return GLDS ? ew_l[g] : ew_g[g]; };
-  auto XT_ = [&](uint32_t i) -> double2 { return TLDS ? xt_l[i] : make_double2(X_g[i], T_g[i]); };
-  const double p0 = sc->p0, U = sc->U, logzi = sc->logzi, oma = 1.0 - sc->a;
-  const CstA cst = {p0, oma, oma * oma, p0 * logzi, p0 * logzi * logzi};
+  if (GLDS) {
+    double2 *t = reinterpret_cast<double2 *>(smem + bhi2);
+    for (uint32_t g = tid; g < Gp; g += kPassThreads) t[g] = ew_g[g];
+  }
+  // global fallbacks see the same byte offsets as the LDS image
+  const unsigned char *ew_b = reinterpret_cast<const unsigned char *>(ew_g) - bhi2;
+  const unsigned char *xt_b = reinterpret_cast<const unsigned char *>(tabA_g);
+  auto EW_ = [&](RT r) -> double2 { return tab16<GLDS>(ew_b, R::hi2(r, shift)); };
+  auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
+  const double p0 = sc->p0, U = sc->U;
   const double zbase = p0 * U, b1 = p0 * sc->V1c, b2 = p0 * sc->V2c;
   double nn = 0.0;
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
-  const uint32_t nw = gridDim.x * (kPassThreads / 64);
-  // Two register buffers in ping-pong: while one slice is processed the records of the wave's
-  // next slice are in flight.  The explicit vmcnt(0) sits BEFORE the next buffer's loads are
-  // issued, so it only waits for the buffer about to be consumed.
-  RT buf0[kRegCells] = {}, buf1[kRegCells] = {};
-  uint32_t o0 = 0, len0 = 0, o1 = 0, len1 = 0;
-  auto issue = [&](uint32_t sl, RT(&b)[kRegCells], uint32_t &o, uint32_t &len) {
-    o = uniform(S.slice_off[sl]);
-    len = uniform(S.slice_off[sl + 1]) - o;
-    if (len <= (uint32_t)kRegCells) load_slice<WIDE>(S.rec, (size_t)o * 64 + lane, len, b);
-  };
-  auto process = [&](uint32_t sl, RT(&b)[kRegCells], uint32_t o, uint32_t len) {
+  auto issue = [&](SliceBuf<WIDE> &) {};
+  auto process = [&](SliceBuf<WIDE> &sb) {
+    RT(&b)[kRegCells] = sb.r;
+    const uint32_t len = sb.len;
     AccA c = {0.0, 0.0, 0.0};
     if (len <= (uint32_t)kRegCells) {
       // straight-line code per slice length (len is wave-uniform and even): all LDS gathers of
-      // the slice can be in flight together instead of one scalar-branched pair at a time
+      // a batch can be in flight together instead of one scalar-branched pair at a time
       auto fixed = [&](auto LEN) {
         constexpr int L = decltype(LEN)::value;
-        constexpr int B = 8;  // cells gathered together: 16 x ds_read_b128 in flight
+        constexpr int B = MSW_PASSA_BATCH;  // cells gathered together (2 x ds_read_b128 each)
 #pragma unroll
         for (int k0 = 0; k0 < L; k0 += B) {
           double2 ewv[B], xtv[B];
 #pragma unroll
           for (int k = 0; k < B; ++k) {
             if (k0 + k < L) {
-              ewv[k] = EW_(R::grp(b[k0 + k]));
-              xtv[k] = XT_(R::idx(b[k0 + k]));
+              ewv[k] = EW_(b[k0 + k]);
+              xtv[k] = XT_(b[k0 + k]);
             }
           }
 #pragma unroll
           for (int k = 0; k < B; ++k)
-            if (k0 + k < L) cellA(c, cst, ewv[k].x, ewv[k].y, xtv[k].x, xtv[k].y);
+            if (k0 + k < L) cellA(c, p0, ewv[k].x, ewv[k].y, xtv[k].x, xtv[k].y);
         }
       };
       switch (len) {
@@ -132,42 +294,30 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
         default: fixed(std::integral_constant<int, 16>{}); break;
       }
     } else {
-      const size_t base = (size_t)o * 64 + lane;
+      const size_t base = (size_t)sb.o * 64 + lane;
       for (uint32_t k = 0; k < len; k += 2) {
         const RT r0 = R::load(S.rec, base + (size_t)k * 64);
         const RT r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
-        const double2 a0 = EW_(R::grp(r0)), a1 = EW_(R::grp(r1));
-        const double2 x0 = XT_(R::idx(r0)), x1 = XT_(R::idx(r1));
-        cellA(c, cst, a0.x, a0.y, x0.x, x0.y);
-        cellA(c, cst, a1.x, a1.y, x1.x, x1.y);
+        const double2 a0 = EW_(r0), a1 = EW_(r1);
+        const double2 x0 = XT_(r0), x1 = XT_(r1);
+        cellA(c, p0, a0.x, a0.y, x0.x, x0.y);
+        cellA(c, p0, a1.x, a1.y, x1.x, x1.y);
       }
     }
-    if (sl * 64 + lane < n_sell) {
+    if (sb.sl * 64 + lane < n_sell) {
       const double iZ = 1.0 / (zbase + c.zs);
       const double S1 = (b1 + c.t1) * iZ, S2 = (b2 + c.t2) * iZ;
       nn += S2 - S1 * S1;
     }
   };
-  uint32_t s0 = uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)), s1;
-  if (s0 < S.nslices) issue(s0, buf0, o0, len0);
-  while (s0 < S.nslices) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): buf0 has landed
-    s1 = s0 + nw;
-    if (s1 < S.nslices) issue(s1, buf1, o1, len1);
-    process(s0, buf0, o0, len0);
-    if (s1 >= S.nslices) break;
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // buf1 has landed
-    s0 = s1 + nw;
-    if (s0 < S.nslices) issue(s0, buf0, o0, len0);
-    process(s1, buf1, o1, len1);
-  }
+  stream.run(issue, process);
   // long ECs: the whole workgroup strides over one EC's cells
   for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
     AccA c = {0.0, 0.0, 0.0};
     for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
       const RT rc = R::load(S.rec_long, k);
-      const double2 a0 = EW_(R::grp(rc)), x0 = XT_(R::idx(rc));
-      cellA(c, cst, a0.x, a0.y, x0.x, x0.y);
+      const double2 a0 = EW_(rc), x0 = XT_(rc);
+      cellA(c, p0, a0.x, a0.y, x0.x, x0.y);
     }
     const double zs = block_sum(c.zs, sh), t1 = block_sum(c.t1, sh), t2 = block_sum(c.t2, sh);
     if (tid == 0) {
@@ -183,65 +333,83 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
 // ---------------------------------------------------------------------------------------
 // Pass B: per EC Z_j (softmax denominator), r_j = c_j / Z_j, the ELBO data terms and the column
 // sums A_g = sum_j r_j (x_gj - p0) accumulated in an LDS-private table (rcgpar logsumexp +
-// update_N_k + ELBO_rcg_mat in one sweep).  The (group, x - p0) pairs of an EC stay in registers
-// between the row sum and the scatter.
+// update_N_k + ELBO_rcg_mat in one sweep).  Slot table {x_i - p0, x_i*T_i - p0*logzi}: two FMAs
+// per cell in the row sums; the x - p0 of an EC stay in registers between the row sum and the
+// scatter.
 // ---------------------------------------------------------------------------------------
-template <bool WIDE, bool GLDS, bool TLDS>
+// GMODE: 0 = e_g / column sums in global memory; 1 = in LDS, column sums right behind e_g;
+// 2 = in LDS, column sums at the fixed distance kAccFixed (an instruction immediate: one VALU
+// operation less per scattered cell; needs 8 * Gp <= kAccFixed).
+template <bool WIDE, int GMODE, bool TLDS>
 __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
-                                                       const double *X_g, const double *T_g,
-                                                       double *partAcc, double *partS,
-                                                       double *accGlobal) {
+                                                       const double2 *tabB_g, double *partAcc,
+                                                       double *partS, double *accGlobal) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
   using RT = typename R::T;
   if (sc->done) return;
   const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t G = S.n_groups, n_lut = S.n_lut;
-  double *sh = reinterpret_cast<double *>(smem);
-  double *p = sh + 32;
-  const double *e_l = e_g;
-  double *acc = accGlobal;
-  if (GLDS) {
-    double *el = p;
-    acc = p + (G + 1);
-    p += 2 * ((size_t)G + 1);
-    for (uint32_t g = tid; g <= G; g += kPassThreads) {
-      el[g] = e_g[g];
-      acc[g] = 0.0;
-    }
-    e_l = el;
-  }
-  double2 *xt_l = reinterpret_cast<double2 *>(p);  // {X_i, T_i}: one ds_read_b128 per lookup
+  const uint32_t G = S.n_groups, n_lut = S.n_area, Gp = G + kSentinels;  // n_lut: entries of the slot area
+  const uint32_t shift = S.shift, mask = S.mask, bhi = S.bhi;
+  constexpr bool GLDS = GMODE > 0;
+  const uint32_t acc_off = pass_acc_off(GMODE, G);
+  double *sh = reinterpret_cast<double *>(smem + pass_scratch_off(GMODE, TLDS, G, n_lut, false));
+  SliceStream<WIDE, 1, MSW_DEPTH_B> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
+                              gridDim.x * (kPassThreads / 64), (uint32_t)lane,
+                              (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 256u +
+                                  uniform(tid >> 6) * kGeoStride);
   if (TLDS) {
-    for (uint32_t i = tid; i < n_lut; i += kPassThreads) xt_l[i] = make_double2(X_g[i], T_g[i]);
+    double2 *t = reinterpret_cast<double2 *>(smem);
+    for (uint32_t i = tid; i < n_lut; i += kPassThreads) t[i] = tabB_g[S.area_slot[i]];
   }
-  auto XT_ = [&](uint32_t i) -> double2 { return TLDS ? xt_l[i] : make_double2(X_g[i], T_g[i]); };
-  const double p0 = sc->p0, U = sc->U, logzi = sc->logzi;
-  const double p0l = p0 * logzi;
-  const double zbase = p0 * U, hbase = p0l * U;
+  if (GLDS) {
+    double *el = reinterpret_cast<double *>(smem + bhi), *al = reinterpret_cast<double *>(smem + bhi + acc_off);
+    for (uint32_t g = tid; g < Gp; g += kPassThreads) {
+      el[g] = e_g[g];
+      al[g] = 0.0;
+    }
+  }
+  const unsigned char *e_b = reinterpret_cast<const unsigned char *>(e_g) - bhi;
+  unsigned char *acc_b = reinterpret_cast<unsigned char *>(accGlobal) - bhi;
+  const unsigned char *xt_b = reinterpret_cast<const unsigned char *>(tabB_g);
+  auto E_ = [&](RT r) -> double { return tab8<(GMODE > 0)>(e_b, R::hi(r, shift)); };
+  auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
+  auto XM_ = [&](RT r) -> double { return tab8<TLDS>(xt_b, R::lo(r, mask)); };
+  auto addACC = [&](RT r, double v) {
+    const uint32_t off = R::hi(r, shift);
+    if constexpr (GMODE == 2)
+      __hip_atomic_fetch_add((lds_d_t *)(size_t)(off + kAccFixed), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if constexpr (GMODE == 1)
+      __hip_atomic_fetch_add((lds_d_t *)(size_t)(off + acc_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+      atomicAdd(reinterpret_cast<double *>(acc_b + off), v);
+  };
+  const double p0 = sc->p0, U = sc->U;
+  const double zbase = p0 * U, hbase = p0 * sc->logzi * U;
   double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
-  const uint32_t nw = gridDim.x * (kPassThreads / 64);
-  RT buf0[kRegCells] = {}, buf1[kRegCells] = {};
-  uint32_t o0 = 0, len0 = 0, o1 = 0, len1 = 0;
-  double c0 = 0.0, c1 = 0.0;
-  auto issue = [&](uint32_t sl, RT(&b)[kRegCells], uint32_t &o, uint32_t &len, double &c) {
-    o = uniform(S.slice_off[sl]);
-    len = uniform(S.slice_off[sl + 1]) - o;
-    if (len <= (uint32_t)kRegCells) load_slice<WIDE>(S.rec, (size_t)o * 64 + lane, len, b);
-    c = (sl * 64 + lane < n_sell) ? S.cvec[S.n_long + sl * 64 + lane] : 0.0;
+  auto issue = [&](SliceBuf<WIDE> &sb) {
+    // always one load (clamped index): the stream counts on a fixed number of loads per slice
+    const uint32_t q = sb.sl * 64 + lane;
+    const double cj = S.cvec[S.n_long + (q < n_sell ? q : 0u)];
+    sb.c = q < n_sell ? cj : 0.0;
   };
-  auto process = [&](RT(&b)[kRegCells], uint32_t o, uint32_t len, double c) {
+  auto process = [&](SliceBuf<WIDE> &sb) {
+    RT(&b)[kRegCells] = sb.r;
+    const uint32_t o = sb.o, len = sb.len;
+    const double c = sb.c;
     double zs = 0.0, hs = 0.0;
     if (len <= (uint32_t)kRegCells) {
-      // row sums: straight-line code per slice length (wave-uniform, even); x - p0 of every cell
-      // stays in registers for the scatter
-      double xv[kRegCells];
+      // row sums: straight-line code per slice length (wave-uniform, even).  x - p0 of every
+      // cell stays in registers for the scatter (with three record buffers there is no room: the
+      // scatter then gathers it a second time).
+      constexpr bool KEEPX = MSW_B_KEEPX;
+      double xv[KEEPX ? kRegCells : 1];
       auto fixed = [&](auto LEN) {
         constexpr int L = decltype(LEN)::value;
-        constexpr int B = 4;
+        constexpr int B = MSW_PASSB_BATCH;  // cells whose gathers are issued together
 #pragma unroll
         for (int k0 = 0; k0 < L; k0 += B) {
           double ev[B];
@@ -249,17 +417,16 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
 #pragma unroll
           for (int k = 0; k < B; ++k) {
             if (k0 + k < L) {
-              ev[k] = e_l[R::grp(b[k0 + k])];
-              xt[k] = XT_(R::idx(b[k0 + k]));
+              ev[k] = E_(b[k0 + k]);
+              xt[k] = XT_(b[k0 + k]);
             }
           }
 #pragma unroll
           for (int k = 0; k < B; ++k) {
             if (k0 + k < L) {
-              const double m = xt[k].x - p0;
-              zs += ev[k] * m;
-              hs += ev[k] * (xt[k].x * xt[k].y - p0l);
-              xv[k0 + k] = m;
+              zs = fma(ev[k], xt[k].x, zs);
+              hs = fma(ev[k], xt[k].y, hs);
+              if constexpr (KEEPX) xv[k0 + k] = xt[k].x;
             }
           }
         }
@@ -281,14 +448,13 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
         s_clogZ += c * log(Z);
         s_rH += rj * H;
         s_W += rj;
+        // padding records point at the lane's own sentinel group: no test, no shared address
 #pragma unroll
         for (int k = 0; k < kRegCells; k += 2) {
           if ((uint32_t)k < len) {
-            // padding records (group id == G) all target one address: skip them instead of
-            // serialising up to 64 same-address LDS atomics per step
-            const uint32_t g0 = R::grp(b[k]), g1 = R::grp(b[k + 1]);
-            if (g0 != G) atomicAdd(&acc[g0], rj * xv[k]);
-            if (g1 != G) atomicAdd(&acc[g1], rj * xv[k + 1]);
+            const double x0 = KEEPX ? xv[k] : XM_(b[k]), x1 = KEEPX ? xv[k + 1] : XM_(b[k + 1]);
+            addACC(b[k], rj * x0);
+            addACC(b[k + 1], rj * x1);
           }
         }
       }
@@ -297,12 +463,12 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
       for (uint32_t k = 0; k < len; k += 2) {
         const RT r0 = R::load(S.rec, base + (size_t)k * 64);
         const RT r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
-        const double e0 = e_l[R::grp(r0)], e1 = e_l[R::grp(r1)];
-        const double2 t0 = XT_(R::idx(r0)), t1 = XT_(R::idx(r1));
-        zs += e0 * (t0.x - p0);
-        hs += e0 * (t0.x * t0.y - p0l);
-        zs += e1 * (t1.x - p0);
-        hs += e1 * (t1.x * t1.y - p0l);
+        const double e0 = E_(r0), e1 = E_(r1);
+        const double2 t0 = XT_(r0), t1 = XT_(r1);
+        zs = fma(e0, t0.x, zs);
+        hs = fma(e0, t0.y, hs);
+        zs = fma(e1, t1.x, zs);
+        hs = fma(e1, t1.y, hs);
       }
       if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
@@ -312,32 +478,20 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
         s_W += rj;
         for (uint32_t k = 0; k < len; ++k) {
           const RT r = R::load(S.rec, base + (size_t)k * 64);
-          atomicAdd(&acc[R::grp(r)], rj * (XT_(R::idx(r)).x - p0));
+          addACC(r, rj * XT_(r).x);
         }
       }
     }
   };
-  uint32_t s0 = uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)), s1;
-  if (s0 < S.nslices) issue(s0, buf0, o0, len0, c0);
-  while (s0 < S.nslices) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): buf0 / c0 have landed
-    s1 = s0 + nw;
-    if (s1 < S.nslices) issue(s1, buf1, o1, len1, c1);
-    process(buf0, o0, len0, c0);
-    if (s1 >= S.nslices) break;
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    s0 = s1 + nw;
-    if (s0 < S.nslices) issue(s0, buf0, o0, len0, c0);
-    process(buf1, o1, len1, c1);
-  }
+  stream.run(issue, process);
   for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
     double zs = 0.0, hs = 0.0;
     for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
       const RT rc = R::load(S.rec_long, k);
-      const double eg = e_l[R::grp(rc)];
-      const double2 t = XT_(R::idx(rc));
-      zs += eg * (t.x - p0);
-      hs += eg * (t.x * t.y - p0l);
+      const double eg = E_(rc);
+      const double2 t = XT_(rc);
+      zs = fma(eg, t.x, zs);
+      hs = fma(eg, t.y, hs);
     }
     zs = block_sum(zs, sh);
     hs = block_sum(hs, sh);
@@ -352,7 +506,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
       }
       for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
         const RT rc = R::load(S.rec_long, k);
-        atomicAdd(&acc[R::grp(rc)], rj * (XT_(R::idx(rc)).x - p0));
+        addACC(rc, rj * XT_(rc).x);
       }
     }
   }
@@ -367,8 +521,9 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
   }
   if (GLDS) {
     __syncthreads();
+    const double *al = reinterpret_cast<const double *>(smem + bhi + acc_off);
     double *dst = partAcc + (size_t)blockIdx.x * G;
-    for (uint32_t g = tid; g < G; g += kPassThreads) dst[g] = acc[g];
+    for (uint32_t g = tid; g < G; g += kPassThreads) dst[g] = al[g];
   }
 }
 

@@ -402,24 +402,24 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
     e[g] = std::exp(st.u[g] - M);
     U += e[g];
   }
-  // centre the step values with the lagged constant (see StructState::kappa)
+  // centre the step values with the lagged constant (see StructState::kappa).  Step values are
+  // taken relative to the background cell of the same EC (a per-EC shift by (1-a)*logzi, which
+  // the variance ignores): s = D_i + wc_g on a listed cell, s0 = wc_g elsewhere.
   const double kappa = st.kappa;
   double V1c = 0.0, V2c = 0.0;
   std::vector<double> wc(G);
   for (size_t g = 0; g < G; ++g) {
-    wc[g] = w[g] - kappa;           // s = oma*T + wc_g ; s0c = oma*logzi + wc_g
-    const double s0c = oma * S.logzi + wc[g];
+    wc[g] = w[g] - kappa;
+    const double s0c = wc[g];
     V1c += e[g] * s0c;
     V2c += e[g] * s0c * s0c;
   }
   st.kappa = kappa + V1c / U;
-  std::vector<double> xm(S.n_lut), A1(S.n_lut), A2(S.n_lut);
+  std::vector<double> x(S.n_lut), D(S.n_lut);
   for (size_t i = 0; i < S.n_lut; ++i) {
     const double T = S.lut[i];
-    const double x = std::exp(a * T);
-    xm[i] = x - p0;
-    A1[i] = oma * (x * T - p0 * S.logzi);
-    A2[i] = oma * oma * (x * T * T - p0 * S.logzi * S.logzi);
+    x[i] = std::exp(a * T);
+    D[i] = oma * (T - S.logzi);
   }
   const double zbase = p0 * U, b1 = p0 * V1c, b2 = p0 * V2c;
   long double newnorm = 0.0L;
@@ -428,10 +428,12 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
     for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
       const uint32_t g = S.grp[k], i = S.lutidx[k];
       const double eg = e[g], wg = wc[g];
-      const double wx = wg * xm[i];
-      zs += eg * xm[i];
-      t1 += eg * (A1[i] + wx);
-      t2 += eg * (A2[i] + wg * (2.0 * A1[i] + wx));
+      const double xm = x[i] - p0;
+      const double xD = x[i] * D[i];
+      const double wx = wg * xm;
+      zs += eg * xm;
+      t1 += eg * (xD + wx);
+      t2 += eg * (xD * D[i] + wg * (2.0 * xD + wx));
     }
     const double iZ = 1.0 / (zbase + zs);
     const double S1 = (b1 + t1) * iZ;
