@@ -29,8 +29,8 @@ constexpr int kRegCells = 16;  // cells per EC a wave keeps in registers (longer
 #ifndef MSW_DEPTH_B
 #define MSW_DEPTH_B 2
 #endif
-#ifndef MSW_B_KEEPX
-#define MSW_B_KEEPX (MSW_DEPTH_B == 2)
+#ifndef MSW_B_KEEPN
+#define MSW_B_KEEPN (MSW_DEPTH_B == 2 ? 8 : 0)
 #endif
 #ifndef MSW_PASSA_BATCH
 #define MSW_PASSA_BATCH 4
@@ -40,6 +40,12 @@ constexpr int kRegCells = 16;  // cells per EC a wave keeps in registers (longer
 #endif
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// a wave-uniform double that was loaded through a vector load: move it to SGPRs
+__device__ __forceinline__ double uniform_d(double v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double((int)hi, (int)lo);
+}
 
 // One slice held in registers (<= kRegCells cells per EC): records, geometry and -- pass B -- the
 // EC's multiplicity.
@@ -250,8 +256,8 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   const unsigned char *xt_b = reinterpret_cast<const unsigned char *>(tabA_g);
   auto EW_ = [&](RT r) -> double2 { return tab16<GLDS>(ew_b, R::hi2(r, shift)); };
   auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
-  const double p0 = sc->p0, U = sc->U;
-  const double zbase = p0 * U, b1 = p0 * sc->V1c, b2 = p0 * sc->V2c;
+  const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
+  const double zbase = p0 * U, b1 = p0 * uniform_d(sc->V1c), b2 = p0 * uniform_d(sc->V2c);
   double nn = 0.0;
   __syncthreads();
 
@@ -384,8 +390,8 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
     else
       atomicAdd(reinterpret_cast<double *>(acc_b + off), v);
   };
-  const double p0 = sc->p0, U = sc->U;
-  const double zbase = p0 * U, hbase = p0 * sc->logzi * U;
+  const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
+  const double zbase = p0 * U, hbase = p0 * uniform_d(sc->logzi) * U;
   double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;
   __syncthreads();
 
@@ -402,11 +408,11 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
     const double c = sb.c;
     double zs = 0.0, hs = 0.0;
     if (len <= (uint32_t)kRegCells) {
-      // row sums: straight-line code per slice length (wave-uniform, even).  x - p0 of every
-      // cell stays in registers for the scatter (with three record buffers there is no room: the
-      // scatter then gathers it a second time).
-      constexpr bool KEEPX = MSW_B_KEEPX;
-      double xv[KEEPX ? kRegCells : 1];
+      // row sums: straight-line code per slice length (wave-uniform, even).  x - p0 of the first
+      // cells stays in registers for the scatter, the rest is gathered a second time (all 16
+      // would push the kernel into scratch, and a scratch reload drains the record prefetch).
+      constexpr int KEEPN = MSW_B_KEEPN;  // x - p0 of the first KEEPN cells stay in registers
+      double xv[KEEPN > 0 ? KEEPN : 1];
       auto fixed = [&](auto LEN) {
         constexpr int L = decltype(LEN)::value;
         constexpr int B = MSW_PASSB_BATCH;  // cells whose gathers are issued together
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
             if (k0 + k < L) {
               zs = fma(ev[k], xt[k].x, zs);
               hs = fma(ev[k], xt[k].y, hs);
-              if constexpr (KEEPX) xv[k0 + k] = xt[k].x;
+              if constexpr (KEEPN > 0) if (k0 + k < KEEPN) xv[k0 + k] = xt[k].x;
             }
           }
         }
@@ -445,18 +451,21 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
       if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
         const double rj = c / Z;
-        s_clogZ += c * log(Z);
         s_rH += rj * H;
         s_W += rj;
         // padding records point at the lane's own sentinel group: no test, no shared address
 #pragma unroll
         for (int k = 0; k < kRegCells; k += 2) {
           if ((uint32_t)k < len) {
-            const double x0 = KEEPX ? xv[k] : XM_(b[k]), x1 = KEEPX ? xv[k + 1] : XM_(b[k + 1]);
+            const double x0 = k < KEEPN ? xv[k < KEEPN ? k : 0] : XM_(b[k]);
+            const double x1 = k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : XM_(b[k + 1]);
             addACC(b[k], rj * x0);
             addACC(b[k + 1], rj * x1);
           }
         }
+        // after the scatter: log() needs ~30 registers, x - p0 of the EC are dead by now
+        __builtin_amdgcn_sched_barrier(0);
+        s_clogZ += c * log(Z);
       }
     } else {
       const size_t base = (size_t)o * 64 + lane;
