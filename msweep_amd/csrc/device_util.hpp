@@ -29,6 +29,26 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
   for (int i = 0; i < nw; ++i) r += sh[i];
   return r;
 }
+// N sums at once with one pair of barriers.  sh: >= 16 * N doubles.  Per value the order of
+// additions is that of block_sum, so both give bitwise the same result.
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double *sh) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) sh[w * N + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double r = 0.0;
+    for (int j = 0; j < nw; ++j) r += sh[j * N + i];
+    v[i] = r;
+  }
+}
 __device__ __forceinline__ double block_max(double v, double *sh) {
   v = wave_max(v);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

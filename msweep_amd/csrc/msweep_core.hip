@@ -59,7 +59,7 @@ struct msw_core {
   DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc;
   DevBuf<double2> ew, tabA, tabB;  // group table of pass A; per-slot tables of both sweeps (TabDev)
   TabDev tabs() const { return TabDev{tabA.p, tabB.p}; }
-  DevBuf<double> partA, partS, partAcc, partC, partR;
+  DevBuf<double> partA, partS, partAcc, partC, partR, totS;
   // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
   size_t lds_attr[2][12] = {};  // dynamic-LDS limit already granted per sweep instantiation
   msw_comm *comm = nullptr;
@@ -217,7 +217,8 @@ void alloc_solve_state(msw_core *h) {
   const int nb = std::max(h->nblk, std::max(h->nblk_dense, h->npart_rows()));
   h->partA.alloc(std::max(nb, 1024));
   h->partS.alloc(4 * (size_t)std::max(nb, 1024));
-  h->partR.alloc(kRedfinParts * ((size_t)G / 64 + 2));
+  h->partR.alloc(kRedfinParts * ((size_t)G / kRedfinGroups + 2));
+  h->totS.alloc(4);
   h->commA.alloc(1);
   h->commB.alloc((size_t)G + 4);
   h->partAcc.alloc((size_t)std::max(nb, 1) * G);
@@ -360,7 +361,7 @@ void launch_passB(msw_core *h) {
   MSW_HIP(hipGetLastError());
   if (ev) MSW_HIP(hipEventRecord(ev->second, h->stream));
   h->timing.passB_launches++;
-  // column sums across workgroups + N_g / lgamma / digamma, spread over G/64 workgroups
+  // column sums across workgroups + N_g / lgamma / digamma, spread over G/16 workgroups
   const bool partials = (h->flavor == 1) || h->glds;
   const int nb = h->npart_rows();
   if (h->comm) {
@@ -368,14 +369,14 @@ void launch_passB(msw_core *h) {
     hipLaunchKernelGGL(k_colsum, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, (int)h->G,
                        partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->commB.p);
     h->comm->allreduce(h->commB.p, (size_t)h->G + 4, h->stream);
-    hipLaunchKernelGGL(k_redfin, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, (int)h->G, 0, 1,
-                       h->partAcc.p, h->commB.p, h->commB.p + h->G, h->e.p, h->u.p, h->alpha0.p, h->Nc.p,
-                       h->N.p, h->w.p, h->ew.p, h->partR.p);
+    hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(1024), 0, h->stream,
+                       h->sc.p, (int)h->G, 0, 1, h->partAcc.p, h->commB.p, h->commB.p + h->G, h->e.p, h->u.p,
+                       h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p, h->totS.p);
     return;
   }
-  hipLaunchKernelGGL(k_redfin, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, (int)h->G,
-                     partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->e.p, h->u.p,
-                     h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p);
+  hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(1024), 0, h->stream,
+                     h->sc.p, (int)h->G, partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->e.p,
+                     h->u.p, h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p, h->totS.p);
 }
 
 // partS as seen by k_fin / k_em_fin: the all-reduced totals when sharded
@@ -385,8 +386,8 @@ int fin_npartS(msw_core *h) { return h->comm ? 1 : h->npart_rows(); }
 void launch_fin(msw_core *h, int mode) {
   TraceDev tr{h->tr_bound.p, h->tr_newnorm.p, h->tr_beta.p, h->tr_theta.p, h->tr_reset.p};
   hipLaunchKernelGGL(k_fin, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G, (int)h->n_lut,
-                     fin_npartS(h), (int)((h->G + 63) / 64), fin_partS(h), h->partR.p, h->Nc.p, h->u.p, h->os_u.p,
-                     h->step_u.p, h->lut.p, h->e.p, h->tabs(), tr);
+                     (int)((h->G + kRedfinGroups - 1) / kRedfinGroups), h->totS.p, h->partR.p, h->Nc.p, h->u.p,
+                     h->os_u.p, h->step_u.p, h->lut.p, h->e.p, h->tabs(), tr);
 }
 
 void poll(msw_core *h) {

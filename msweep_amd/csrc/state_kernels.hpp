@@ -58,19 +58,39 @@ __global__ __launch_bounds__(1024) void k_prepB(Scalars *sc, int G, int n_lut, c
 }
 
 // Fletcher-Reeves step (rcgpar rcg_optl_mat: beta_FR, oldstep scaling, gamma += step) on
-// the (a, u) state, followed by the pass-B preparation.
+// the (a, u) state, followed by the pass-B preparation.  This single-workgroup kernel sits between
+// the two sweeps of every iteration, so it is organised around memory round trips, not arithmetic:
+// every load is issued up front, u stays in registers from the step to the exp, and the
+// per-slot tables (which only need the new scalar a) are built while the group loop runs.
+// Groups beyond kStepRegs * 1024 take the (slower) looping path through prepB_block.
+constexpr int kStepRegs = 8;
 __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, int n_partA,
                                               const double *partA, const double *w, double *u,
                                               double *os_u, double *step_u, const double *lut,
                                               double *e, TabDev X) {
   __shared__ double sh[32];
-  if (sc->done || sc->reset_pending) return;  // a pending re-evaluation skips pass A and the step
+  const Scalars s0 = *sc;  // one read of the whole state: no dependent scalar round trips later
+  if (s0.done || s0.reset_pending) return;  // a pending re-evaluation skips pass A and the step
   const int tid = threadIdx.x, nt = blockDim.x;
-  const double a = sc->a, oldnorm = sc->oldnorm, bound = sc->bound;
-  double os_a = sc->os_a;
-  const int didreset = sc->didreset;
+  const double a = s0.a, oldnorm = s0.oldnorm, bound = s0.bound, logzi = s0.logzi;
+  double os_a = s0.os_a;
+  const int didreset = s0.didreset;
+  const bool inreg = G <= kStepRegs * nt;
   double pn = 0.0;
   for (int i = tid; i < n_partA; i += nt) pn += partA[i];
+  double wv[kStepRegs], ov[kStepRegs], uv[kStepRegs];
+  if (inreg) {
+#pragma unroll
+    for (int k = 0; k < kStepRegs; ++k) {
+      const int g = tid + k * nt;
+      if (g < G) {
+        wv[k] = w[g];
+        ov[k] = os_u[g];
+        uv[k] = u[g];
+      }
+    }
+  }
+  const double lt = tid < n_lut ? lut[tid] : 0.0;  // first table entry of this thread
   const double newnorm = block_sum(pn, sh);
   const double beta = newnorm / oldnorm;
   double step_a = 1.0 - a;
@@ -80,20 +100,79 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
     os_a *= beta;
     step_a += os_a;
   }
-  for (int g = tid; g < G; g += nt) {
-    double osu = os_u[g], su = w[g];
-    if (didreset) {
-      osu *= 0.0;
-    } else if (beta > 0) {
-      osu *= beta;
-      su += osu;
-    }
-    os_u[g] = osu;
-    step_u[g] = su;
-    u[g] += su;
-  }
   const double a_new = a + step_a;
-  __syncthreads();
+  if (!inreg) {
+    for (int g = tid; g < G; g += nt) {
+      double osu = os_u[g], su = w[g];
+      if (didreset) {
+        osu *= 0.0;
+      } else if (beta > 0) {
+        osu *= beta;
+        su += osu;
+      }
+      os_u[g] = osu;
+      step_u[g] = su;
+      u[g] += su;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      sc->a = a_new;
+      sc->os_a = os_a;
+      sc->step_a = step_a;
+      sc->oldnorm = newnorm;
+      sc->newnorm = newnorm;
+      sc->beta = beta;
+      sc->didreset = 0;
+      sc->oldbound = bound;
+    }
+    if (s0.flavor == 0) prepB_block(sc, a_new, G, n_lut, u, lut, e, X, sh);
+    return;
+  }
+  double m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < kStepRegs; ++k) {
+    const int g = tid + k * nt;
+    if (g < G) {
+      double osu = ov[k], su = wv[k];
+      if (didreset) {
+        osu *= 0.0;
+      } else if (beta > 0) {
+        osu *= beta;
+        su += osu;
+      }
+      uv[k] += su;
+      os_u[g] = osu;
+      step_u[g] = su;
+      u[g] = uv[k];
+      m = fmax(m, uv[k]);
+    }
+  }
+  const int flavor = s0.flavor;
+  double p0 = 0.0;
+  if (flavor == 0) {  // per-slot tables of both sweeps (prepB_block's arithmetic)
+    const double oma = 1.0 - a_new;
+    p0 = exp(a_new * logzi);
+    for (int i = tid; i < n_lut; i += nt) {
+      const double T = i == tid ? lt : lut[i], x = exp(a_new * T);
+      X.A[i] = make_double2(x, oma * (T - logzi));
+      X.B[i] = make_double2(x - p0, x * T - p0 * logzi);
+    }
+  }
+  double M = 0.0, U = 0.0;
+  if (flavor == 0) {
+    M = block_max(m, sh);
+    double su = 0.0;
+#pragma unroll
+    for (int k = 0; k < kStepRegs; ++k) {
+      const int g = tid + k * nt;
+      if (g < G) {
+        const double eg = exp(uv[k] - M);
+        e[g] = eg;
+        su += eg;
+      }
+    }
+    U = block_sum(su, sh);
+  }
   if (tid == 0) {
     sc->a = a_new;
     sc->os_a = os_a;
@@ -103,71 +182,96 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
     sc->beta = beta;
     sc->didreset = 0;
     sc->oldbound = bound;
+    if (flavor == 0) {
+      sc->M = M;
+      sc->U = U;
+      sc->p0 = p0;
+    }
   }
-  if (sc->flavor == 0) prepB_block(sc, a_new, G, n_lut, u, lut, e, X, sh);
 }
 
 // Column sums across workgroups (fixed order) fused with the per-group math that follows them:
 // Nc_g, N_g, lgamma(N_g), (M - u_g) * Nc_g, w_g = digamma(N_g) - 1 - u_g and the pass-A gradient
 // preparation {e_g, w_g - kappa} with its sums S0 = sum e, S1 = sum e*s0, S2 = sum e*s0^2
 // (s0_g = w_g - kappa: the step value of a background cell relative to which pass A measures the
-// listed cells; kappa = lagged centring constant, see k_fin).  One
-// 1024-thread workgroup per 64 groups: 16 wavefronts split the partial rows, so the lgamma /
-// digamma evaluations spread over ~G/64 CUs instead of one.
+// listed cells; kappa = lagged centring constant, see k_fin).  One 1024-thread workgroup per
+// kRedfinGroups = 16 groups (313 workgroups at 5k groups: the 10 MB of partial rows pass B left
+// behind are read by the whole chip, not by 79 CUs): thread t sums rows t/16, t/16 + 64, ... of
+// group t%16 (a row's 16 groups are one 128-byte line), 64 row slots meet in LDS in fixed order.
 //   nblk > 0: sum partAcc[b*G + g] over b;  nblk == 0: Acc already holds the totals.
+// Block 0 also leaves the totals of the per-workgroup ELBO terms for k_fin in totS[0..2].
 constexpr int kRedfinParts = 5;
+constexpr int kRedfinGroups = 16;
 __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int nblk,
                                                 int npartS, const double *partAcc, const double *Acc,
                                                 const double *partS, const double *e, const double *u,
                                                 const double *alpha0, double *Nc, double *N, double *w,
-                                                double2 *ew, double *partR) {
-  __shared__ double sh[32];
-  __shared__ double accs[16][64];
-  if (sc->done) return;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int g = blockIdx.x * 64 + lane;
-  // W = sum_j r_j : every workgroup forms it in the same fixed order
-  double pw = 0.0;
-  for (int b = tid; b < npartS; b += 1024) pw += partS[4 * b + 2];
-  const double W = block_sum(pw, sh);
+                                                double2 *ew, double *partR, double *totS) {
+  __shared__ double sh[48];
+  __shared__ double accs[64][kRedfinGroups];
+  const Scalars s0 = *sc;
+  if (s0.done) return;
+  const int tid = threadIdx.x, gl = tid & (kRedfinGroups - 1), rs = tid >> 4;
+  const int g = blockIdx.x * kRedfinGroups + gl;
   double s = 0.0;
   if (g < G) {
     if (nblk > 0) {
-      for (int b = wv; b < nblk; b += 16) s += partAcc[(size_t)b * G + g];
-    } else if (wv == 0) {
+      for (int b = rs; b < nblk; b += 64) s += partAcc[(size_t)b * G + g];
+    } else if (rs == 0) {
       s = Acc[g];
     }
   }
-  accs[wv][lane] = s;
-  __syncthreads();
-  if (wv != 0) return;
+  // per-group operands of the math below: loaded now, needed after the reductions
+  double ug0 = 0.0, eg0 = 0.0, al0 = 0.0;
+  if (tid < kRedfinGroups && g < G) {
+    ug0 = u[g];
+    eg0 = e[g];
+    al0 = alpha0[g];
+  }
+  // W = sum_j r_j (and, for k_fin, the other two ELBO sums): every workgroup forms them in the
+  // same fixed order
+  double t[3] = {0.0, 0.0, 0.0};
+  for (int b = tid; b < npartS; b += 1024) {
+    t[0] += partS[4 * b];
+    t[1] += partS[4 * b + 1];
+    t[2] += partS[4 * b + 2];
+  }
+  accs[rs][gl] = s;
+  block_sum_n<3>(t, sh);  // its barriers also publish accs
+  const double W = t[2];
+  if (blockIdx.x == 0 && tid == 0) {
+    totS[0] = t[0];
+    totS[1] = t[1];
+    totS[2] = t[2];
+  }
+  if (tid >= 64) return;
   double lgv = 0.0, muv = 0.0, s0v = 0.0, s1v = 0.0, s2v = 0.0;
-  if (g < G) {
+  if (tid < kRedfinGroups && g < G) {
     double A = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) A += accs[i][lane];
+    for (int i = 0; i < 64; ++i) A += accs[i][gl];
     double nc;
-    const double ug = u[g];
-    const int flavor = sc->flavor;
+    const double ug = ug0;
+    const int flavor = s0.flavor;
     if (flavor == 0) {
-      nc = e[g] * (sc->p0 * W + A);
-      muv = (sc->M - ug) * nc;
+      nc = eg0 * (s0.p0 * W + A);
+      muv = (s0.M - ug) * nc;
     } else {
       nc = A;
     }
-    const double n = alpha0[g] + nc;
+    const double n = al0 + nc;
     Nc[g] = nc;
     N[g] = n;
     lgv = lgamma(n);
     const double wg = digamma_ref(n) - 1.0 - ug;
     w[g] = wg;
     if (flavor == 0) {
-      const double eg = e[g], wc = wg - sc->kappa;
-      const double s0 = wc;
+      const double eg = eg0, wc = wg - s0.kappa;
+      const double sb = wc;
       ew[g] = make_double2(eg, wc);
       s0v = eg;
-      s1v = eg * s0;
-      s2v = eg * s0 * s0;
+      s1v = eg * sb;
+      s2v = eg * sb * sb;
     }
   }
   lgv = wave_sum(lgv);
@@ -175,7 +279,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
   s0v = wave_sum(s0v);
   s1v = wave_sum(s1v);
   s2v = wave_sum(s2v);
-  if (lane == 0) {
+  if (tid == 0) {
     double *o = partR + kRedfinParts * blockIdx.x;
     o[0] = lgv;
     o[1] = muv;
@@ -191,32 +295,34 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
 //   reset_pending is set -- the re-evaluation after a rejected step.
 // kappa (centring constant of the pass-A step values) advances to the e-weighted mean just
 // measured: kappa += S1 / S0.
-__global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int n_lut, int npartS,
-                                             int npartR, const double *partS, const double *partR,
+// totS = {sum c log Z, sum r H, sum r} as left by k_redfin's block 0.
+__global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int n_lut, int npartR,
+                                             const double *totS, const double *partR,
                                              const double *Nc, double *u, double *os_u,
                                              const double *step_u, const double *lut, double *e,
                                              TabDev X, TraceDev tr) {
-  __shared__ double sh[32];
-  if (sc->done) return;
+  __shared__ double sh[16 * kRedfinParts];
+  const Scalars s0 = *sc;  // one read of the whole state
+  if (s0.done) return;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int flavor = sc->flavor;
-  const int reeval = sc->reset_pending;
-  const double a = sc->a, oldbound = sc->oldbound;
-  const double beta = sc->beta, tol = sc->tol, csum = sc->csum, kappa = sc->kappa;
-  double p1 = 0.0, p2 = 0.0, q[kRedfinParts] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int b = tid; b < npartS; b += nt) {
-    p1 += partS[4 * b];
-    p2 += partS[4 * b + 1];
-  }
+  const int flavor = s0.flavor;
+  const int reeval = s0.reset_pending;
+  const double a = s0.a, oldbound = s0.oldbound;
+  const double beta = s0.beta, tol = s0.tol, csum = s0.csum, kappa = s0.kappa;
+  double q[kRedfinParts] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int b = tid; b < npartR; b += nt)
     for (int i = 0; i < kRedfinParts; ++i) q[i] += partR[kRedfinParts * b + i];
-  const double s_clogZ = block_sum(p1, sh);
-  const double s_rH = block_sum(p2, sh);
-  const double lg = block_sum(q[0], sh);
-  const double mu = block_sum(q[1], sh);
-  const double S0 = block_sum(q[2], sh);
-  const double S1 = block_sum(q[3], sh);
-  const double S2 = block_sum(q[4], sh);
+  const double s_clogZ = totS[0], s_rH = totS[1];
+  // the accepted step becomes oldstep below: fetch it now, together with everything else
+  const bool inreg = G <= kStepRegs * nt;
+  double sv[kStepRegs];
+  if (inreg && !reeval && mode != 2) {
+#pragma unroll
+    for (int k = 0; k < kStepRegs; ++k)
+      if (tid + k * nt < G) sv[k] = step_u[tid + k * nt];
+  }
+  block_sum_n<kRedfinParts>(q, sh);  // one pair of barriers for the five sums
+  const double lg = q[0], mu = q[1], S0 = q[2], S1 = q[3], S2 = q[4];
   if (mode == 2) {
     if (tid == 0 && flavor == 0) {
       sc->V1c = S1;
@@ -226,14 +332,14 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
     return;
   }
   const double coef = (flavor == 0) ? (1.0 - a) : 1.0;
-  const double bound = sc->bound_const + s_clogZ + coef * s_rH + mu + lg;
-  const int didreset = sc->didreset;
+  const double bound = s0.bound_const + s_clogZ + coef * s_rH + mu + lg;
+  const int didreset = s0.didreset;
   __syncthreads();
   if (!reeval && bound < oldbound) {
     // bad step: revert to steepest descent (gamma += oldm; gamma -= oldstep) and re-evaluate
     double a2 = a;
     if (beta > 0) {
-      a2 = a - sc->os_a;
+      a2 = a - s0.os_a;
       for (int g = tid; g < G; g += nt) u[g] -= os_u[g];
     }
     __syncthreads();
@@ -248,18 +354,24 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
   }
   if (!reeval) {
     // oldstep = step
-    for (int g = tid; g < G; g += nt) os_u[g] = step_u[g];
+    if (inreg) {
+#pragma unroll
+      for (int k = 0; k < kStepRegs; ++k)
+        if (tid + k * nt < G) os_u[tid + k * nt] = sv[k];
+    } else {
+      for (int g = tid; g < G; g += nt) os_u[g] = step_u[g];
+    }
   }
-  const int it = sc->iter;
-  if (it < sc->trace_theta && tr.theta) {
+  const int it = s0.iter;
+  if (it < s0.trace_theta && tr.theta) {
     for (int g = tid; g < G; g += nt) tr.theta[(size_t)it * G + g] = Nc[g] / csum;
   }
   int done = 0;
-  if (!sc->fixed_iters && (bound - oldbound < tol) && !didreset) done = 1;
-  if (it + 1 >= sc->max_iters) done = 1;
+  if (!s0.fixed_iters && (bound - oldbound < tol) && !didreset) done = 1;
+  if (it + 1 >= s0.max_iters) done = 1;
   __syncthreads();
   if (tid == 0) {
-    if (!reeval) sc->os_a = sc->step_a;
+    if (!reeval) sc->os_a = s0.step_a;
     sc->bound = bound;
     sc->reset_pending = 0;
     if (flavor == 0) {
@@ -269,7 +381,7 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
     }
     if (it < kMaxTrace) {
       tr.bound[it] = bound;
-      tr.newnorm[it] = sc->newnorm;
+      tr.newnorm[it] = s0.newnorm;
       tr.beta[it] = beta;
       tr.didreset[it] = didreset;
     }

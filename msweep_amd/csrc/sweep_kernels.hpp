@@ -29,6 +29,9 @@ constexpr int kRegCells = 16;  // cells per EC a wave keeps in registers (longer
 #ifndef MSW_DEPTH_B
 #define MSW_DEPTH_B 2
 #endif
+#ifndef MSW_REVERSE_B
+#define MSW_REVERSE_B true
+#endif
 #ifndef MSW_B_KEEPN
 #define MSW_B_KEEPN (MSW_DEPTH_B == 2 ? 8 : 0)
 #endif
@@ -91,7 +94,7 @@ __device__ __forceinline__ void wait_vm() {
 // double-buffered version).  The slice geometry (slice_off pairs) of 64 slices at a time is
 // fetched with one gather per lane and parked in LDS: no dependent global load sits between two
 // slices.  EXTRA = vector loads per slice that `issue` adds besides the records.
-template <bool WIDE, int EXTRA, int DEPTH>
+template <bool WIDE, int EXTRA, int DEPTH, bool REVERSE>
 struct SliceStream {
   const SellDev &S;
   uint32_t s_first, nw, n_mine, lane;
@@ -103,13 +106,20 @@ struct SliceStream {
     n_mine = first < S.nslices ? (S.nslices - first + nw_ - 1) / nw_ : 0;
     gather_offs(0);
   }
+  // i-th slice this wave visits.  Pass B walks the list backwards: the sweeps alternate, so each
+  // starts on the part of the record stream the other has just left in the memory-side cache
+  // (the stream is larger than the 256 MB Infinity Cache: walking it the same way every time
+  // would evict every line before its reuse).
+  __device__ __forceinline__ uint32_t slice_at(uint32_t i) const {
+    return s_first + (REVERSE ? (i < n_mine ? n_mine - 1 - i : i) : i) * nw;
+  }
   // geometry of the wave's slices [64 * chunk, 64 * chunk + 64): one gather per lane, parked in LDS
   // (a register copy would make every later use wait for ALL outstanding vector loads)
   __device__ __forceinline__ void gather_offs(uint32_t chunk) {
     const uint32_t i = chunk * 64 + lane;
     pend = make_uint2(0, 0);  // past the wave's last slice: the dummy geometry
     if (i < n_mine) {
-      const uint32_t sl = s_first + i * nw;
+      const uint32_t sl = slice_at(i);
       pend = make_uint2(S.slice_off[sl], S.slice_off[sl + 1]);
     }
   }
@@ -127,7 +137,7 @@ struct SliceStream {
     typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const v2u_t lds_cu2_t;
     const v2u_t oe = *(lds_cu2_t *)(size_t)(geo + j * 8);
-    b.sl = s_first + (base + j) * nw;
+    b.sl = slice_at(base + j);
     b.o = uniform(oe.x);
     b.len = uniform(oe.y) - b.o;
     load_slice<WIDE, DEPTH == 3>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r);
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   const uint32_t shift = S.shift, mask = S.mask, bhi2 = 2 * S.bhi;
   double *sh = reinterpret_cast<double *>(smem + pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true));
   // slice geometry of this wave: the gather is in flight while the LDS image is filled
-  SliceStream<WIDE, 0, MSW_DEPTH_A> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
+  SliceStream<WIDE, 0, MSW_DEPTH_A, false> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
                               gridDim.x * (kPassThreads / 64), (uint32_t)lane,
                               (uint32_t)pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true) + 256u +
                                   uniform(tid >> 6) * kGeoStride);
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
   constexpr bool GLDS = GMODE > 0;
   const uint32_t acc_off = pass_acc_off(GMODE, G);
   double *sh = reinterpret_cast<double *>(smem + pass_scratch_off(GMODE, TLDS, G, n_lut, false));
-  SliceStream<WIDE, 1, MSW_DEPTH_B> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
+  SliceStream<WIDE, 1, MSW_DEPTH_B, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
                               gridDim.x * (kPassThreads / 64), (uint32_t)lane,
                               (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 256u +
                                   uniform(tid >> 6) * kGeoStride);
