@@ -57,6 +57,7 @@ struct msw_core {
 
   // ---- solve state ---------------------------------------------------------------------
   DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc;
+  DevBuf<uint8_t> c8;  // byte image of cvec (sell.hpp)
   DevBuf<double2> ew, tabA, tabB;  // group table of pass A; per-slot tables of both sweeps (TabDev)
   TabDev tabs() const { return TabDev{tabA.p, tabB.p}; }
   DevBuf<double> partA, partS, partAcc, partC, partR, totS;
@@ -146,6 +147,7 @@ SellDev sell_view(msw_core *h) {
   S.rec_long = h->rec_long.p;
   S.perm = h->perm.p;
   S.cvec = h->cvec.p;
+  S.c8 = h->c8.p;
   S.nslices = h->nslices;
   S.n_long = h->n_long;
   S.n_ecs = h->E;
@@ -189,7 +191,8 @@ void choose_layout(msw_core *h) {
   h->wide = true;
   h->enc_shift = 0;
   h->enc_mask = 0xffffffffu;
-  for (uint32_t s = 5; s <= 31; ++s) {
+  const char *force = getenv("MSWEEP_RECORD_BYTES");  // developer switch: 8 = skip the 4-byte format
+  for (uint32_t s = 5; s <= 31 && !(force && atoi(force) == 8); ++s) {
     if (lo_end <= (1ull << (s - 1)) && hi_end <= (1ull << (32 - s))) {
       h->wide = false;
       h->enc_shift = s;
@@ -211,6 +214,7 @@ void alloc_solve_state(msw_core *h) {
   h->e.zero(h->stream);
   h->ew.zero(h->stream);
   h->cvec.alloc(E);
+  h->c8.alloc((size_t)E + 64);
   h->logc_d.alloc(E);
   h->tabA.alloc((size_t)std::max<uint32_t>(h->n_lut, 1));
   h->tabB.alloc((size_t)std::max<uint32_t>(h->n_lut, 1));
@@ -404,11 +408,11 @@ void prepare_inputs(msw_core *h, const double *logc_host, const uint32_t *counts
   const uint32_t E = h->E, G = h->G;
   if (counts_dev) {
     hipLaunchKernelGGL(k_cvec_from_counts, dim3(kCvecBlocks), dim3(256), 0, h->stream, counts_dev,
-                       h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->partC.p);
+                       h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->c8.p, h->partC.p);
   } else {
     MSW_HIP(hipMemcpyAsync(h->logc_d.p, logc_host, E * sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_cvec_from_logc, dim3(kCvecBlocks), dim3(256), 0, h->stream, h->logc_d.p,
-                       h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->partC.p);
+                       h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->c8.p, h->partC.p);
   }
   if (alpha0_host)
     MSW_HIP(hipMemcpyAsync(h->alpha0.p, alpha0_host, G * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -520,7 +524,7 @@ void collect_timing(msw_core *h) {
     // algorithmic bytes: every real cell record once + the per-EC count vector in
     // pass B; SELL padding, slice offsets and the L2-served second read of pass B are not counted
     h->timing.bytes_passA = h->nnz * recsz;
-    h->timing.bytes_passB = h->nnz * recsz + 8ull * h->E;
+    h->timing.bytes_passB = h->nnz * recsz + 1ull * h->E;  // + one byte per EC (its multiplicity)
   } else {
     h->timing.bytes_passA = 8ull * h->E * h->G;
     h->timing.bytes_passB = 8ull * h->E * h->G + 8ull * h->E;

@@ -32,11 +32,13 @@ struct SellDev {
   const uint32_t *rec_long;   // records of the long ECs (CSR)
   const uint32_t *perm;       // [E] permuted position -> original EC index
   const double *cvec;         // [E] EC multiplicities, permuted order
+  const uint8_t *c8;          // [E] the same as a byte; kC8Escape = not a small integer, read cvec
   const uint32_t *area_slot;  // [n_area] LUT slot held by each 16-byte entry of the slot area
   uint32_t nslices, n_long, n_ecs, n_groups, n_lut, n_area;
   uint32_t shift, mask, bhi;  // record encoding (narrow: shift / lo mask; both: bhi)
 };
 
+constexpr uint32_t kC8Escape = 255;
 constexpr int kLongRow = 256;  // ECs with more cells than this take the workgroup path
 
 template <bool WIDE>

@@ -454,12 +454,25 @@ __global__ __launch_bounds__(1024) void k_colsum(const Scalars *sc, int G, int n
 // order, sum of counts, bound constant (rcgpar calc_bound_const), initial gamma = log(1/G).
 // perm == nullptr: identity (dense flavour).
 // ---------------------------------------------------------------------------------------
+// Byte image of a multiplicity for pass B's stream (8 bytes per EC would be a sixth of that
+// sweep's HBM traffic): small integer counts -- the normal case -- as themselves, anything else
+// as kC8Escape.  c is snapped to the integer it is within rounding of (exp(log(n)) need not be n).
+__device__ __forceinline__ uint8_t c8_of(double &c) {
+  const double r = rint(c);
+  if (r >= 0.0 && r < 255.0 && fabs(c - r) <= 1e-12 * r) {
+    c = r;
+    return (uint8_t)r;
+  }
+  return (uint8_t)255;
+}
+
 __global__ __launch_bounds__(256) void k_cvec_from_logc(const double *logc, const uint32_t *perm,
-                                                       uint32_t E, double *cvec, double *part) {
+                                                       uint32_t E, double *cvec, uint8_t *c8, double *part) {
   __shared__ double sh[32];
   double s = 0.0;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < E; j += gridDim.x * blockDim.x) {
-    const double c = exp(logc[perm ? perm[j] : j]);
+    double c = exp(logc[perm ? perm[j] : j]);
+    c8[j] = c8_of(c);
     cvec[j] = c;
     s += c;
   }
@@ -468,11 +481,12 @@ __global__ __launch_bounds__(256) void k_cvec_from_logc(const double *logc, cons
 }
 
 __global__ __launch_bounds__(256) void k_cvec_from_counts(const uint32_t *cnt, const uint32_t *perm,
-                                                         uint32_t E, double *cvec, double *part) {
+                                                         uint32_t E, double *cvec, uint8_t *c8, double *part) {
   __shared__ double sh[32];
   double s = 0.0;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < E; j += gridDim.x * blockDim.x) {
-    const double c = (double)cnt[perm ? perm[j] : j];
+    double c = (double)cnt[perm ? perm[j] : j];
+    c8[j] = c8_of(c);
     cvec[j] = c;
     s += c;
   }

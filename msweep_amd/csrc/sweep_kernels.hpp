@@ -33,7 +33,7 @@ constexpr int kRegCells = 16;  // cells per EC a wave keeps in registers (longer
 #define MSW_REVERSE_B true
 #endif
 #ifndef MSW_B_KEEPN
-#define MSW_B_KEEPN (MSW_DEPTH_B == 2 ? 8 : 0)
+#define MSW_B_KEEPN (MSW_DEPTH_B == 2 ? 6 : 0)
 #endif
 #ifndef MSW_PASSA_BATCH
 #define MSW_PASSA_BATCH 4
@@ -56,7 +56,7 @@ template <bool WIDE>
 struct SliceBuf {
   typename Rec<WIDE>::T r[kRegCells];
   uint32_t sl, o, len;
-  double c;
+  uint32_t c8;  // byte image of the EC's multiplicity (sell.hpp)
 };
 
 // Issue the loads of one slice into registers: ALWAYS kRegCells loads.  Rows past the slice's
@@ -149,8 +149,8 @@ struct SliceStream {
   // conditional between two fetches (even a rarely taken reload of the geometry) makes the
   // compiler fall back to vmcnt(0).  The geometry is therefore renewed between 64-slice chunks,
   // with the stream drained.
-  template <class Issue, class Process>
-  __device__ __forceinline__ void run(Issue issue, Process process) {
+  template <class Issue, class Process, class ChunkEnd>
+  __device__ __forceinline__ void run(Issue issue, Process process, ChunkEnd chunk_end) {
     for (uint32_t base = 0; base == 0 || base < n_mine; base += 64) {
       if (base) gather_offs(base >> 6);
       commit_offs();
@@ -171,6 +171,7 @@ struct SliceStream {
           ++j;
         }
         wait_vm<0>();
+        chunk_end();
         continue;
       }
       fetch(base, 0, A, issue);
@@ -191,6 +192,7 @@ struct SliceStream {
         ++j;
       }
       wait_vm<0>();
+      chunk_end();
     }
   }
 };
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
       nn += S2 - S1 * S1;
     }
   };
-  stream.run(issue, process);
+  stream.run(issue, process, [] {});
   // long ECs: the whole workgroup strides over one EC's cells
   for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
     AccA c = {0.0, 0.0, 0.0};
@@ -403,19 +405,27 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, hbase = p0 * uniform_d(sc->logzi) * U;
   double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;
+  double lp_mant = 1.0;  // deferred logarithms: product of mantissas in [2^-192, 1] ...
+  int lp_exp = 0;        // ... and sum of exponents, per lane
+  auto flush_logs = [&] {
+    s_clogZ += log(lp_mant) + (double)lp_exp * 0.693147180559945309417232121458;
+    lp_mant = 1.0;
+    lp_exp = 0;
+  };
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
   auto issue = [&](SliceBuf<WIDE> &sb) {
     // always one load (clamped index): the stream counts on a fixed number of loads per slice
     const uint32_t q = sb.sl * 64 + lane;
-    const double cj = S.cvec[S.n_long + (q < n_sell ? q : 0u)];
-    sb.c = q < n_sell ? cj : 0.0;
+    const uint32_t cj = S.c8[S.n_long + (q < n_sell ? q : 0u)];
+    sb.c8 = q < n_sell ? cj : 0u;
   };
   auto process = [&](SliceBuf<WIDE> &sb) {
     RT(&b)[kRegCells] = sb.r;
     const uint32_t o = sb.o, len = sb.len;
-    const double c = sb.c;
+    double c = (double)sb.c8;
+    if (sb.c8 == kC8Escape) c = S.cvec[S.n_long + sb.sl * 64 + lane];  // not a small integer: rare
     double zs = 0.0, hs = 0.0;
     if (len <= (uint32_t)kRegCells) {
       // row sums: straight-line code per slice length (wave-uniform, even).  x - p0 of the first
@@ -473,9 +483,22 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
             addACC(b[k + 1], rj * x1);
           }
         }
-        // after the scatter: log() needs ~30 registers, x - p0 of the EC are dead by now
+        // sum c log Z after the scatter (its registers are free by now).  For the multiplicities
+        // 1..3 -- nearly all ECs -- the logarithm is deferred: the mantissas are multiplied up per
+        // lane and one log per 64 slices is taken of the product (flush_logs): ~8 operations per
+        // EC instead of ~40, and if anything a smaller rounding error than the sum of logs.
         __builtin_amdgcn_sched_barrier(0);
-        s_clogZ += c * log(Z);
+        if (sb.c8 <= 3u) {
+          int ez;
+          const double m = frexp(Z, &ez);
+          double r = m;
+          r *= sb.c8 >= 2u ? m : 1.0;
+          r *= sb.c8 >= 3u ? m : 1.0;
+          lp_mant *= r;
+          lp_exp += ez * (int)sb.c8;
+        } else {
+          s_clogZ += c * log(Z);
+        }
       }
     } else {
       const size_t base = (size_t)o * 64 + lane;
@@ -502,7 +525,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
       }
     }
   };
-  stream.run(issue, process);
+  stream.run(issue, process, flush_logs);
   for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
     double zs = 0.0, hs = 0.0;
     for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
