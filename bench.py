@@ -166,9 +166,14 @@ def main():
     core.run(max_iters=max(a.warmup, 1))     # W untimed warm-up steps
 
     def sync():
+        # barrier + device synchronisation on both sides of the timed region.  core.run() itself
+        # returns only after its HIP stream has drained (it downloads theta), so with one rank there
+        # is nothing left to wait for and torch is not even imported.
         if dist is not None:
+            import torch
+            torch.cuda.synchronize()
             dist.barrier()
-        # core.run() returns only after the solve stream has drained (it downloads theta)
+            torch.cuda.synchronize()
 
     sync()
     t0 = time.perf_counter()
