@@ -80,6 +80,9 @@ int msw_core_build_likelihood(msw_handle h, const uint64_t *ec_tptr,
  * what Likelihood::log_mat() (include/Likelihood.hpp:325) would hold; used by
  * --write-likelihood (include/Likelihood.hpp:255-273) and the parity tests. */
 int msw_core_get_dense_logl(msw_handle h, double *L_out, size_t ld);
+/* FNV-1a hash of the resident CSR-of-ECs layout (EC order, slice geometry, records): test hook that
+ * holds the device packer against its host reference implementation (MSWEEP_HOST_PACK=1). */
+int msw_core_layout_hash(msw_handle h, uint64_t *hash_out);
 /* shape of the resident likelihood */
 int msw_core_shape(msw_handle h, size_t *n_groups, size_t *n_ecs, size_t *nnz);
 

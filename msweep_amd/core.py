@@ -20,7 +20,7 @@ PREC_DOUBLE, PREC_FLOAT = 0, 1
 EXPORTS = [
     "msw_core_create", "msw_core_destroy", "msw_last_error", "msw_core_version",
     "msw_core_set_dense_logl", "msw_core_set_csr", "msw_core_build_likelihood",
-    "msw_core_get_dense_logl", "msw_core_shape", "msw_core_solve", "msw_core_prepare", "msw_core_run",
+    "msw_core_get_dense_logl", "msw_core_layout_hash", "msw_core_shape", "msw_core_solve", "msw_core_prepare", "msw_core_run",
     "msw_core_gamma",
     "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
@@ -63,6 +63,7 @@ def load_library():
     L.msw_core_build_likelihood.argtypes = [vp, vp, vp, sz, vp, sz, vp, sz, vp, dp, dp, dp, sz,
                                             C.POINTER(sz), vp, vp]
     L.msw_core_get_dense_logl.argtypes = [vp, vp, sz]
+    L.msw_core_layout_hash.argtypes = [vp, vp]
     L.msw_core_shape.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.msw_core_solve.argtypes = [vp, vp, vp, dp, sz, C.c_int, C.c_int, vp, C.POINTER(sz), C.POINTER(dp)]
     L.msw_core_prepare.argtypes = [vp, vp, vp]
@@ -175,6 +176,11 @@ class Core:
         g, e, n = C.c_size_t(), C.c_size_t(), C.c_size_t()
         self._check(self._L.msw_core_shape(self._h, C.byref(g), C.byref(e), C.byref(n)))
         return g.value, e.value, n.value
+
+    def layout_hash(self):
+        out = C.c_uint64(0)
+        self._check(self._L.msw_core_layout_hash(self._h, C.byref(out)))
+        return int(out.value)
 
     def get_dense_logl(self):
         G, E, _ = self.shape()

@@ -16,7 +16,10 @@
 #include <unordered_map>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "kernels.hpp"
+#include "pack_kernels.hpp"
 #include "comm.hpp"
 #include "likelihood_kernels.hpp"
 #include "bootstrap_kernels.hpp"
@@ -552,6 +555,7 @@ void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, dou
 }  // namespace
 
 #include "host_likelihood.inc"
+#include "host_pack.inc"
 #include "host_em.inc"
 #include "host_bootstrap.inc"
 #include "host_build.inc"
@@ -623,6 +627,13 @@ int msw_core_build_likelihood(msw_handle h, const uint64_t *ec_tptr, const uint3
     build_likelihood_impl(h, ec_tptr, ec_targets, n_ecs, target_group, n_targets, group_sizes,
                           n_groups, ec_counts, q, e, zero_inflation, min_hits, n_groups_out, mask_out,
                           logc_out);
+  });
+}
+
+int msw_core_layout_hash(msw_handle h, uint64_t *hash_out) {
+  return guarded(h, [&] {
+    if (!hash_out) throw Fail("null out");
+    *hash_out = layout_hash(h);
   });
 }
 

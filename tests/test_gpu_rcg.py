@@ -250,6 +250,52 @@ def test_fractional_and_large_multiplicities(gpu_core, oracle):
     assert_theta(res["theta"], ref["theta"])
 
 
+def _ragged_problem(rng, E, G, sizes, lens):
+    lut = precalc_lls(sizes)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    grp = np.concatenate([np.sort(rng.choice(G, k, replace=False)) for k in lens] + [np.zeros(0, np.int64)]).astype(np.uint32)
+    cnt = rng.integers(1, sizes[grp] + 1).astype(np.uint32)
+    return rowptr, grp, cnt, lut
+
+
+@pytest.mark.parametrize("case", ["short", "ragged", "wide"])
+def test_device_packer_matches_host_packer(oracle, monkeypatch, case):
+    """The SELL layout is built on the device (pack_kernels.hpp); MSWEEP_HOST_PACK=1 runs the host
+    reference implementation.  Same EC order, slice geometry and records, byte for byte -- with
+    empty ECs, every slice length, streaming (17..256 cells) and long (> 256) ECs, 8-byte records."""
+    rng = np.random.default_rng({"short": 1, "ragged": 2, "wide": 3}[case])
+    if case == "short":
+        G = 300
+        p = synth.make_csr_problem(30000, G, seed=41, max_other=15)
+        lut = precalc_lls(p["group_sizes"])
+        rowptr, grp, cnt = p["rowptr"], p["grp"], p["cnt"]
+    else:
+        G = 700 if case == "ragged" else 400
+        sizes = (rng.integers(2, 12, G) if case == "ragged" else rng.permutation(np.arange(100, 100 + G))).astype(np.uint64)
+        E = 5000
+        lens = rng.integers(0, 17, E)
+        lens[rng.choice(E, 300, replace=False)] = rng.integers(17, 257, 300)
+        lens[rng.choice(E, 12, replace=False)] = rng.integers(257, min(G, 600), 12)
+        rowptr, grp, cnt, lut = _ragged_problem(rng, E, G, sizes, lens)
+    hashes = []
+    for host in (True, False):
+        if host:
+            monkeypatch.setenv("MSWEEP_HOST_PACK", "1")
+        else:
+            monkeypatch.delenv("MSWEEP_HOST_PACK")
+        with Core(0) as core:
+            core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
+            hashes.append(core.layout_hash())
+            if not host:  # and the packed likelihood still is the likelihood
+                E = len(rowptr) - 1
+                logc = np.log(rng.integers(1, 20, E).astype(float))
+                res = core.solve(logc, np.ones(G))
+                lutidx = (grp * lut.shape[1] + cnt).astype(np.uint32)
+                ref = oracle.rcg_optl_csr(rowptr, grp, lutidx, lut, np.log(0.01), G, logc, np.ones(G))
+                assert_theta(res["theta"], ref["theta"])
+    assert hashes[0] == hashes[1]
+
+
 def test_properties_at_scale(gpu_core):
     """Size-independent properties on a problem too large for the dense oracle: sum theta = 1,
     sum N = sum alpha + sum c, EC-splitting invariance, group-permutation equivariance, bound
