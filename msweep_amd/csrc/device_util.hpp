@@ -5,18 +5,42 @@
 namespace msw {
 
 // ---------------------------------------------------------------------------------------
-// wave / block reductions (wave64; xor butterflies: every lane ends with the same value,
-// the order of additions is fixed -> bitwise reproducible)
+// wave / block reductions (wave64).  The cross-lane steps are DPP moves (row_shr 1/2/4/8 inside a
+// row of 16 lanes, row_bcast:15 / row_bcast:31 across rows -- gfx9-family controls) feeding an
+// ordinary fp64 operation: no LDS round trip per step as with ds_bpermute-based shuffles.  Lane 63
+// ends with the result of a fixed tree and is broadcast, so every lane returns the same value and
+// the order of the operations is fixed -> bitwise reproducible.
 // ---------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v, double fill) {
+  // lanes whose source is outside the row, or whose row is masked, receive `fill`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast_lane63(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-  return v;
+  v += dpp_move<0x111, 0xf>(v, 0.0);  // row_shr:1
+  v += dpp_move<0x112, 0xf>(v, 0.0);  // row_shr:2
+  v += dpp_move<0x114, 0xf>(v, 0.0);  // row_shr:4
+  v += dpp_move<0x118, 0xf>(v, 0.0);  // row_shr:8  -> lane 15 of each row: the row's sum
+  v += dpp_move<0x142, 0xa>(v, 0.0);  // row_bcast:15 into rows 1, 3
+  v += dpp_move<0x143, 0xc>(v, 0.0);  // row_bcast:31 into rows 2, 3 -> lane 63: the total
+  return bcast_lane63(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, kWave));
-  return v;
+  const double ninf = -INFINITY;
+  v = fmax(v, dpp_move<0x111, 0xf>(v, ninf));
+  v = fmax(v, dpp_move<0x112, 0xf>(v, ninf));
+  v = fmax(v, dpp_move<0x114, 0xf>(v, ninf));
+  v = fmax(v, dpp_move<0x118, 0xf>(v, ninf));
+  v = fmax(v, dpp_move<0x142, 0xa>(v, ninf));
+  v = fmax(v, dpp_move<0x143, 0xc>(v, ninf));
+  return bcast_lane63(v);
 }
 // sh: >= 16 doubles of LDS scratch.  Result valid in every thread.
 __device__ __forceinline__ double block_sum(double v, double *sh) {
