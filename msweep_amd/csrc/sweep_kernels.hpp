@@ -21,19 +21,12 @@
 namespace msw {
 
 constexpr int kRegCells = 16;  // cells per EC a wave keeps in registers (longer slices stream)
-// record buffers per wave (SliceStream): measured on MI355X, two are as fast as three -- the
-// stream already runs at the achievable HBM rate -- and leave registers for pass B's x - p0
-#ifndef MSW_DEPTH_A
-#define MSW_DEPTH_A 2
-#endif
-#ifndef MSW_DEPTH_B
-#define MSW_DEPTH_B 2
-#endif
+// tuning knobs (defaults measured on MI355X; tools/ab_build.py builds variants)
 #ifndef MSW_REVERSE_B
 #define MSW_REVERSE_B true
 #endif
 #ifndef MSW_B_KEEPN
-#define MSW_B_KEEPN (MSW_DEPTH_B == 2 ? 6 : 0)
+#define MSW_B_KEEPN 6
 #endif
 #ifndef MSW_PASSA_BATCH
 #define MSW_PASSA_BATCH 4
@@ -59,12 +52,8 @@ struct SliceBuf {
   uint32_t c8;  // byte image of the EC's multiplicity (sell.hpp)
 };
 
-// Issue the loads of one slice into registers: ALWAYS kRegCells loads.  Rows past the slice's
-// length re-read (part of) its first row (an L1 hit, value unused), so that the number of vector loads per
-// slice is a compile-time constant: the compiler's waitcnt analysis is path-insensitive, and only
-// with a fixed count can it (and the manual counted wait below) tell that an older slice has
-// landed while newer ones are still in flight.
-template <bool WIDE, bool FIXED>
+// Issue the loads of one slice (<= kRegCells cells per EC, even count) into registers.
+template <bool WIDE>
 __device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uint32_t len,
                                            typename Rec<WIDE>::T (&r)[kRegCells]) {
 #pragma unroll
@@ -72,29 +61,24 @@ __device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uin
     if ((uint32_t)k < len) {
       r[k] = Rec<WIDE>::load(rec, base + (size_t)k * 64);
       r[k + 1] = Rec<WIDE>::load(rec, base + (size_t)(k + 1) * 64);
-    } else if (FIXED) {
-      // distinct addresses inside the first row (+ the allocation's spare row): identical loads
-      // would be merged into one load + register copies, which have to wait for the data
-      r[k] = Rec<WIDE>::load(rec, base + 1 + k);
-      r[k + 1] = Rec<WIDE>::load(rec, base + 2 + k);
     }
   }
 }
 
-// s_waitcnt vmcnt(N) with the gfx9 field layout (vmcnt = imm[3:0] | imm[15:14] << 4).  Vector
-// loads return in order: "at most N outstanding" = everything but the N most recent has landed.
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
-}
+// s_waitcnt vmcnt(0), leaving the other counters alone (gfx9 layout: vmcnt = imm[3:0] | imm[15:14] << 4)
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
-// The record stream of one wavefront: its slices s_first, s_first + nw, ... go through THREE
-// register buffers, so the records of two slices are in flight while a third is processed (the
-// sweeps run at one workgroup per CU: bytes in flight per CU, not arithmetic, bound a
-// double-buffered version).  The slice geometry (slice_off pairs) of 64 slices at a time is
-// fetched with one gather per lane and parked in LDS: no dependent global load sits between two
-// slices.  EXTRA = vector loads per slice that `issue` adds besides the records.
-template <bool WIDE, int EXTRA, int DEPTH, bool REVERSE>
+// The record stream of one wavefront: its slices s_first, s_first + nw, ... go through two
+// register buffers in ping-pong -- while one slice is processed the records of the next are in
+// flight; the explicit vmcnt(0) sits BEFORE the next buffer's loads are issued, so it only waits
+// for the buffer about to be consumed.  The slice geometry (slice_off pairs) of 64 slices at a time
+// is fetched with one gather per lane and parked in LDS: no dependent global load sits between two
+// slices (a register copy handed out with v_readlane would make the compiler's waitcnt analysis
+// drain ALL vector loads at every use).  A third buffer (two slices in flight) was built and
+// measured: no faster -- the stream already runs at the achievable HBM rate -- and it needs a fixed
+// number of loads per slice plus dummy fetches to keep the compiler's path-insensitive vmcnt
+// accounting exact.
+template <bool WIDE, bool REVERSE>
 struct SliceStream {
   const SellDev &S;
   uint32_t s_first, nw, n_mine, lane;
@@ -114,10 +98,9 @@ struct SliceStream {
     return s_first + (REVERSE ? (i < n_mine ? n_mine - 1 - i : i) : i) * nw;
   }
   // geometry of the wave's slices [64 * chunk, 64 * chunk + 64): one gather per lane, parked in LDS
-  // (a register copy would make every later use wait for ALL outstanding vector loads)
   __device__ __forceinline__ void gather_offs(uint32_t chunk) {
     const uint32_t i = chunk * 64 + lane;
-    pend = make_uint2(0, 0);  // past the wave's last slice: the dummy geometry
+    pend = make_uint2(0, 0);  // past the wave's last slice: an empty slice
     if (i < n_mine) {
       const uint32_t sl = slice_at(i);
       pend = make_uint2(S.slice_off[sl], S.slice_off[sl + 1]);
@@ -128,10 +111,9 @@ struct SliceStream {
     typedef __attribute__((address_space(3))) v2u_t lds_u2_t;
     v2u_t v = {pend.x, pend.y}, z = {0u, 0u};
     *(lds_u2_t *)(size_t)(geo + lane * 8) = v;
-    if (lane < 2) *(lds_u2_t *)(size_t)(geo + (64 + lane) * 8) = z;  // dummies
+    if (lane < 2) *(lds_u2_t *)(size_t)(geo + (64 + lane) * 8) = z;  // read by the look-ahead fetch
   }
-  static constexpr int kLoads = kRegCells + EXTRA;  // vector loads per fetched slice
-  // j = position inside the current 64-slice chunk; j >= n_chunk fetches the dummy geometry
+  // j = position inside the current 64-slice chunk; j >= n_chunk fetches an empty slice
   template <class Issue>
   __device__ __forceinline__ void fetch(uint32_t base, uint32_t j, SliceBuf<WIDE> &b, Issue &issue) {
     typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
@@ -140,58 +122,32 @@ struct SliceStream {
     b.sl = slice_at(base + j);
     b.o = uniform(oe.x);
     b.len = uniform(oe.y) - b.o;
-    load_slice<WIDE, DEPTH == 3>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r);
+    if (b.len <= (uint32_t)kRegCells) load_slice<WIDE>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r);
     issue(b);
   }
-  // Every step does exactly one fetch (past the last slice a dummy one: geometry {0, 0}, sixteen
-  // L1 hits) so that the stream has ONE static shape -- fetch, fetch, [wait, fetch, process]* --
-  // in which the counted wait provably covers the buffer about to be processed; anything
-  // conditional between two fetches (even a rarely taken reload of the geometry) makes the
-  // compiler fall back to vmcnt(0).  The geometry is therefore renewed between 64-slice chunks,
-  // with the stream drained.
+  // issue(buf): further loads of a slice; process(buf): its arithmetic; chunk_end(): every 64 slices
+  // (the geometry is renewed there, with the stream drained)
   template <class Issue, class Process, class ChunkEnd>
   __device__ __forceinline__ void run(Issue issue, Process process, ChunkEnd chunk_end) {
     for (uint32_t base = 0; base == 0 || base < n_mine; base += 64) {
       if (base) gather_offs(base >> 6);
       commit_offs();
       const uint32_t n_chunk = n_mine > base ? (n_mine - base < 64u ? n_mine - base : 64u) : 0u;
-      SliceBuf<WIDE> A = {}, B = {}, C = {};
+      SliceBuf<WIDE> A = {}, B = {};
       uint32_t j = 0;
-      if constexpr (DEPTH == 2) {  // two buffers, variable load count, full drains
-        fetch(base, 0, A, issue);
-        for (;;) {
-          if (j >= n_chunk) break;
-          wait_vm<0>();
-          fetch(base, j + 1, B, issue);
-          process(A);
-          if (++j >= n_chunk) break;
-          wait_vm<0>();
-          fetch(base, j + 1, A, issue);
-          process(B);
-          ++j;
-        }
-        wait_vm<0>();
-        chunk_end();
-        continue;
-      }
       fetch(base, 0, A, issue);
-      fetch(base, 1, B, issue);
       for (;;) {
         if (j >= n_chunk) break;
-        wait_vm<kLoads>();  // A has landed; B may still be in flight
-        fetch(base, j + 2, C, issue);
+        wait_vm0();  // A has landed
+        fetch(base, j + 1, B, issue);
         process(A);
         if (++j >= n_chunk) break;
-        wait_vm<kLoads>();
-        fetch(base, j + 2, A, issue);
+        wait_vm0();
+        fetch(base, j + 1, A, issue);
         process(B);
-        if (++j >= n_chunk) break;
-        wait_vm<kLoads>();
-        fetch(base, j + 2, B, issue);
-        process(C);
         ++j;
       }
-      wait_vm<0>();
+      wait_vm0();
       chunk_end();
     }
   }
@@ -251,7 +207,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   const uint32_t shift = S.shift, mask = S.mask, bhi2 = 2 * S.bhi;
   double *sh = reinterpret_cast<double *>(smem + pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true));
   // slice geometry of this wave: the gather is in flight while the LDS image is filled
-  SliceStream<WIDE, 0, MSW_DEPTH_A, false> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
+  SliceStream<WIDE, false> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
                               gridDim.x * (kPassThreads / 64), (uint32_t)lane,
                               (uint32_t)pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true) + 256u +
                                   uniform(tid >> 6) * kGeoStride);
@@ -372,7 +328,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
   constexpr bool GLDS = GMODE > 0;
   const uint32_t acc_off = pass_acc_off(GMODE, G);
   double *sh = reinterpret_cast<double *>(smem + pass_scratch_off(GMODE, TLDS, G, n_lut, false));
-  SliceStream<WIDE, 1, MSW_DEPTH_B, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
+  SliceStream<WIDE, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
                               gridDim.x * (kPassThreads / 64), (uint32_t)lane,
                               (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 256u +
                                   uniform(tid >> 6) * kGeoStride);
@@ -416,7 +372,6 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
   auto issue = [&](SliceBuf<WIDE> &sb) {
-    // always one load (clamped index): the stream counts on a fixed number of loads per slice
     const uint32_t q = sb.sl * 64 + lane;
     const uint32_t cj = S.c8[S.n_long + (q < n_sell ? q : 0u)];
     sb.c8 = q < n_sell ? cj : 0u;

@@ -4,7 +4,7 @@ hooks to the sweeps, and build library variants build_ab/lib_<name>.so that tool
 one GPU job through MSWEEP_CORE_LIB.  MSW_EXP: 1 near-conflict-free LDS addresses, 2 no cell arithmetic
 in pass A, 3 record stream only, 4 no column-sum atomics, 5 no log / division, 6 no log.  The hooks are
 text patches against sweep_kernels.hpp and need refreshing when the patched lines change.
-usage: ab_build.py [--nopatch] name "-DMSW_EXP=3 -DMSW_DEPTH_A=3" [name flags]..."""
+usage: ab_build.py [--nopatch] name "-DMSW_EXP=3 " [name flags]..."""
 import os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 X = os.path.join(R, "build_ab", "exp")
