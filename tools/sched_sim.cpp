@@ -50,7 +50,7 @@ int main(int argc, char **argv) {
     for (auto &v : ecs) { v.push_back(src(rng)); while ((int)v.size() < len0) { uint32_t g = rng() % G; if (std::find(v.begin(), v.end(), g) == v.end()) v.push_back(g); } }
     std::vector<int> order(NEC);
     for (int i = 0; i < NEC; ++i) order[i] = i;
-    if (mode >= 1) {
+    if (mode == 1 || mode == 7) {
       // greedy: K open 8-EC blocks; each EC goes where it adds the least overflow above ceil(len0/2)
       struct Blk { int n = 0; int cnt[16] = {0}; std::vector<int> ids; };
       std::vector<Blk> open(K); std::vector<int> out;
@@ -86,6 +86,87 @@ int main(int argc, char **argv) {
       std::vector<std::vector<uint32_t>> sched(len, std::vector<uint32_t>(64));
       std::vector<std::vector<char>> taken(64);
       for (int l = 0; l < 64; ++l) taken[l].assign(cells[l].size(), 0);
+      if (mode == 6 || mode == 7) {
+        // proper edge colouring (alternating paths) of lanes x residues per contiguous 16-lane group
+        std::vector<int> step_of[64];
+        for (int l = 0; l < 64; ++l) step_of[l].assign(cells[l].size(), -1);
+        for (int C = 0; C < 4; ++C) {
+          const int NC = 64;
+          struct Edge { int u, v, c; };
+          std::vector<Edge> ed;
+          for (int l = C * 16; l < C * 16 + 16; ++l) for (size_t c = 0; c < cells[l].size(); ++c) ed.push_back({l - C * 16, (int)(cells[l][c] & 15), -1});
+          std::vector<std::vector<int>> atU(16, std::vector<int>(NC, -1)), atV(16, std::vector<int>(NC, -1));
+          for (int e = 0; e < (int)ed.size(); ++e) {
+            int u = ed[e].u, v = ed[e].v;
+            int a = 0; while (atU[u][a] >= 0) ++a;
+            int b = 0; while (atV[v][b] >= 0) ++b;
+            if (a != b) {
+              std::vector<int> path; int side = 1, node = v, col = a;
+              while (true) {
+                int e2 = side ? atV[node][col] : atU[node][col];
+                if (e2 < 0) break;
+                path.push_back(e2);
+                node = side ? ed[e2].u : ed[e2].v; side ^= 1; col = (col == a) ? b : a;
+              }
+              for (int e2 : path) { atU[ed[e2].u][ed[e2].c] = -1; atV[ed[e2].v][ed[e2].c] = -1; }
+              for (int e2 : path) { ed[e2].c = (ed[e2].c == a) ? b : a; }
+              for (int e2 : path) { atU[ed[e2].u][ed[e2].c] = e2; atV[ed[e2].v][ed[e2].c] = e2; }
+            }
+            ed[e].c = a; atU[u][a] = e; atV[v][a] = e;
+          }
+          int idx = 0;
+          for (int l = C * 16; l < C * 16 + 16; ++l) {
+            std::vector<char> used(len, 0);
+            size_t base = idx;
+            for (size_t c = 0; c < cells[l].size(); ++c) { int col = ed[base + c].c; if (col < len) used[col] = 1; }
+            for (size_t c = 0; c < cells[l].size(); ++c) {
+              int col = ed[base + c].c;
+              if (col >= len) { col = 0; while (used[col]) ++col; used[col] = 1; }
+              step_of[l][c] = col;
+            }
+            idx += (int)cells[l].size();
+          }
+        }
+        for (int k = 0; k < len; ++k) for (int l = 0; l < 64; ++l) sched[k][l] = G + l;
+        for (int l = 0; l < 64; ++l) for (size_t c = 0; c < cells[l].size(); ++c) sched[step_of[l][c]][l] = cells[l][c];
+        eval(sched, cost);
+        continue;
+      }
+      if (mode == 5) {
+        // residue-major: per step and 16-lane contiguous group, residues by decreasing remaining degree
+        // each take the lane with the most unplaced cells that still has a cell of that residue
+        for (int k = 0; k < len; ++k) {
+          int pickc[64]; for (int l = 0; l < 64; ++l) pickc[l] = -1;
+          for (int C = 0; C < 4; ++C) {
+            int deg[16] = {0};
+            for (int l = C * 16; l < C * 16 + 16; ++l) for (size_t c = 0; c < cells[l].size(); ++c) if (!taken[l][c]) ++deg[cells[l][c] & 15];
+            int ord[16]; for (int r = 0; r < 16; ++r) ord[r] = r;
+            std::stable_sort(ord, ord + 16, [&](int a, int b) { return deg[a] > deg[b]; });
+            for (int oi = 0; oi < 16; ++oi) {
+              const int r = ord[oi]; if (!deg[r]) break;
+              int bl = -1, bc = -1, brem = -1;
+              for (int l = C * 16; l < C * 16 + 16; ++l) if (pickc[l] < 0) {
+                int rem = 0; int cc = -1;
+                for (size_t c = 0; c < cells[l].size(); ++c) if (!taken[l][c]) { ++rem; if ((int)(cells[l][c] & 15) == r && cc < 0) cc = (int)c; }
+                if (cc >= 0 && rem > brem) { brem = rem; bl = l; bc = cc; }
+              }
+              if (bl >= 0) pickc[bl] = bc;
+            }
+            // lanes without a pick that cannot wait (remaining cells == remaining steps) take anything
+            for (int l = C * 16; l < C * 16 + 16; ++l) if (pickc[l] < 0) {
+              int rem = 0, first = -1;
+              for (size_t c = 0; c < cells[l].size(); ++c) if (!taken[l][c]) { ++rem; if (first < 0) first = (int)c; }
+              if (rem >= len - k && first >= 0) pickc[l] = first;
+            }
+          }
+          for (int l = 0; l < 64; ++l) {
+            if (pickc[l] >= 0) { taken[l][pickc[l]] = 1; sched[k][l] = cells[l][pickc[l]]; }
+            else sched[k][l] = G + l;
+          }
+        }
+        eval(sched, cost);
+        continue;
+      }
       for (int k = 0; k < len; ++k) {
         uint32_t rg[4][16], hg[2][32]; uint16_t at[4] = {0,0,0,0};
         memset(rg, 0xff, sizeof rg); memset(hg, 0xff, sizeof hg);
