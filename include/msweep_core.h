@@ -164,6 +164,29 @@ int msw_core_set_comm(msw_handle h, msw_comm_t comm);
 /* last error text of the msw_comm_* calls of this thread */
 const char *msw_comm_last_error(void);
 
+/* ---- pseudoalignment input (host code, no GPU) -------------------------
+ * Replaces mSWEEP::Alignment::read + collapse (include/mSWEEP_alignment.hpp:97-215) for Themisto
+ * plaintext files ("read_id target target ..." per line; one file per strand): reads -> sets of
+ * targets, strands merged by intersection / union (--themisto-mode, :123-133), unaligned reads
+ * dropped, reads keyed by the reference's 64-bit hash of their target set (:152-156) and collapsed
+ * into equivalence classes in ascending hash order.  The export is what msw_core_build_likelihood
+ * takes: ec_tptr[n_ecs + 1], ec_targets[n_hits] (ascending target ids of each EC's first read),
+ * ec_counts[n_ecs] (Alignment::reads_in_ec, :220), plus ec_rptr[n_ecs + 1] / ec_reads[n_aligned]
+ * (Alignment::reads_assigned_to_ec, :229: the read ids of every EC, ascending).  n_reads is the line
+ * count of the last strand (Alignment::n_reads, :219).  Any output pointer may be NULL.
+ * The compact alignment-writer format is not supported (BitMagic): convert to plaintext. */
+typedef struct msw_alignment *msw_alignment_t;
+#define MSW_MERGE_INTERSECTION 0
+#define MSW_MERGE_UNION 1
+int msw_alignment_read(const char *const *paths, size_t n_paths, size_t n_targets, int merge_mode,
+                       msw_alignment_t *out);
+int msw_alignment_shape(msw_alignment_t a, size_t *n_ecs, size_t *n_reads, size_t *n_hits, size_t *n_aligned);
+int msw_alignment_export(msw_alignment_t a, uint64_t *ec_tptr, uint32_t *ec_targets, uint64_t *ec_counts,
+                         uint64_t *ec_rptr, uint32_t *ec_reads);
+void msw_alignment_destroy(msw_alignment_t a);
+/* error text of the last failed msw_alignment_read of this thread (the reference's messages) */
+const char *msw_alignment_last_error(void);
+
 /* ---- measurement hooks (used by bench.py; no effect on results) ---------------------- */
 /* Device time (ms, HIP events on the solve stream) and launch counts of the dominant
  * kernels during the last solve: pass A (gradient norm sweep) and pass B (softmax /

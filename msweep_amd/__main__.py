@@ -106,11 +106,7 @@ def main(argv=None):
             if not files:
                 raise RuntimeError("no pseudoalignment files given")
             aln = Alignment(len(grouping.group_indicators))
-            streams = [open(p) for p in files]
-            aln.read(a.themisto_mode, streams)
-            for s in streams:
-                s.close()
-            aln.collapse()
+            aln.read_files(a.themisto_mode, files)   # native reader + collapse (msw_alignment_read)
     except (RuntimeError, OSError) as ex:
         sys.stderr.write(f"Reading the pseudoalignments failed:\n  {ex}\nexiting\n")
         return 1

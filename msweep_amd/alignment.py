@@ -68,7 +68,24 @@ class Alignment:
             self.n_queries = n          # the last strand's line count, as the reference (:119)
         self._reads = merge_strands(parsed, merge_mode) if len(parsed) > 1 else parsed[0]
 
+    def read_files(self, merge_mode, paths):
+        """Fast path for files on disk: the library's native reader + collapse (msw_alignment_read);
+        leaves the object in the collapsed state.  The pure-Python read()/collapse() pair stays as the
+        stream-based implementation and as the cross-check of the native one (tests)."""
+        from .core import MswError, read_alignment
+        try:
+            r = read_alignment(paths, self.n_targets, merge_mode)
+        except MswError as ex:
+            raise RuntimeError(str(ex)) from None
+        self.n_queries = r["n_reads"]
+        self.ec_tptr, self.ec_targets, self.ec_counts = r["ec_tptr"], r["ec_targets"], r["ec_counts"]
+        rp = r["ec_rptr"].astype(np.int64)
+        self.ec_read_ids = [r["ec_reads"][rp[i]:rp[i + 1]].tolist() for i in range(len(rp) - 1)]
+        self._reads = None
+
     def collapse(self):
+        if self._reads is None:   # read_files() already collapsed
+            return
         by_hash = {}
         for rid in sorted(self._reads):
             t = self._reads[rid]

@@ -20,7 +20,8 @@ PREC_DOUBLE, PREC_FLOAT = 0, 1
 EXPORTS = [
     "msw_core_create", "msw_core_destroy", "msw_last_error", "msw_core_version",
     "msw_core_set_dense_logl", "msw_core_set_csr", "msw_core_build_likelihood",
-    "msw_core_get_dense_logl", "msw_core_layout_hash", "msw_core_shape", "msw_core_solve", "msw_core_prepare", "msw_core_run",
+    "msw_core_get_dense_logl", "msw_core_layout_hash", "msw_core_shape", "msw_alignment_read",
+    "msw_alignment_shape", "msw_alignment_export", "msw_alignment_destroy", "msw_alignment_last_error", "msw_core_solve", "msw_core_prepare", "msw_core_run",
     "msw_core_gamma",
     "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
@@ -83,8 +84,38 @@ def load_library():
     L.msw_comm_destroy.restype = None
     L.msw_core_set_comm.argtypes = [vp, vp]
     L.msw_comm_last_error.restype = C.c_char_p
+    L.msw_alignment_read.argtypes = [C.POINTER(C.c_char_p), sz, sz, C.c_int, C.POINTER(vp)]
+    L.msw_alignment_shape.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    L.msw_alignment_export.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.msw_alignment_destroy.argtypes = [vp]
+    L.msw_alignment_destroy.restype = None
+    L.msw_alignment_last_error.restype = C.c_char_p
     _lib = L
     return L
+
+
+def read_alignment(paths, n_targets, merge_mode="intersection"):
+    """Native Themisto plaintext reader + EC collapse (msw_alignment_*, host code of the library):
+    dict(ec_tptr, ec_targets, ec_counts, ec_rptr, ec_reads, n_reads).  Errors carry the reference's
+    messages (include/mSWEEP_alignment.hpp:84-91, :131)."""
+    L = load_library()
+    if merge_mode not in ("intersection", "union"):
+        raise MswError(f"Unrecognized option `{merge_mode}` for --themisto-mode")
+    arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    h = C.c_void_p()
+    if L.msw_alignment_read(arr, len(paths), int(n_targets), 0 if merge_mode == "intersection" else 1, C.byref(h)):
+        raise MswError(L.msw_alignment_last_error().decode())
+    try:
+        ne, nr, nh, na = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        L.msw_alignment_shape(h, C.byref(ne), C.byref(nr), C.byref(nh), C.byref(na))
+        out = dict(ec_tptr=np.zeros(ne.value + 1, np.uint64), ec_targets=np.zeros(nh.value, np.uint32),
+                   ec_counts=np.zeros(ne.value, np.uint64), ec_rptr=np.zeros(ne.value + 1, np.uint64),
+                   ec_reads=np.zeros(na.value, np.uint32), n_reads=int(nr.value))
+        L.msw_alignment_export(h, _ptr(out["ec_tptr"]), _ptr(out["ec_targets"]), _ptr(out["ec_counts"]),
+                               _ptr(out["ec_rptr"]), _ptr(out["ec_reads"]))
+        return out
+    finally:
+        L.msw_alignment_destroy(h)
 
 
 def _ptr(a):

@@ -559,6 +559,7 @@ void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, dou
 #include "host_em.inc"
 #include "host_bootstrap.inc"
 #include "host_build.inc"
+#include "host_alignment.inc"
 
 // =========================================================================================
 // C ABI

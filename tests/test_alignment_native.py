@@ -1,0 +1,93 @@
+"""Native Themisto reader + EC collapse (msw_alignment_*, host code of libmsweep_core.so) against the
+pure-Python mirror of mSWEEP::Alignment (msweep_amd/alignment.py, include/mSWEEP_alignment.hpp:54-215)
+on random single- and paired-end inputs, and the reference's error messages.  No GPU needed."""
+import io
+
+import numpy as np
+import pytest
+
+from msweep_amd.alignment import Alignment, ec_hash
+from msweep_amd.core import MswError, read_alignment
+
+
+def _write_strand(path, rng, n_reads, n_targets, p_unaligned=0.2, shuffle=True, dup_lines=True):
+    lines = []
+    for r in range(n_reads):
+        if rng.random() < p_unaligned:
+            lines.append(f"{r}")
+            continue
+        k = int(rng.integers(1, 7))
+        t = rng.choice(n_targets, k, replace=False)
+        lines.append(f"{r} " + " ".join(str(int(x)) for x in t))
+    if dup_lines:  # the same read id on a second line: the sets are united (bits OR-ed, :60-66)
+        for r in rng.choice(n_reads, max(1, n_reads // 20), replace=False):
+            lines.append(f"{int(r)} {int(rng.integers(0, n_targets))}")
+    if shuffle:
+        rng.shuffle(lines)
+    path.write_text("\n".join(lines) + "\n")
+    return len(lines)
+
+
+def _python_alignment(paths, n_targets, mode):
+    a = Alignment(n_targets)
+    streams = [open(p) for p in paths]
+    a.read(mode, streams)
+    for s in streams:
+        s.close()
+    # the reference only visits read ids below the last strand's line count (:148)
+    a._reads = {r: t for r, t in a._reads.items() if r < a.n_queries}
+    a.collapse()
+    return a
+
+
+@pytest.mark.parametrize("mode,n_strands", [("intersection", 1), ("intersection", 2), ("union", 2)])
+def test_native_reader_matches_python_mirror(tmp_path, mode, n_strands):
+    rng = np.random.default_rng(7 + n_strands + len(mode))
+    n_targets, n_reads = 37, 600
+    paths = []
+    for s in range(n_strands):
+        p = tmp_path / f"strand_{s}.txt"
+        _write_strand(p, rng, n_reads, n_targets, dup_lines=(s == 0))
+        paths.append(str(p))
+    ref = _python_alignment(paths, n_targets, mode)
+    got = read_alignment(paths, n_targets, mode)
+    assert got["n_reads"] == ref.n_queries
+    np.testing.assert_array_equal(got["ec_counts"], ref.ec_counts)
+    np.testing.assert_array_equal(got["ec_tptr"], ref.ec_tptr)
+    np.testing.assert_array_equal(got["ec_targets"], ref.ec_targets)
+    rp = got["ec_rptr"].astype(int)
+    assert [got["ec_reads"][rp[i]:rp[i + 1]].tolist() for i in range(len(rp) - 1)] == ref.ec_read_ids
+    # ECs in ascending order of the reference's hash (std::map, :186)
+    tp = got["ec_tptr"].astype(int)
+    hashes = [ec_hash(got["ec_targets"][tp[i]:tp[i + 1]].tolist()) for i in range(len(tp) - 1)]
+    assert hashes == sorted(hashes) and len(set(hashes)) == len(hashes)
+    # Alignment.read_files() is the same thing behind the mirror's interface
+    a = Alignment(n_targets)
+    a.read_files(mode, paths)
+    a.collapse()
+    assert a.n_reads() == ref.n_reads() and a.n_ecs() == ref.n_ecs()
+    np.testing.assert_array_equal(a.ec_targets, ref.ec_targets)
+
+
+def test_native_reader_errors(tmp_path):
+    good = tmp_path / "good.txt"
+    good.write_text("0 1 2\n1 3\n")
+    bad = tmp_path / "bad.txt"
+    bad.write_text("0 1 2\n1 x3\n")
+    with pytest.raises(MswError, match="File format not supported on line 2 with content: 1 x3"):
+        read_alignment([str(bad)], 10)
+    with pytest.raises(MswError, match="more target sequences than expected"):
+        read_alignment([str(good)], 3)
+    with pytest.raises(MswError, match="themisto-mode"):
+        read_alignment([str(good)], 10, "xor")
+    with pytest.raises(MswError, match="cannot open"):
+        read_alignment([str(tmp_path / "missing.txt")], 10)
+    compact = tmp_path / "compact.txt"
+    compact.write_text("10,4\n")
+    with pytest.raises(MswError, match="compact"):
+        read_alignment([str(compact)], 10)
+    # only unaligned reads: zero ECs, n_reads = number of lines
+    empty = tmp_path / "unaligned.txt"
+    empty.write_text("0\n1\n2\n")
+    r = read_alignment([str(empty)], 10)
+    assert r["n_reads"] == 3 and len(r["ec_counts"]) == 0 and r["ec_tptr"].tolist() == [0]
