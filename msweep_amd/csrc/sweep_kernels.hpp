@@ -442,9 +442,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
         // 1..3 -- nearly all ECs -- the logarithm is deferred: the mantissas are multiplied up per
         // lane and one log per 64 slices is taken of the product (flush_logs): ~8 operations per
         // EC instead of ~40, and if anything a smaller rounding error than the sum of logs.
-#ifndef MSW_NOSB
         __builtin_amdgcn_sched_barrier(0);
-#endif
         if (sb.c8 <= 3u) {
           int ez;
           const double m = frexp(Z, &ez);
