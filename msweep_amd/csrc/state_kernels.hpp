@@ -69,13 +69,10 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
                                               double *os_u, double *step_u, const double *lut,
                                               double *e, TabDev X) {
   __shared__ double sh[32];
-  const Scalars s0 = *sc;  // one read of the whole state: no dependent scalar round trips later
-  if (s0.done || s0.reset_pending) return;  // a pending re-evaluation skips pass A and the step
   const int tid = threadIdx.x, nt = blockDim.x;
-  const double a = s0.a, oldnorm = s0.oldnorm, bound = s0.bound, logzi = s0.logzi;
-  double os_a = s0.os_a;
-  const int didreset = s0.didreset;
   const bool inreg = G <= kStepRegs * nt;
+  // every load of the kernel is issued here, BEFORE the state decides whether the step runs at
+  // all: one memory round trip instead of two on the critical path between the sweeps
   double pn = 0.0;
   for (int i = tid; i < n_partA; i += nt) pn += partA[i];
   double wv[kStepRegs], ov[kStepRegs], uv[kStepRegs];
@@ -91,6 +88,11 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
     }
   }
   const double lt = tid < n_lut ? lut[tid] : 0.0;  // first table entry of this thread
+  const Scalars s0 = *sc;  // one read of the whole state: no dependent scalar round trips later
+  if (s0.done || s0.reset_pending) return;  // a pending re-evaluation skips pass A and the step
+  const double a = s0.a, oldnorm = s0.oldnorm, bound = s0.bound, logzi = s0.logzi;
+  double os_a = s0.os_a;
+  const int didreset = s0.didreset;
   const double newnorm = block_sum(pn, sh);
   const double beta = newnorm / oldnorm;
   double step_a = 1.0 - a;
@@ -209,10 +211,9 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
                                                 double2 *ew, double *partR, double *totS) {
   __shared__ double sh[48];
   __shared__ double accs[64][kRedfinGroups];
-  const Scalars s0 = *sc;
-  if (s0.done) return;
   const int tid = threadIdx.x, gl = tid & (kRedfinGroups - 1), rs = tid >> 4;
   const int g = blockIdx.x * kRedfinGroups + gl;
+  const Scalars s0 = *sc;  // in flight together with the partial rows below
   double s = 0.0;
   if (g < G) {
     if (nblk > 0) {
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
     t[1] += partS[4 * b + 1];
     t[2] += partS[4 * b + 2];
   }
+  if (s0.done) return;
   accs[rs][gl] = s;
   block_sum_n<3>(t, sh);  // its barriers also publish accs
   const double W = t[2];
@@ -302,25 +304,25 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
                                              const double *step_u, const double *lut, double *e,
                                              TabDev X, TraceDev tr) {
   __shared__ double sh[16 * kRedfinParts];
-  const Scalars s0 = *sc;  // one read of the whole state
-  if (s0.done) return;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int flavor = s0.flavor;
-  const int reeval = s0.reset_pending;
-  const double a = s0.a, oldbound = s0.oldbound;
-  const double beta = s0.beta, tol = s0.tol, csum = s0.csum, kappa = s0.kappa;
+  // all loads first, then the state decides (one round trip on the critical path, not two)
   double q[kRedfinParts] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int b = tid; b < npartR; b += nt)
     for (int i = 0; i < kRedfinParts; ++i) q[i] += partR[kRedfinParts * b + i];
   const double s_clogZ = totS[0], s_rH = totS[1];
-  // the accepted step becomes oldstep below: fetch it now, together with everything else
   const bool inreg = G <= kStepRegs * nt;
   double sv[kStepRegs];
-  if (inreg && !reeval && mode != 2) {
+  if (inreg) {  // the accepted step becomes oldstep below
 #pragma unroll
     for (int k = 0; k < kStepRegs; ++k)
       if (tid + k * nt < G) sv[k] = step_u[tid + k * nt];
   }
+  const Scalars s0 = *sc;  // one read of the whole state
+  if (s0.done) return;
+  const int flavor = s0.flavor;
+  const int reeval = s0.reset_pending;
+  const double a = s0.a, oldbound = s0.oldbound;
+  const double beta = s0.beta, tol = s0.tol, csum = s0.csum, kappa = s0.kappa;
   block_sum_n<kRedfinParts>(q, sh);  // one pair of barriers for the five sums
   const double lg = q[0], mu = q[1], S0 = q[2], S1 = q[3], S2 = q[4];
   if (mode == 2) {
