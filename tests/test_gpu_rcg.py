@@ -154,6 +154,13 @@ def test_edge_cases_csr(gpu_core, oracle):
     o2 = oracle.rcg_optl_csr(np.array([0, 2], np.uint64), [1, 3], (np.array([1, 3]) * lut.shape[1] + 1), lut, lz, 4,
                              np.log([10.0]), np.ones(4))
     np.testing.assert_allclose(r2["theta"], o2["theta"], rtol=1e-9)
+    # (e) no EC hits anything (nnz = 0): every row is background, the weights follow the prior
+    gpu_core.set_csr(np.zeros(4, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint32), lut, lz, 4)
+    r4 = gpu_core.solve(np.log([2.0, 3.0, 4.0]), alpha0)
+    o4 = oracle.rcg_optl_csr(np.zeros(4, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint32), lut, lz, 4,
+                             np.log([2.0, 3.0, 4.0]), alpha0)
+    assert r4["iters"] == o4["iters"]
+    np.testing.assert_allclose(r4["theta"], o4["theta"], rtol=1e-9)
     # (d) max_iters cap is honoured
     p = synth.make_csr_problem(5000, 40, seed=3, max_other=5)
     res3, _, _, _ = solve_csr(gpu_core, p, max_iters=3)
