@@ -91,3 +91,25 @@ def test_native_reader_errors(tmp_path):
     empty.write_text("0\n1\n2\n")
     r = read_alignment([str(empty)], 10)
     assert r["n_reads"] == 3 and len(r["ec_counts"]) == 0 and r["ec_tptr"].tolist() == [0]
+
+
+def test_native_reader_multithreaded_chunks(tmp_path):
+    """Files above 1 MB are parsed in per-thread chunks cut at line boundaries: same result as the
+    mirror, and the line number of a late format error is that of the whole file."""
+    rng = np.random.default_rng(99)
+    n_targets, n_reads = 5000, 150_000
+    p = tmp_path / "big.txt"
+    n_lines = _write_strand(p, rng, n_reads, n_targets, dup_lines=True)
+    assert p.stat().st_size > 2 * (1 << 20)   # at least three chunks
+    ref = _python_alignment([str(p)], n_targets, "intersection")
+    got = read_alignment([str(p)], n_targets)
+    assert got["n_reads"] == ref.n_queries == n_lines
+    np.testing.assert_array_equal(got["ec_counts"], ref.ec_counts)
+    np.testing.assert_array_equal(got["ec_tptr"], ref.ec_tptr)
+    np.testing.assert_array_equal(got["ec_targets"], ref.ec_targets)
+    lines = p.read_text().splitlines()
+    bad_line = len(lines) - 7
+    lines[bad_line - 1] = "12 34 x"
+    p.write_text("\n".join(lines) + "\n")
+    with pytest.raises(MswError, match=f"File format not supported on line {bad_line} with content: 12 34 x"):
+        read_alignment([str(p)], n_targets)
