@@ -92,6 +92,8 @@ int msw_core_shape(msw_handle h, size_t *n_groups, size_t *n_ecs, size_t *nnz);
  * (src/mSWEEP.cpp:419-423, 512-516):
  *   logc[E]   = log_times_observed (natural log of EC counts; -inf allowed,
  *               src/BootstrapSample.cpp:70)
+ *               NULL = the log counts msw_core_build_likelihood left on the device (no 8 * E
+ *               byte upload per solve; an error for likelihoods that were uploaded instead)
  *   alpha0[G] = prior_counts (src/mSWEEP.cpp:391-398)
  *   tol, max_iters = --tol / --max-iters (src/mSWEEP.cpp:123-125)
  * theta_out[G] receives mixture_components(gamma, logc).  iters_out / bound_out optional. */

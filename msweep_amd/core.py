@@ -221,10 +221,11 @@ class Core:
 
     # ---- solve --------------------------------------------------------------------------
     def solve(self, logc, alpha0, tol=1e-6, max_iters=5000, algo=ALGO_RCG, prec=PREC_DOUBLE):
+        """logc=None: the log counts build_likelihood() left on the device (no upload per solve)."""
         G, E, _ = self.shape()
-        logc = _arr(logc, np.float64)
+        logc = None if logc is None else _arr(logc, np.float64)
         alpha0 = _arr(alpha0, np.float64)
-        if len(logc) != E or len(alpha0) != G:
+        if (logc is not None and len(logc) != E) or len(alpha0) != G:
             raise MswError(f"solve: expected logc[{E}] and alpha0[{G}], got {len(logc)} and {len(alpha0)}")
         theta = np.empty(G)
         it, b = C.c_size_t(), C.c_double()

@@ -61,6 +61,8 @@ struct msw_core {
   // ---- solve state ---------------------------------------------------------------------
   DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc;
   DevBuf<uint8_t> c8;  // byte image of cvec (sell.hpp)
+  DevBuf<double> logc_res;  // log counts left on the device by msw_core_build_likelihood
+  bool have_logc_res = false;
   DevBuf<double2> ew, tabA, tabB;  // group table of pass A; per-slot tables of both sweeps (TabDev)
   TabDev tabs() const { return TabDev{tabA.p, tabB.p}; }
   DevBuf<double> partA, partS, partAcc, partC, partR, totS;
@@ -413,8 +415,14 @@ void prepare_inputs(msw_core *h, const double *logc_host, const uint32_t *counts
     hipLaunchKernelGGL(k_cvec_from_counts, dim3(kCvecBlocks), dim3(256), 0, h->stream, counts_dev,
                        h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->c8.p, h->partC.p);
   } else {
-    MSW_HIP(hipMemcpyAsync(h->logc_d.p, logc_host, E * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_cvec_from_logc, dim3(kCvecBlocks), dim3(256), 0, h->stream, h->logc_d.p,
+    const double *src = h->logc_d.p;
+    if (logc_host) {
+      MSW_HIP(hipMemcpyAsync(h->logc_d.p, logc_host, E * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    } else {  // the log counts msw_core_build_likelihood left on the device: no 8 * E byte upload
+      if (!h->have_logc_res) throw Fail("null logc: only a likelihood built by msw_core_build_likelihood keeps its log counts");
+      src = h->logc_res.p;
+    }
+    hipLaunchKernelGGL(k_cvec_from_logc, dim3(kCvecBlocks), dim3(256), 0, h->stream, src,
                        h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->c8.p, h->partC.p);
   }
   if (alpha0_host)
@@ -652,7 +660,7 @@ int msw_core_gamma(msw_handle h, double *gamma_out, size_t ld) {
 int msw_core_solve(msw_handle h, const double *logc, const double *alpha0, double tol, size_t max_iters,
                    int algo, int prec, double *theta_out, size_t *iters_out, double *bound_out) {
   return guarded(h, [&] {
-    if (!logc || !alpha0) throw Fail("msw_core_solve: null logc / alpha0");
+    if (!alpha0) throw Fail("msw_core_solve: null alpha0");
     prepare_inputs(h, logc, nullptr, alpha0);
     run_impl(h, tol, max_iters, algo, prec, theta_out, iters_out, bound_out);
   });
@@ -660,7 +668,7 @@ int msw_core_solve(msw_handle h, const double *logc, const double *alpha0, doubl
 
 int msw_core_prepare(msw_handle h, const double *logc, const double *alpha0) {
   return guarded(h, [&] {
-    if (!logc || !alpha0) throw Fail("msw_core_prepare: null logc / alpha0");
+    if (!alpha0) throw Fail("msw_core_prepare: null alpha0");
     prepare_inputs(h, logc, nullptr, alpha0);
   });
 }

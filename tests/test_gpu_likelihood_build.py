@@ -28,10 +28,16 @@ def test_build_matches_oracle_dense_matrix(gpu_core, oracle, R, G, seed, mo):
     np.testing.assert_array_equal(lik.log_counts(), np.log(p["ec_counts"].astype(float)))
     # same abundances as the pre-counted upload path
     r1 = gpu_core.solve(lik.log_counts(), np.ones(G))
+    # logc = NULL: the log counts the build left on the device (no upload per solve)
+    r0 = gpu_core.solve(None, np.ones(G))
+    assert r0["iters"] == r1["iters"]
+    np.testing.assert_allclose(r0["theta"], r1["theta"], rtol=1e-12)
     from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
     r2 = gpu_core.solve(lik.log_counts(), np.ones(G))
     assert r1["iters"] == r2["iters"]
     assert_theta(r1["theta"], r2["theta"])
+    with pytest.raises(MswError, match="null logc"):   # an uploaded likelihood keeps no counts
+        gpu_core.solve(None, np.ones(G))
 
 
 def test_build_long_ecs_and_other_parameters(gpu_core, oracle):
