@@ -147,7 +147,8 @@ def main(argv=None):
     total = int(ec_counts.sum())
     sample = BootstrapSample(n_reads, total, a.iters) if a.iters > 0 else PlainSample(n_reads, total)
     try:
-        res = core.solve(lik.log_counts(), prior, a.tol, a.max_iters, algo, prec)
+        # a likelihood built on the device keeps its log counts there: nothing to upload per solve
+        res = core.solve(None if not a.read_likelihood else lik.log_counts(), prior, a.tol, a.max_iters, algo, prec)
         if a.verbose:
             t = core.trace(min(res["iters"], 4096))
             for k in range(0, t["n"], 5):
