@@ -146,3 +146,41 @@ def test_cli_likelihood_roundtrip_probs_and_rate(tmp_path, oracle, capsys):
     assert probs[0] == ["ec_id"] + grouping.get_names() and len(probs) == aln.n_ecs() + 1
     P = np.array([[float(x) for x in r[1:]] for r in probs[1:]])
     np.testing.assert_allclose(P.sum(1), 1.0, rtol=1e-4)
+
+
+@pytest.fixture(scope="module")
+def mini_binary(tmp_path_factory):
+    """msweep_amd/cpp/msweep_mini.cpp: the estimation path of mSWEEP's main() as a native program."""
+    import subprocess
+    from conftest import ROOT
+    out = str(tmp_path_factory.mktemp("mini") / "msweep_mini")
+    lib = os.path.join(ROOT, "msweep_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", out, os.path.join(lib, "cpp", "msweep_mini.cpp"),
+                           "-L" + lib, "-lmsweep_core", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    return out
+
+
+@pytest.mark.parametrize("extra", [[], ["--min-hits", "400"], ["--iters", "3", "--seed", "42"],
+                                   ["--algorithm", "emgpu", "--themisto-mode", "union"]])
+def test_native_driver_matches_python_cli(tmp_path, mini_binary, extra):
+    """Same flags, same abundances file, byte for byte (bootstrap included: the device stream is seeded)."""
+    import subprocess
+    _toy(tmp_path)
+    common = ["--themisto-1", str(tmp_path / "toy_1.txt"), "--themisto-2", str(tmp_path / "toy_2.txt"),
+              "-i", str(tmp_path / "clustering.txt")] + extra
+    assert main(common + ["-o", str(tmp_path / "py")]) == 0
+    p = subprocess.run([mini_binary] + common + ["-o", str(tmp_path / "cc")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert (tmp_path / "cc_abundances.txt").read_text() == (tmp_path / "py_abundances.txt").read_text()
+
+
+def test_native_driver_errors(tmp_path, mini_binary):
+    import subprocess
+    _toy(tmp_path)
+    (tmp_path / "bad.txt").write_text("0 1 2\n1 x\n")
+    p = subprocess.run([mini_binary, "--themisto", str(tmp_path / "bad.txt"), "-i", str(tmp_path / "clustering.txt")],
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "Reading the pseudoalignments failed" in p.stderr and "line 2" in p.stderr
+    p = subprocess.run([mini_binary, "--themisto-1", str(tmp_path / "toy_1.txt"), "-i", str(tmp_path / "clustering.txt"),
+                        "--alphas", "1,2"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "--alphas must have the same number of values" in p.stderr
