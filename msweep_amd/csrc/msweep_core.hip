@@ -67,7 +67,7 @@ struct msw_core {
   TabDev tabs() const { return TabDev{tabA.p, tabB.p}; }
   DevBuf<double> partA, partS, partAcc, partC, partR, totS;
   // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
-  size_t lds_attr[2][12] = {};  // dynamic-LDS limit already granted per sweep instantiation
+  size_t lds_attr[2][16] = {};  // dynamic-LDS limit already granted per sweep instantiation
   msw_comm *comm = nullptr;
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
   DevBuf<Scalars> sc;
@@ -180,6 +180,8 @@ void choose_lds_mode(msw_core *h) {
       if (o[0] && 8ull * (h->G + kSentinels) <= kAccFixed &&
           pass_lds_bytes(2, o[1], h->G, h->n_area, false) <= kLdsMax)
         h->gmodeB = 2;
+      // too many groups for {e, w} / e + sums in LDS: the column sums alone may still fit (mode 3)
+      if (!o[0] && pass_lds_bytes(3, o[1], h->G, h->n_area, false) <= kLdsMax) h->gmodeB = 3;
       return;
     }
   }
@@ -269,7 +271,7 @@ template <bool W, int GM, bool TL>
 void launch_passB_t(msw_core *h) {
   const size_t lds = pass_lds_bytes(GM, TL, h->G, h->n_area, false);
   auto k = k_passB<W, GM, TL>;
-  prepare_sweep(k, lds, h->lds_attr[1][(W ? 6 : 0) + 2 * GM + (TL ? 1 : 0)]);
+  prepare_sweep(k, lds, h->lds_attr[1][(W ? 8 : 0) + 2 * GM + (TL ? 1 : 0)]);
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
                      h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p);
 }
@@ -290,7 +292,7 @@ void launch_passB_t(msw_core *h) {
   } while (0)
 #define MSW_DISPATCH_B(fn, ...)                                                      \
   do {                                                                               \
-    const int key = (h->wide ? 6 : 0) + 2 * h->gmodeB + (h->tlds ? 1 : 0);           \
+    const int key = (h->wide ? 8 : 0) + 2 * h->gmodeB + (h->tlds ? 1 : 0);           \
     switch (key) {                                                                   \
       case 0: fn<false, 0, false>(__VA_ARGS__); break;                               \
       case 1: fn<false, 0, true>(__VA_ARGS__); break;                                \
@@ -298,12 +300,16 @@ void launch_passB_t(msw_core *h) {
       case 3: fn<false, 1, true>(__VA_ARGS__); break;                                \
       case 4: fn<false, 2, false>(__VA_ARGS__); break;                               \
       case 5: fn<false, 2, true>(__VA_ARGS__); break;                                \
-      case 6: fn<true, 0, false>(__VA_ARGS__); break;                                \
-      case 7: fn<true, 0, true>(__VA_ARGS__); break;                                 \
-      case 8: fn<true, 1, false>(__VA_ARGS__); break;                                \
-      case 9: fn<true, 1, true>(__VA_ARGS__); break;                                 \
-      case 10: fn<true, 2, false>(__VA_ARGS__); break;                               \
-      default: fn<true, 2, true>(__VA_ARGS__); break;                                \
+      case 6: fn<false, 3, false>(__VA_ARGS__); break;                               \
+      case 7: fn<false, 3, true>(__VA_ARGS__); break;                                \
+      case 8: fn<true, 0, false>(__VA_ARGS__); break;                                \
+      case 9: fn<true, 0, true>(__VA_ARGS__); break;                                 \
+      case 10: fn<true, 1, false>(__VA_ARGS__); break;                               \
+      case 11: fn<true, 1, true>(__VA_ARGS__); break;                                \
+      case 12: fn<true, 2, false>(__VA_ARGS__); break;                               \
+      case 13: fn<true, 2, true>(__VA_ARGS__); break;                                \
+      case 14: fn<true, 3, false>(__VA_ARGS__); break;                               \
+      default: fn<true, 3, true>(__VA_ARGS__); break;                                \
     }                                                                                \
   } while (0)
 
@@ -362,7 +368,7 @@ void launch_passB(msw_core *h) {
     MSW_HIP(hipEventRecord(ev->first, h->stream));
   }
   if (h->flavor == 0) {
-    if (!h->glds) MSW_HIP(hipMemsetAsync(h->Acc.p, 0, ((size_t)h->G + kSentinels) * sizeof(double), h->stream));
+    if (h->gmodeB == 0) MSW_HIP(hipMemsetAsync(h->Acc.p, 0, ((size_t)h->G + kSentinels) * sizeof(double), h->stream));
     MSW_DISPATCH_B(launch_passB_t, h);
   } else {
     MSW_DISPATCH_NREG(launch_dense_B, launch_dense_big_B, h);
@@ -371,7 +377,7 @@ void launch_passB(msw_core *h) {
   if (ev) MSW_HIP(hipEventRecord(ev->second, h->stream));
   h->timing.passB_launches++;
   // column sums across workgroups + N_g / lgamma / digamma, spread over G/16 workgroups
-  const bool partials = (h->flavor == 1) || h->glds;
+  const bool partials = (h->flavor == 1) || h->gmodeB > 0;
   const int nb = h->npart_rows();
   if (h->comm) {
     // EC-sharded: local column sums + ELBO terms -> one all-reduce -> k_redfin on the totals

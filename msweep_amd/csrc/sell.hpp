@@ -94,7 +94,8 @@ __device__ __forceinline__ void for_each_cell(const SellDev &S, uint32_t p, F f)
 // LDS image of the sweeps (byte offsets; bhi = sell_bhi()):
 //   [0, 16 * n_area)                    slot area: 16-byte per-slot entries of the pass (tlds)
 //   pass A: [2 * bhi, 2 * bhi + 16 * Gp)  {e_g, wc_g}                         (glds)
-//   pass B: [bhi, bhi + 8 * Gp) e_g,  column sums pass_acc_off() bytes behind      (glds)
+//   pass B: [bhi, bhi + 8 * Gp) e_g,  column sums pass_acc_off() bytes behind      (glds);
+//           with too many groups for both (GMODE 3) the column sums alone, e_g gathered from memory
 //   then 32 doubles of reduction scratch and 8 KB of slice geometry.   Gp = G + kSentinels
 __host__ __device__ inline uint32_t sell_bhi(bool tlds, uint32_t n_area) {
   return tlds ? ((16u * n_area + 255u) & ~255u) : 0u;
@@ -103,12 +104,12 @@ constexpr uint32_t kGeoStride = 66 * 8;  // bytes of slice geometry per wavefron
 constexpr uint32_t kAccFixed = 65528;  // largest 8-byte-aligned ds immediate offset
 // byte distance from e_g to the column sum of the same group in pass B's LDS image
 __host__ __device__ inline uint32_t pass_acc_off(int gmode, uint32_t G) {
-  return gmode == 2 ? kAccFixed : 8u * (G + kSentinels);
+  return gmode == 3 ? 0u : (gmode == 2 ? kAccFixed : 8u * (G + kSentinels));  // 3: the sums take e_g's place
 }
 __host__ __device__ inline size_t pass_scratch_off(int gmode, bool tlds, uint32_t G, uint32_t n_area,
                                                    bool passA) {
   const size_t bhi = sell_bhi(tlds, n_area), Gp = (size_t)G + kSentinels;
-  if (gmode == 0) return bhi;
+  if (gmode == 0 || (passA && gmode == 3)) return bhi;  // pass A of mode 3 gathers {e, w} from memory
   if (passA) return 2 * bhi + 16 * Gp;
   return bhi + pass_acc_off(gmode, G) + 8 * Gp;
 }

@@ -311,7 +311,9 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
 // per cell in the row sums; the x - p0 of an EC stay in registers between the row sum and the
 // scatter.
 // ---------------------------------------------------------------------------------------
-// GMODE: 0 = e_g / column sums in global memory; 1 = in LDS, column sums right behind e_g;
+// GMODE: 3 = column sums in LDS (where e_g would be), e_g gathered from memory: groups up to ~17 k
+// (global fp64 atomics, mode 0, cost 20 x more than everything else in the sweep);
+// 0 = e_g / column sums in global memory; 1 = in LDS, column sums right behind e_g;
 // 2 = in LDS, column sums at the fixed distance kAccFixed (an instruction immediate: one VALU
 // operation less per scattered cell; needs 8 * Gp <= kAccFixed).
 template <bool WIDE, int GMODE, bool TLDS>
@@ -325,7 +327,8 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t G = S.n_groups, n_lut = S.n_area, Gp = G + kSentinels;  // n_lut: entries of the slot area
   const uint32_t shift = S.shift, mask = S.mask, bhi = S.bhi;
-  constexpr bool GLDS = GMODE > 0;
+  constexpr bool GLDS = GMODE == 1 || GMODE == 2;  // e_g in LDS
+  constexpr bool ALDS = GMODE > 0;                  // column sums in LDS
   const uint32_t acc_off = pass_acc_off(GMODE, G);
   double *sh = reinterpret_cast<double *>(smem + pass_scratch_off(GMODE, TLDS, G, n_lut, false));
   SliceStream<WIDE, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
@@ -336,17 +339,17 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
     double2 *t = reinterpret_cast<double2 *>(smem);
     for (uint32_t i = tid; i < n_lut; i += kPassThreads) t[i] = tabB_g[S.area_slot[i]];
   }
-  if (GLDS) {
+  if (ALDS) {
     double *el = reinterpret_cast<double *>(smem + bhi), *al = reinterpret_cast<double *>(smem + bhi + acc_off);
     for (uint32_t g = tid; g < Gp; g += kPassThreads) {
-      el[g] = e_g[g];
+      if (GLDS) el[g] = e_g[g];
       al[g] = 0.0;
     }
   }
   const unsigned char *e_b = reinterpret_cast<const unsigned char *>(e_g) - bhi;
   unsigned char *acc_b = reinterpret_cast<unsigned char *>(accGlobal) - bhi;
   const unsigned char *xt_b = reinterpret_cast<const unsigned char *>(tabB_g);
-  auto E_ = [&](RT r) -> double { return tab8<(GMODE > 0)>(e_b, R::hi(r, shift)); };
+  auto E_ = [&](RT r) -> double { return tab8<GLDS>(e_b, R::hi(r, shift)); };
   auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
   auto XM_ = [&](RT r) -> double { return tab8<TLDS>(xt_b, R::lo(r, mask)); };
   auto addACC = [&](RT r, double v) {
@@ -355,6 +358,8 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
       __hip_atomic_fetch_add((lds_d_t *)(size_t)(off + kAccFixed), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if constexpr (GMODE == 1)
       __hip_atomic_fetch_add((lds_d_t *)(size_t)(off + acc_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if constexpr (GMODE == 3)
+      __hip_atomic_fetch_add((lds_d_t *)(size_t)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else
       atomicAdd(reinterpret_cast<double *>(acc_b + off), v);
   };
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
     partS[4 * blockIdx.x + 2] = s_W;
     partS[4 * blockIdx.x + 3] = 0.0;
   }
-  if (GLDS) {
+  if (ALDS) {
     __syncthreads();
     const double *al = reinterpret_cast<const double *>(smem + bhi + acc_off);
     double *dst = partAcc + (size_t)blockIdx.x * G;

@@ -303,6 +303,19 @@ def test_device_packer_matches_host_packer(oracle, monkeypatch, case):
     assert hashes[0] == hashes[1]
 
 
+@pytest.mark.parametrize("G", [12000, 19500])
+def test_many_groups_modes(gpu_core, oracle, G):
+    """More groups than the LDS images of the sweeps hold: {e, w} / e_g gathered from memory, the
+    column sums still in LDS up to ~17 k groups (pass B mode 3), global atomics beyond (mode 0)."""
+    p = synth.make_csr_problem(30000, G, seed=17, max_other=8)
+    res, tr, logc, alpha0 = solve_csr(gpu_core, p)
+    lut = precalc_lls(p["group_sizes"])
+    ref = oracle.rcg_optl_csr(p["rowptr"], p["grp"], lutidx_of(p, lut), lut, np.log(0.01), G, logc, alpha0, trace=20)
+    lockstep(tr, ref["trace"], 20)
+    assert res["iters"] == ref["iters"]
+    assert_theta(res["theta"], ref["theta"])
+
+
 def test_properties_at_scale(gpu_core):
     """Size-independent properties on a problem too large for the dense oracle: sum theta = 1,
     sum N = sum alpha + sum c, EC-splitting invariance, group-permutation equivariance, bound
