@@ -67,7 +67,7 @@ struct msw_core {
   TabDev tabs() const { return TabDev{tabA.p, tabB.p}; }
   DevBuf<double> partA, partS, partAcc, partC, partR, totS;
   // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
-  size_t lds_attr[2][16] = {};  // dynamic-LDS limit already granted per sweep instantiation
+  size_t lds_attr[2][20] = {};  // dynamic-LDS limit already granted per sweep instantiation
   msw_comm *comm = nullptr;
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
   DevBuf<Scalars> sc;
@@ -181,7 +181,10 @@ void choose_lds_mode(msw_core *h) {
           pass_lds_bytes(2, o[1], h->G, h->n_area, false) <= kLdsMax)
         h->gmodeB = 2;
       // too many groups for {e, w} / e + sums in LDS: the column sums alone may still fit (mode 3)
+      if (!o[0] && getenv("MSWEEP_GLOBAL_ATOMICS")) return;  // developer switch: mode 0 (column sums in HBM)
       if (!o[0] && pass_lds_bytes(3, o[1], h->G, h->n_area, false) <= kLdsMax) h->gmodeB = 3;
+      // ... and beyond that one range of groups at a time does (mode 4), whatever the group count
+      else if (!o[0] && pass_lds_bytes(4, o[1], h->G, h->n_area, false) <= kLdsMax) h->gmodeB = 4;
       return;
     }
   }
@@ -271,9 +274,16 @@ template <bool W, int GM, bool TL>
 void launch_passB_t(msw_core *h) {
   const size_t lds = pass_lds_bytes(GM, TL, h->G, h->n_area, false);
   auto k = k_passB<W, GM, TL>;
-  prepare_sweep(k, lds, h->lds_attr[1][(W ? 8 : 0) + 2 * GM + (TL ? 1 : 0)]);
+  prepare_sweep(k, lds, h->lds_attr[1][(W ? 10 : 0) + 2 * GM + (TL ? 1 : 0)]);
+  if (GM == 4) {  // one run per range of groups; the first also delivers the ELBO terms
+    for (uint32_t g0 = 0; g0 < h->G; g0 += kRangeGroups)
+      hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
+                         h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p,
+                         RangeB{g0, std::min<uint32_t>(kRangeGroups, h->G - g0), g0 == 0 ? 1 : 0});
+    return;
+  }
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
-                     h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p);
+                     h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p, RangeB{0, 0, 1});
 }
 
 #define MSW_DISPATCH3(fn, ...)                                                       \
@@ -292,7 +302,7 @@ void launch_passB_t(msw_core *h) {
   } while (0)
 #define MSW_DISPATCH_B(fn, ...)                                                      \
   do {                                                                               \
-    const int key = (h->wide ? 8 : 0) + 2 * h->gmodeB + (h->tlds ? 1 : 0);           \
+    const int key = (h->wide ? 10 : 0) + 2 * h->gmodeB + (h->tlds ? 1 : 0);          \
     switch (key) {                                                                   \
       case 0: fn<false, 0, false>(__VA_ARGS__); break;                               \
       case 1: fn<false, 0, true>(__VA_ARGS__); break;                                \
@@ -302,14 +312,18 @@ void launch_passB_t(msw_core *h) {
       case 5: fn<false, 2, true>(__VA_ARGS__); break;                                \
       case 6: fn<false, 3, false>(__VA_ARGS__); break;                               \
       case 7: fn<false, 3, true>(__VA_ARGS__); break;                                \
-      case 8: fn<true, 0, false>(__VA_ARGS__); break;                                \
-      case 9: fn<true, 0, true>(__VA_ARGS__); break;                                 \
-      case 10: fn<true, 1, false>(__VA_ARGS__); break;                               \
-      case 11: fn<true, 1, true>(__VA_ARGS__); break;                                \
-      case 12: fn<true, 2, false>(__VA_ARGS__); break;                               \
-      case 13: fn<true, 2, true>(__VA_ARGS__); break;                                \
-      case 14: fn<true, 3, false>(__VA_ARGS__); break;                               \
-      default: fn<true, 3, true>(__VA_ARGS__); break;                                \
+      case 8: fn<false, 4, false>(__VA_ARGS__); break;                               \
+      case 9: fn<false, 4, true>(__VA_ARGS__); break;                                \
+      case 10: fn<true, 0, false>(__VA_ARGS__); break;                               \
+      case 11: fn<true, 0, true>(__VA_ARGS__); break;                                \
+      case 12: fn<true, 1, false>(__VA_ARGS__); break;                               \
+      case 13: fn<true, 1, true>(__VA_ARGS__); break;                                \
+      case 14: fn<true, 2, false>(__VA_ARGS__); break;                               \
+      case 15: fn<true, 2, true>(__VA_ARGS__); break;                                \
+      case 16: fn<true, 3, false>(__VA_ARGS__); break;                               \
+      case 17: fn<true, 3, true>(__VA_ARGS__); break;                                \
+      case 18: fn<true, 4, false>(__VA_ARGS__); break;                               \
+      default: fn<true, 4, true>(__VA_ARGS__); break;                                \
     }                                                                                \
   } while (0)
 

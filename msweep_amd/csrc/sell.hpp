@@ -104,13 +104,21 @@ constexpr uint32_t kGeoStride = 66 * 8;  // bytes of slice geometry per wavefron
 constexpr uint32_t kAccFixed = 65528;  // largest 8-byte-aligned ds immediate offset
 // byte distance from e_g to the column sum of the same group in pass B's LDS image
 __host__ __device__ inline uint32_t pass_acc_off(int gmode, uint32_t G) {
-  return gmode == 3 ? 0u : (gmode == 2 ? kAccFixed : 8u * (G + kSentinels));  // 3: the sums take e_g's place
+  return gmode >= 3 ? 0u : (gmode == 2 ? kAccFixed : 8u * (G + kSentinels));  // 3, 4: the sums take e_g's place
 }
+// pass B mode 4 (any number of groups): the sweep is run once per range of kRangeGroups groups,
+// each run accumulating only its range's column sums in LDS
+constexpr uint32_t kRangeGroups = 16384;
+struct RangeB {
+  uint32_t g0, n;  // groups [g0, g0 + n) of this run
+  int first;       // the run that also delivers the per-EC ELBO terms
+};
 __host__ __device__ inline size_t pass_scratch_off(int gmode, bool tlds, uint32_t G, uint32_t n_area,
                                                    bool passA) {
   const size_t bhi = sell_bhi(tlds, n_area), Gp = (size_t)G + kSentinels;
-  if (gmode == 0 || (passA && gmode == 3)) return bhi;  // pass A of mode 3 gathers {e, w} from memory
+  if (gmode == 0 || (passA && gmode >= 3)) return bhi;  // pass A of modes 3, 4 gathers {e, w} from memory
   if (passA) return 2 * bhi + 16 * Gp;
+  if (gmode == 4) return bhi + 8 * (size_t)kRangeGroups;
   return bhi + pass_acc_off(gmode, G) + 8 * Gp;
 }
 __host__ __device__ inline size_t pass_lds_bytes(int gmode, bool tlds, uint32_t G, uint32_t n_area,

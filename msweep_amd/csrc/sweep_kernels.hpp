@@ -313,13 +313,14 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
 // ---------------------------------------------------------------------------------------
 // GMODE: 3 = column sums in LDS (where e_g would be), e_g gathered from memory: groups up to ~17 k
 // (global fp64 atomics, mode 0, cost 20 x more than everything else in the sweep);
+// 4 = as 3 for any number of groups: one run of the sweep per range of kRangeGroups groups (RangeB);
 // 0 = e_g / column sums in global memory; 1 = in LDS, column sums right behind e_g;
 // 2 = in LDS, column sums at the fixed distance kAccFixed (an instruction immediate: one VALU
 // operation less per scattered cell; needs 8 * Gp <= kAccFixed).
 template <bool WIDE, int GMODE, bool TLDS>
 __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
                                                        const double2 *tabB_g, double *partAcc,
-                                                       double *partS, double *accGlobal) {
+                                                       double *partS, double *accGlobal, RangeB rg) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
   using RT = typename R::T;
@@ -341,7 +342,8 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
   }
   if (ALDS) {
     double *el = reinterpret_cast<double *>(smem + bhi), *al = reinterpret_cast<double *>(smem + bhi + acc_off);
-    for (uint32_t g = tid; g < Gp; g += kPassThreads) {
+    const uint32_t n_acc = GMODE == 4 ? rg.n : Gp;
+    for (uint32_t g = tid; g < n_acc; g += kPassThreads) {
       if (GLDS) el[g] = e_g[g];
       al[g] = 0.0;
     }
@@ -360,6 +362,11 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
       __hip_atomic_fetch_add((lds_d_t *)(size_t)(off + acc_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if constexpr (GMODE == 3)
       __hip_atomic_fetch_add((lds_d_t *)(size_t)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if constexpr (GMODE == 4) {
+      const uint32_t d = off - bhi - 8u * rg.g0;  // unsigned: groups below the range wrap around
+      if (d < 8u * rg.n)
+        __hip_atomic_fetch_add((lds_d_t *)(size_t)(bhi + d), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     else
       atomicAdd(reinterpret_cast<double *>(acc_b + off), v);
   };
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
   s_clogZ = block_sum(s_clogZ, sh);
   s_rH = block_sum(s_rH, sh);
   s_W = block_sum(s_W, sh);
-  if (tid == 0) {
+  if (tid == 0 && (GMODE != 4 || rg.first)) {
     partS[4 * blockIdx.x + 0] = s_clogZ;
     partS[4 * blockIdx.x + 1] = s_rH;
     partS[4 * blockIdx.x + 2] = s_W;
@@ -525,7 +532,11 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
     __syncthreads();
     const double *al = reinterpret_cast<const double *>(smem + bhi + acc_off);
     double *dst = partAcc + (size_t)blockIdx.x * G;
-    for (uint32_t g = tid; g < G; g += kPassThreads) dst[g] = al[g];
+    if (GMODE == 4) {
+      for (uint32_t g = tid; g < rg.n; g += kPassThreads) dst[rg.g0 + g] = al[g];
+    } else {
+      for (uint32_t g = tid; g < G; g += kPassThreads) dst[g] = al[g];
+    }
   }
 }
 

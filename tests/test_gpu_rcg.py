@@ -303,10 +303,14 @@ def test_device_packer_matches_host_packer(oracle, monkeypatch, case):
     assert hashes[0] == hashes[1]
 
 
-@pytest.mark.parametrize("G", [12000, 19500])
-def test_many_groups_modes(gpu_core, oracle, G):
+@pytest.mark.parametrize("G,global_atomics", [(12000, False), (19500, False), (36000, False), (12000, True)])
+def test_many_groups_modes(gpu_core, oracle, monkeypatch, G, global_atomics):
     """More groups than the LDS images of the sweeps hold: {e, w} / e_g gathered from memory, the
-    column sums still in LDS up to ~17 k groups (pass B mode 3), global atomics beyond (mode 0)."""
+    column sums still in LDS -- all at once up to ~17 k groups (pass B mode 3), one range of 16 k
+    groups per run of the sweep beyond (mode 4: two and three runs here); MSWEEP_GLOBAL_ATOMICS=1
+    keeps the column sums in HBM (mode 0)."""
+    if global_atomics:
+        monkeypatch.setenv("MSWEEP_GLOBAL_ATOMICS", "1")
     p = synth.make_csr_problem(30000, G, seed=17, max_other=8)
     res, tr, logc, alpha0 = solve_csr(gpu_core, p)
     lut = precalc_lls(p["group_sizes"])
