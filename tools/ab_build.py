@@ -47,10 +47,10 @@ rep('''  const double xm = x - p0;
   c.t1 = fma(e, xD + wx, c.t1);
   c.t2 = fma(e, fma(xD, D, w * fma(2.0, xD, wx)), c.t2);
 #endif''')
-rep('''  auto E_ = [&](RT r) -> double { return tab8<(GMODE > 0)>(e_b, R::hi(r, shift)); };
+rep('''  auto E_ = [&](RT r) -> double { return tab8<GLDS>(e_b, R::hi(r, shift)); };
   auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
   auto XM_ = [&](RT r) -> double { return tab8<TLDS>(xt_b, R::lo(r, mask)); };''','''#if MSW_EXP == 1
-  auto E_ = [&](RT r) -> double { return tab8<(GMODE > 0)>(e_b, bhi + lane * 8 + (R::hi(r, shift) & 8)); };
+  auto E_ = [&](RT r) -> double { return tab8<GLDS>(e_b, bhi + lane * 8 + (R::hi(r, shift) & 8)); };
   auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, lane * 16 + (R::lo(r, mask) & 16)); };
   auto XM_ = [&](RT r) -> double { return tab8<TLDS>(xt_b, lane * 16 + (R::lo(r, mask) & 16)); };
 #elif MSW_EXP == 3
@@ -58,13 +58,11 @@ rep('''  auto E_ = [&](RT r) -> double { return tab8<(GMODE > 0)>(e_b, R::hi(r, 
   auto XT_ = [&](RT r) -> double2 { return make_double2((double)R::lo(r, mask), 1.0); };
   auto XM_ = [&](RT r) -> double { return (double)R::lo(r, mask); };
 #else
-  auto E_ = [&](RT r) -> double { return tab8<(GMODE > 0)>(e_b, R::hi(r, shift)); };
+  auto E_ = [&](RT r) -> double { return tab8<GLDS>(e_b, R::hi(r, shift)); };
   auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
   auto XM_ = [&](RT r) -> double { return tab8<TLDS>(xt_b, R::lo(r, mask)); };
 #endif
-  double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;''')
-rep('''  double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;
-  __syncthreads();''', '''  __syncthreads();''')
+  double exp_sink = 0.0;''')
 rep('''    const uint32_t off = R::hi(r, shift);
     if constexpr (GMODE == 2)''','''#if MSW_EXP == 1
     const uint32_t off = bhi + lane * 8 + (R::hi(r, shift) & 8);
@@ -72,10 +70,10 @@ rep('''    const uint32_t off = R::hi(r, shift);
     const uint32_t off = R::hi(r, shift);
 #endif
 #if MSW_EXP == 3
-    s_W += v + (double)off; return;
+    exp_sink += v + (double)off; return;
 #endif
 #if MSW_EXP == 4
-    s_W += v + (double)off; return;
+    exp_sink += v + (double)off; return;
 #endif
     if constexpr (GMODE == 2)''')
 
@@ -90,15 +88,11 @@ rep("""        const double rj = c / Z;
         s_rH += rj * H;
         s_W += rj;
         // padding records""")
-rep("""        s_clogZ += c * log(Z);
-      }
-    } else {""","""#if MSW_EXP == 5 || MSW_EXP == 6
-        s_clogZ += c * Z;
-#else
-        s_clogZ += c * log(Z);
+rep("""        if (sb.c8 <= 3u) {""","""#if MSW_EXP == 5 || MSW_EXP == 6
+        if (true) { s_clogZ += c * Z; } else
 #endif
-      }
-    } else {""")
+        if (sb.c8 <= 3u) {""")
+rep("""  s_clogZ = block_sum(s_clogZ, sh);""","""  s_clogZ = block_sum(s_clogZ + exp_sink * 1e-300, sh);""")
 open(p, "w").write(s)
 args = sys.argv[1:]
 for name, flags in zip(args[0::2], args[1::2]):
