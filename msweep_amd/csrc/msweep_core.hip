@@ -7,6 +7,7 @@
 #include "../../include/msweep_core.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -585,6 +586,7 @@ void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, dou
 #include "host_likelihood.inc"
 #include "host_pack.inc"
 #include "host_em.inc"
+#include "host_mtjump.inc"
 #include "host_bootstrap.inc"
 #include "host_build.inc"
 #include "host_alignment.inc"

@@ -36,6 +36,21 @@ def test_resample_counts_match_oracle_large(gpu_core, oracle):
     assert np.all(got.sum(1) == 300_000)
 
 
+def test_far_seek_jumps_ahead_like_stepping(gpu_core, monkeypatch):
+    """Rank r of a multi-GPU bootstrap starts r * (B / P) * draws words into the stream: beyond 2^27
+    words the seek is a GF(2) jump on the host; same counts as stepping there on the device."""
+    rng = np.random.default_rng(3)
+    w = rng.integers(1, 50, 5000).astype(np.uint32)
+    draws, first = 100_000, 1500            # 1.5e8 words in
+    jumped = gpu_core.resample_counts(w, 11, draws, first, first + 2)
+    jumped_on = gpu_core.resample_counts(w, 11, draws, first + 2, first + 3)   # short forward seek after a jump
+    monkeypatch.setenv("MSWEEP_MT_NOJUMP", "1")
+    stepped = gpu_core.resample_counts(w, 11, draws, first, first + 3)
+    np.testing.assert_array_equal(jumped, stepped[:2])
+    np.testing.assert_array_equal(jumped_on, stepped[2:])
+    assert np.all(stepped.sum(1) == draws)
+
+
 def test_bootstrap_driver_matches_replicate_by_replicate_oracle(gpu_core, oracle):
     p = synth.make_csr_problem(30000, 80, seed=14, max_other=6)
     G = 80
