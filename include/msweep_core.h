@@ -44,7 +44,12 @@ const char *msw_core_version(void);
 
 /* Dense G x E, rows = groups, element (g, j) at L[g*ld + j] -- the seamat layout read via
  * operator()(row, col) (include/Likelihood.hpp:182,265); needed for --read-likelihood
- * (include/Likelihood.hpp:224-253). */
+ * (include/Likelihood.hpp:224-253).
+ * A matrix of the shape fill_ll_mat writes (include/Likelihood.hpp:176-185: one background value,
+ * log(zi), in at least 3/4 of the cells and at most 65536 distinct values elsewhere) is re-expressed
+ * on the device as the CSR-of-ECs form below -- the same numbers, bit for bit
+ * (msw_core_get_dense_logl returns the input), any group count, solved by the sparse sweeps.
+ * Any other matrix is kept dense (n_groups <= 8192).  msw_core_shape's nnz tells which. */
 int msw_core_set_dense_logl(msw_handle h, const double *L, size_t n_groups, size_t n_ecs,
                             size_t ld);
 

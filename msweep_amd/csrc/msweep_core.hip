@@ -21,6 +21,7 @@
 
 #include "kernels.hpp"
 #include "pack_kernels.hpp"
+#include "compress_kernels.hpp"
 #include "comm.hpp"
 #include "likelihood_kernels.hpp"
 #include "bootstrap_kernels.hpp"
@@ -169,7 +170,9 @@ SellDev sell_view(msw_core *h) {
 
 void choose_lds_mode(msw_core *h) {
   const bool opts[4][2] = {{true, true}, {true, false}, {false, true}, {false, false}};
+  const char *force = getenv("MSWEEP_FORCE_LDS");  // developer switch: "gt", e.g. "10" = groups in LDS, slots not
   for (auto &o : opts) {
+    if (force && strlen(force) == 2 && (o[0] != (force[0] == '1') || o[1] != (force[1] == '1'))) continue;
     const int gm = o[0] ? 1 : 0;
     const size_t a = pass_lds_bytes(gm, o[1], h->G, h->n_area, true);
     const size_t b = pass_lds_bytes(gm, o[1], h->G, h->n_area, false);
@@ -589,6 +592,7 @@ void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, dou
 #include "host_mtjump.inc"
 #include "host_bootstrap.inc"
 #include "host_build.inc"
+#include "host_compress.inc"
 #include "host_alignment.inc"
 
 // =========================================================================================

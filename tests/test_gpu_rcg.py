@@ -37,6 +37,17 @@ def lockstep(tr, rt, k, rel=1e-9):
     np.testing.assert_allclose(tr["theta"][:k], rt["theta"][:k], rtol=rel, atol=1e-15)
 
 
+@pytest.fixture(params=["dense", "auto"])
+def dense_mode(request, monkeypatch):
+    """msw_core_set_dense_logl either keeps the matrix dense ("dense": MSWEEP_DENSE_COMPRESS=0) or may
+    re-express it as CSR-of-ECs + value table when it has background structure ("auto", the default)."""
+    if request.param == "dense":
+        monkeypatch.setenv("MSWEEP_DENSE_COMPRESS", "0")
+    else:
+        monkeypatch.delenv("MSWEEP_DENSE_COMPRESS", raising=False)
+    return request.param
+
+
 def solve_csr(core, p, alpha0=None, logc=None, trace=20, **kw):
     G = len(p["group_sizes"])
     alpha0 = np.ones(G) if alpha0 is None else alpha0
@@ -80,7 +91,7 @@ def test_csr_vs_dense_state_reference_shaped_oracle(gpu_core, oracle):
 
 
 @pytest.mark.parametrize("idx", range(7))
-def test_golden_fixture_dense_path(gpu_core, idx):
+def test_golden_fixture_dense_path(gpu_core, idx, dense_mode):
     """HIP dense-L path against the committed golden trajectories (tests/golden/rcg_golden.json)."""
     c = load_golden("rcg_golden.json")["cases"][idx]
     L = np.array(c["logl"])
@@ -100,10 +111,16 @@ def test_golden_fixture_dense_path(gpu_core, idx):
 
 
 @pytest.mark.parametrize("E,G,seed", [(2000, 40, 3), (20000, 500, 4), (3000, 1000, 5), (513, 65, 6)])
-def test_dense_path_vs_dense_state_oracle(gpu_core, oracle, E, G, seed):
+def test_dense_path_vs_dense_state_oracle(gpu_core, oracle, E, G, seed, dense_mode):
     p = synth.make_dense_problem(E, G, seed=seed)
     alpha0 = np.ones(G)
     from_dense(gpu_core, p["logl"], p["logc"])
+    # continuous listed values: re-expressed while the distinct values fit the slot tables (<= 65536)
+    compressed = gpu_core.shape()[2] < G * E
+    if dense_mode == "dense" or (E, G) == (20000, 500):
+        assert not compressed
+    elif (E, G) in ((3000, 1000), (513, 65)):
+        assert compressed
     gpu_core.set_trace_theta(20)
     res = gpu_core.solve(p["logc"], alpha0)
     tr = gpu_core.trace(20, with_theta=True)
@@ -116,7 +133,40 @@ def test_dense_path_vs_dense_state_oracle(gpu_core, oracle, E, G, seed):
     np.testing.assert_array_equal(gpu_core.get_dense_logl(), p["logl"])
 
 
-def test_dense_strided_input_and_gamma(gpu_core, oracle):
+@pytest.mark.parametrize("R,G,seed", [(40000, 200, 31), (150000, 9000, 32)])
+def test_reference_shaped_dense_matrix_takes_the_csr_sweeps(gpu_core, oracle, R, G, seed):
+    """The matrix LL_WOR21::fill_ll_mat hands to rcg_optl (include/Likelihood.hpp:176-185): log(zi)
+    background + lookup-table values.  msw_core_set_dense_logl re-expresses it on the device as
+    CSR-of-ECs + value table: same solve as the CSR boundary, exact expansion back, any group count."""
+    p = synth.make_csr_problem(R, G, seed=seed, max_other=6)
+    lut = precalc_lls(p["group_sizes"])
+    E = len(p["ec_counts"])
+    if G > 8192:                        # keep the dense copy small: the first ECs only
+        E = 3000
+        p = dict(p, rowptr=p["rowptr"][:E + 1], ec_counts=p["ec_counts"][:E])
+        p["grp"], p["cnt"] = p["grp"][:p["rowptr"][E]], p["cnt"][:p["rowptr"][E]]
+    L = dense_from_csr(p, lut)
+    logc = np.log(p["ec_counts"].astype(float))
+    alpha0 = np.ones(G)
+    from_dense(gpu_core, L, logc)
+    g_, e_, nnz = gpu_core.shape()
+    assert (g_, e_) == (G, E) and nnz == p["rowptr"][E]
+    gpu_core.set_trace_theta(20)
+    res = gpu_core.solve(logc, alpha0)
+    tr = gpu_core.trace(20, with_theta=True)
+    ref = oracle.rcg_optl_csr(p["rowptr"], p["grp"], lutidx_of(p, lut), lut, np.log(0.01), G, logc, alpha0, trace=20)
+    lockstep(tr, ref["trace"], 20)
+    assert res["iters"] == ref["iters"]
+    assert_theta(res["theta"], ref["theta"])
+    np.testing.assert_array_equal(gpu_core.get_dense_logl(), L)
+    # the CSR boundary fed with the same cells
+    res2, _, _, _ = solve_csr(gpu_core, p)
+    assert res2["iters"] == res["iters"]
+    if G <= 8192:
+        np.testing.assert_allclose(res2["theta"], res["theta"], rtol=1e-9, atol=1e-15)
+
+
+def test_dense_strided_input_and_gamma(gpu_core, oracle, dense_mode):
     p = synth.make_dense_problem(700, 33, seed=9)
     big = np.zeros((33, 1000))
     big[:, :700] = p["logl"]
@@ -381,7 +431,7 @@ def test_error_behaviour(gpu_core):
 
 
 @pytest.mark.parametrize("E,G,seed", [(1500, 1500, 7), (400, 5000, 8)])
-def test_dense_path_many_groups(gpu_core, oracle, E, G, seed):
+def test_dense_path_many_groups(gpu_core, oracle, E, G, seed, dense_mode):
     """1024 < G <= 8192: the two-sweep dense kernels (an EC no longer fits a wavefront's registers)."""
     p = synth.make_dense_problem(E, G, seed=seed)
     alpha0 = np.ones(G)
@@ -395,7 +445,7 @@ def test_dense_path_many_groups(gpu_core, oracle, E, G, seed):
     assert_theta(res["theta"], s["theta"])
     np.testing.assert_allclose(np.exp(gpu_core.gamma()), np.exp(s["gamma"]), atol=1e-6)
     with pytest.raises(MswError, match="n_groups <= 8192"):
-        gpu_core.set_dense_logl(np.zeros((8193, 2)))
+        gpu_core.set_dense_logl(np.random.default_rng(0).normal(size=(8193, 2)))   # no background structure
 
 
 def test_mid_length_ecs_streaming_path(gpu_core, oracle):
