@@ -79,6 +79,7 @@ struct Scalars {
   double logzi;
   int32_t didreset, reset_pending, done, iter;
   int32_t max_iters, fixed_iters, trace_theta, flavor;  // flavor: 0 csr, 1 dense
+  int32_t tab_ver, pad_;  // bumped whenever (a) changes the per-slot tables: k_tables (large slot areas) follows
 };
 
 }  // namespace msw

@@ -51,6 +51,9 @@ struct msw_core {
   uint32_t enc_shift = 0, enc_mask = 0, enc_bhi = 0;  // record encoding (sell.hpp)
   uint32_t n_area = 0;                                  // 16-byte entries of the slot area
   DevBuf<uint32_t> area_slot;
+  DevBuf<double> lut_area;  // lut[area_slot[i]]: what the per-slot tables are built from, in their order
+  DevBuf<int> tab_built;    // k_tables bookkeeping
+  int n_tab_inline() const { return flavor == 0 && n_area <= (uint32_t)kTabInline ? (int)n_area : 0; }
   double logzi = 0.0;
   DevBuf<uint32_t> rec, slice_off, long_ptr, rec_long, perm;
   DevBuf<double> lut, Lt;
@@ -230,8 +233,10 @@ void alloc_solve_state(msw_core *h) {
   h->cvec.alloc(E);
   h->c8.alloc((size_t)E + 64);
   h->logc_d.alloc(E);
-  h->tabA.alloc((size_t)std::max<uint32_t>(h->n_lut, 1));
-  h->tabB.alloc((size_t)std::max<uint32_t>(h->n_lut, 1));
+  h->tabA.alloc((size_t)std::max<uint32_t>(h->n_area, 1));
+  h->tabB.alloc((size_t)std::max<uint32_t>(h->n_area, 1));
+  h->tab_built.alloc(2);
+  if (h->flavor != 0) h->lut_area.alloc(1);
   const int nb = std::max(h->nblk, std::max(h->nblk_dense, h->npart_rows()));
   h->partA.alloc(std::max(nb, 1024));
   h->partS.alloc(4 * (size_t)std::max(nb, 1024));
@@ -416,11 +421,21 @@ void launch_passB(msw_core *h) {
 const double *fin_partS(msw_core *h) { return h->comm ? h->commB.p + h->G : h->partS.p; }
 int fin_npartS(msw_core *h) { return h->comm ? 1 : h->npart_rows(); }
 
+// slot areas beyond kTabInline entries: the tables are rebuilt by their own kernel after every
+// kernel that may have moved a (it returns at once when they are current)
+void launch_tables(msw_core *h) {
+  if (h->flavor != 0 || h->n_area <= (uint32_t)kTabInline) return;
+  const unsigned nb = std::min<unsigned>((h->n_area + 255) / 256, (unsigned)h->n_cu * 8);
+  hipLaunchKernelGGL(k_tables, dim3(nb), dim3(256), 0, h->stream, h->sc.p, (int)h->n_area, h->lut_area.p, h->tabs(),
+                     h->tab_built.p);
+}
+
 void launch_fin(msw_core *h, int mode) {
   TraceDev tr{h->tr_bound.p, h->tr_newnorm.p, h->tr_beta.p, h->tr_theta.p, h->tr_reset.p};
-  hipLaunchKernelGGL(k_fin, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G, (int)h->n_lut,
+  hipLaunchKernelGGL(k_fin, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G, h->n_tab_inline(),
                      (int)((h->G + kRedfinGroups - 1) / kRedfinGroups), h->totS.p, h->partR.p, h->Nc.p, h->u.p,
-                     h->os_u.p, h->step_u.p, h->lut.p, h->e.p, h->tabs(), tr);
+                     h->os_u.p, h->step_u.p, h->lut_area.p, h->e.p, h->tabs(), tr);
+  launch_tables(h);
 }
 
 void poll(msw_core *h) {
@@ -474,15 +489,16 @@ void begin_solve(msw_core *h, double tol, size_t max_iters) {
   }
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1024), 0, h->stream, h->sc.p, (int)G, ncpart,
                      cpart, h->alpha0.p, h->u.p, h->os_u.p, h->step_u.p, tol, (int)max_iters,
-                     h->fixed_iters ? 1 : 0, (int)h->trace_theta, h->flavor, h->logzi, kInitBound);
+                     h->fixed_iters ? 1 : 0, (int)h->trace_theta, h->flavor, h->logzi, kInitBound, h->tab_built.p);
   MSW_HIP(hipGetLastError());
 }
 
 void run_rcg(msw_core *h, size_t max_iters) {
-  const int G = (int)h->G, n_lut = (int)h->n_lut;
+  const int G = (int)h->G, n_lut = h->n_tab_inline();
   // initial update_N_k on gamma = log(1/G)
-  hipLaunchKernelGGL(k_prepB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->u.p, h->lut.p,
+  hipLaunchKernelGGL(k_prepB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->u.p, h->lut_area.p,
                      h->e.p, h->tabs());
+  launch_tables(h);
   launch_passB(h);
   h->timing.passB_launches--;  // the initial evaluation is not an iteration
   if (h->profiling && h->evB_used) h->evB_used--;
@@ -507,8 +523,9 @@ void run_rcg(msw_core *h, size_t max_iters) {
         npA = 1;
       }
       hipLaunchKernelGGL(k_step, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, npA,
-                         pA, h->w.p, h->u.p, h->os_u.p, h->step_u.p, h->lut.p, h->e.p,
+                         pA, h->w.p, h->u.p, h->os_u.p, h->step_u.p, h->lut_area.p, h->e.p,
                          h->tabs());
+      launch_tables(h);
       launch_passB(h);
       launch_fin(h, 0);
     }

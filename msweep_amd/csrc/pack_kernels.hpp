@@ -69,6 +69,11 @@ __global__ __launch_bounds__(256) void k_slot_hist(const uint32_t *idx, uint64_t
   }
 }
 
+__global__ __launch_bounds__(256) void k_gather_f64(const double *src, const uint32_t *at, uint32_t n, double *dst) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[at[i]];
+}
+
 // how a (group, slot, lane) becomes a record
 struct PackEnc {
   const uint32_t *canon;     // [n_lut] slot -> entry of the compact part of the slot area

@@ -44,6 +44,31 @@ __device__ inline void prepB_block(Scalars *sc, double a, int G, int n_lut, cons
     sc->M = M;
     sc->U = U;
     sc->p0 = p0;
+    sc->tab_ver = sc->tab_ver + 1;
+  }
+}
+
+// The per-slot tables for slot areas too large to be rebuilt by the single workgroup of k_step /
+// k_fin / k_prepB (those are then called with n_lut = 0 and this kernel follows them): any number
+// of workgroups, and nothing to do when the tables already belong to the current a (built[0] =
+// version they were built for, built[1] = workgroups that have finished).
+constexpr int kTabInline = 16384;
+__global__ __launch_bounds__(256) void k_tables(const Scalars *sc, int n_tab, const double *lut, TabDev X,
+                                               int *built) {
+  const int ver = sc->tab_ver;
+  if (built[0] != ver) {
+    const double a = sc->a, logzi = sc->logzi, oma = 1.0 - a;
+    const double p0 = exp(a * logzi);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_tab; i += gridDim.x * blockDim.x) {
+      const double T = lut[i], x = exp(a * T);
+      X.A[i] = make_double2(x, oma * (T - logzi));
+      X.B[i] = make_double2(x - p0, x * T - p0 * logzi);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&built[1], 1) == (int)gridDim.x - 1) {  // the last workgroup: all have read built[0]
+    built[1] = 0;
+    built[0] = ver;
   }
 }
 
@@ -177,6 +202,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
   }
   if (tid == 0) {
     sc->a = a_new;
+    sc->tab_ver = s0.tab_ver + 1;
     sc->os_a = os_a;
     sc->step_a = step_a;
     sc->oldnorm = newnorm;
@@ -500,7 +526,7 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
                                                     const double *alpha0, double *u, double *os_u,
                                                     double *step_u, double tol, int max_iters,
                                                     int fixed_iters, int trace_theta, int flavor,
-                                                    double logzi, double init_bound) {
+                                                    double logzi, double init_bound, int *tab_built) {
   __shared__ double sh[32];
   const int tid = threadIdx.x, nt = blockDim.x;
   double s = 0.0;
@@ -531,6 +557,8 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
     z.trace_theta = trace_theta;
     z.flavor = flavor;
     *sc = z;
+    tab_built[0] = -1;  // no tables yet
+    tab_built[1] = 0;
   }
 }
 

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
                                   uniform(tid >> 6) * kGeoStride);
   if (TLDS) {
     double2 *t = reinterpret_cast<double2 *>(smem);
-    for (uint32_t i = tid; i < n_lut; i += kPassThreads) t[i] = tabA_g[S.area_slot[i]];
+    for (uint32_t i = tid; i < n_lut; i += kPassThreads) t[i] = tabA_g[i];
   }
   if (GLDS) {
     double2 *t = reinterpret_cast<double2 *>(smem + bhi2);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
                                   uniform(tid >> 6) * kGeoStride);
   if (TLDS) {
     double2 *t = reinterpret_cast<double2 *>(smem);
-    for (uint32_t i = tid; i < n_lut; i += kPassThreads) t[i] = tabB_g[S.area_slot[i]];
+    for (uint32_t i = tid; i < n_lut; i += kPassThreads) t[i] = tabB_g[i];
   }
   if (ALDS) {
     double *el = reinterpret_cast<double *>(smem + bhi), *al = reinterpret_cast<double *>(smem + bhi + acc_off);

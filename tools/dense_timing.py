@@ -10,11 +10,18 @@ from msweep_amd.likelihood import from_dense
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 p = synth.make_dense_problem(E, G, seed=1)
-with Core(0) as core:
+for mode in ("0", "1"):
+  os.environ["MSWEEP_DENSE_COMPRESS"] = mode
+  with Core(0) as core:
+    t0 = time.time()
     from_dense(core, p["logl"], p["logc"])
+    print(f"MSWEEP_DENSE_COMPRESS={mode}: set_dense_logl {time.time() - t0:.3f} s, cells resident {core.shape()[2]}")
     core.set_fixed_iters(True)
     core.prepare(p["logc"], np.ones(G))
     core.run(max_iters=5)
+    t0 = time.time()
+    core.run(max_iters=50)
+    print(f"  {(time.time() - t0) / 50 * 1e3:.3f} ms/iter (wall)")
     core.set_profiling(True)
     core.run(max_iters=50)
     tm = core.last_timing()
