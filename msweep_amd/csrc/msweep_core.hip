@@ -286,12 +286,12 @@ void launch_passB_t(msw_core *h) {
   prepare_sweep(k, lds, h->lds_attr[1][(W ? 10 : 0) + 2 * GM + (TL ? 1 : 0)]);
   if (GM == 4) {  // one run per range of groups; the first also delivers the ELBO terms
     for (uint32_t g0 = 0; g0 < h->G; g0 += kRangeGroups)
-      hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
+      hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreadsB), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
                          h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p,
                          RangeB{g0, std::min<uint32_t>(kRangeGroups, h->G - g0), g0 == 0 ? 1 : 0});
     return;
   }
-  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
+  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreadsB), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
                      h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p, RangeB{0, 0, 1});
 }
 

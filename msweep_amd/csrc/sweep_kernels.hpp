@@ -26,7 +26,7 @@ constexpr int kRegCells = 16;  // cells per EC a wave keeps in registers (longer
 #define MSW_REVERSE_B true
 #endif
 #ifndef MSW_B_KEEPN
-#define MSW_B_KEEPN 6
+#define MSW_B_KEEPN 16
 #endif
 #ifndef MSW_PASSA_BATCH
 #define MSW_PASSA_BATCH 4
@@ -201,7 +201,9 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
   using RT = typename R::T;
-  if (sc->done || sc->reset_pending) return;  // a pending re-evaluation skips pass A
+  // a pending re-evaluation skips pass A; the test sits behind the LDS fill so that the fill's loads
+  // do not wait for this one (one memory round trip less at the head of every sweep)
+  const int skip = sc->done | sc->reset_pending;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t G = S.n_groups, n_lut = S.n_area, Gp = G + kSentinels;  // n_lut: entries of the slot area
   const uint32_t shift = S.shift, mask = S.mask, bhi2 = 2 * S.bhi;
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, b1 = p0 * uniform_d(sc->V1c), b2 = p0 * uniform_d(sc->V2c);
   double nn = 0.0;
+  if (skip) return;
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
@@ -318,13 +321,13 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
 // 2 = in LDS, column sums at the fixed distance kAccFixed (an instruction immediate: one VALU
 // operation less per scattered cell; needs 8 * Gp <= kAccFixed).
 template <bool WIDE, int GMODE, bool TLDS>
-__global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
+__global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
                                                        const double2 *tabB_g, double *partAcc,
                                                        double *partS, double *accGlobal, RangeB rg) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
   using RT = typename R::T;
-  if (sc->done) return;
+  const int skip = sc->done;  // tested behind the LDS fill (see pass A)
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t G = S.n_groups, n_lut = S.n_area, Gp = G + kSentinels;  // n_lut: entries of the slot area
   const uint32_t shift = S.shift, mask = S.mask, bhi = S.bhi;
@@ -332,18 +335,18 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
   constexpr bool ALDS = GMODE > 0;                  // column sums in LDS
   const uint32_t acc_off = pass_acc_off(GMODE, G);
   double *sh = reinterpret_cast<double *>(smem + pass_scratch_off(GMODE, TLDS, G, n_lut, false));
-  SliceStream<WIDE, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
-                              gridDim.x * (kPassThreads / 64), (uint32_t)lane,
+  SliceStream<WIDE, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (kPassThreadsB / 64) + (tid >> 6)),
+                              gridDim.x * (kPassThreadsB / 64), (uint32_t)lane,
                               (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 256u +
                                   uniform(tid >> 6) * kGeoStride);
   if (TLDS) {
     double2 *t = reinterpret_cast<double2 *>(smem);
-    for (uint32_t i = tid; i < n_lut; i += kPassThreads) t[i] = tabB_g[i];
+    for (uint32_t i = tid; i < n_lut; i += kPassThreadsB) t[i] = tabB_g[i];
   }
   if (ALDS) {
     double *el = reinterpret_cast<double *>(smem + bhi), *al = reinterpret_cast<double *>(smem + bhi + acc_off);
     const uint32_t n_acc = GMODE == 4 ? rg.n : Gp;
-    for (uint32_t g = tid; g < n_acc; g += kPassThreads) {
+    for (uint32_t g = tid; g < n_acc; g += kPassThreadsB) {
       if (GLDS) el[g] = e_g[g];
       al[g] = 0.0;
     }
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
     lp_mant = 1.0;
     lp_exp = 0;
   };
+  if (skip) return;
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
@@ -396,8 +400,9 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
     double zs = 0.0, hs = 0.0;
     if (len <= (uint32_t)kRegCells) {
       // row sums: straight-line code per slice length (wave-uniform, even).  x - p0 of the first
-      // cells stays in registers for the scatter, the rest is gathered a second time (all 16
-      // would push the kernel into scratch, and a scratch reload drains the record prefetch).
+      // KEEPN cells stays in registers for the scatter, any others are gathered a second time (with
+      // 16 wavefronts per workgroup all 16 would push the kernel into scratch, and a scratch reload
+      // drains the record prefetch: hence 12 wavefronts, common.hpp).
       constexpr int KEEPN = MSW_B_KEEPN;  // x - p0 of the first KEEPN cells stay in registers
       double xv[KEEPN > 0 ? KEEPN : 1];
       auto fixed = [&](auto LEN) {
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
   stream.run(issue, process, flush_logs);
   for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
     double zs = 0.0, hs = 0.0;
-    for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
+    for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreadsB) {
       const RT rc = R::load(S.rec_long, k);
       const double eg = E_(rc);
       const double2 t = XT_(rc);
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
         s_rH += rj * H;
         s_W += rj;
       }
-      for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
+      for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreadsB) {
         const RT rc = R::load(S.rec_long, k);
         addACC(rc, rj * XT_(rc).x);
       }
@@ -533,9 +538,9 @@ __global__ __launch_bounds__(kPassThreads) void k_passB(const Scalars *sc, SellD
     const double *al = reinterpret_cast<const double *>(smem + bhi + acc_off);
     double *dst = partAcc + (size_t)blockIdx.x * G;
     if (GMODE == 4) {
-      for (uint32_t g = tid; g < rg.n; g += kPassThreads) dst[rg.g0 + g] = al[g];
+      for (uint32_t g = tid; g < rg.n; g += kPassThreadsB) dst[rg.g0 + g] = al[g];
     } else {
-      for (uint32_t g = tid; g < G; g += kPassThreads) dst[g] = al[g];
+      for (uint32_t g = tid; g < G; g += kPassThreadsB) dst[g] = al[g];
     }
   }
 }
