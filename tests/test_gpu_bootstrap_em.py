@@ -113,3 +113,36 @@ def test_em_csr_matches_oracle_and_rcg_region(gpu_core, oracle):
     # --emprecision float is accepted (served in fp64)
     em32 = gpu_core.solve(lik.log_counts(), alpha0, tol=1e-8, max_iters=20000, algo=ALGO_EM, prec=1)
     np.testing.assert_allclose(em32["theta"], em["theta"], rtol=1e-9, atol=1e-15)
+
+
+def test_large_slot_area_em_and_bootstrap(gpu_core, oracle):
+    """A dense matrix with continuous listed values is re-expressed with one table slot per listed
+    cell: far more than 16384 slots, so the per-slot tables are rebuilt by k_tables (many workgroups)
+    instead of inside k_step / k_fin / k_em_fin.  EM, RCG and the bootstrap driver on that form."""
+    E, G = 12000, 300
+    p = synth.make_dense_problem(E, G, seed=23)
+    rng = np.random.default_rng(5)
+    w = rng.integers(1, 40, E).astype(np.uint32)
+    logc = np.log(w.astype(float))
+    alpha0 = np.ones(G)
+    from_dense(gpu_core, p["logl"], logc)
+    assert 16384 < gpu_core.shape()[2] < G * E // 4
+    em = gpu_core.solve(logc, alpha0, tol=1e-4, max_iters=5000, algo=ALGO_EM)
+    ref = oracle.em_dense(p["logl"], logc, alpha0, tol=1e-4, max_iters=5000)
+    assert abs(em["iters"] - ref["iters"]) <= max(2, ref["iters"] // 200)   # a flat tail: the stop is soft
+    np.testing.assert_allclose(em["theta"], ref["theta"], rtol=1e-5, atol=1e-8)
+    rcg = gpu_core.solve(logc, alpha0)
+    s = oracle.rcg_optl_dense_structured(p["logl"], logc, alpha0)
+    assert abs(rcg["iters"] - s["iters"]) <= 2
+    assert_theta(rcg["theta"], s["theta"])
+    # bootstrap replicates: each equals a solve on the oracle's resampled counts
+    draws = int(w.sum())
+    theta, iters = gpu_core.bootstrap(w, 7, draws, 0, 2, alpha0)
+    counts = oracle.bootstrap_counts(w, 7, draws, 2)
+    for b in range(2):
+        with np.errstate(divide="ignore"):
+            lc = np.log(counts[b].astype(float))
+        rb = oracle.rcg_optl_dense_structured(p["logl"], lc, alpha0)
+        assert abs(iters[b] - rb["iters"]) <= 2
+        assert_theta(theta[b], rb["theta"])
+
