@@ -235,50 +235,69 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   const uint32_t n_sell = S.n_ecs - S.n_long;
   auto issue = [&](SliceBuf<WIDE> &) {};
   auto process = [&](SliceBuf<WIDE> &sb) {
-    RT(&b)[kRegCells] = sb.r;
     const uint32_t len = sb.len;
     AccA c = {0.0, 0.0, 0.0};
-    if (len <= (uint32_t)kRegCells) {
-      // straight-line code per slice length (len is wave-uniform and even): all LDS gathers of
-      // a batch can be in flight together instead of one scalar-branched pair at a time
-      auto fixed = [&](auto LEN) {
-        constexpr int L = decltype(LEN)::value;
-        constexpr int B = MSW_PASSA_BATCH;  // cells gathered together (2 x ds_read_b128 each)
+    // straight-line code per cell count (wave-uniform and even): all LDS gathers of a batch can be
+    // in flight together instead of one scalar-branched pair at a time
+    auto fixed = [&](RT(&b)[kRegCells], auto LEN) {
+      constexpr int L = decltype(LEN)::value;
+      constexpr int B = MSW_PASSA_BATCH;  // cells gathered together (2 x ds_read_b128 each)
 #pragma unroll
-        for (int k0 = 0; k0 < L; k0 += B) {
-          double2 ewv[B], xtv[B];
+      for (int k0 = 0; k0 < L; k0 += B) {
+        double2 ewv[B], xtv[B];
 #pragma unroll
-          for (int k = 0; k < B; ++k) {
-            if (k0 + k < L) {
-              ewv[k] = EW_(b[k0 + k]);
-              xtv[k] = XT_(b[k0 + k]);
-            }
+        for (int k = 0; k < B; ++k) {
+          if (k0 + k < L) {
+            ewv[k] = EW_(b[k0 + k]);
+            xtv[k] = XT_(b[k0 + k]);
           }
-#pragma unroll
-          for (int k = 0; k < B; ++k)
-            if (k0 + k < L) cellA(c, p0, ewv[k].x, ewv[k].y, xtv[k].x, xtv[k].y);
         }
-      };
-      switch (len) {
-        case 0: break;
-        case 2: fixed(std::integral_constant<int, 2>{}); break;
-        case 4: fixed(std::integral_constant<int, 4>{}); break;
-        case 6: fixed(std::integral_constant<int, 6>{}); break;
-        case 8: fixed(std::integral_constant<int, 8>{}); break;
-        case 10: fixed(std::integral_constant<int, 10>{}); break;
-        case 12: fixed(std::integral_constant<int, 12>{}); break;
-        case 14: fixed(std::integral_constant<int, 14>{}); break;
-        default: fixed(std::integral_constant<int, 16>{}); break;
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+          if (k0 + k < L) cellA(c, p0, ewv[k].x, ewv[k].y, xtv[k].x, xtv[k].y);
       }
+    };
+    auto cells = [&](RT(&b)[kRegCells], uint32_t n) {
+      switch (n) {
+        case 0: break;
+        case 2: fixed(b, std::integral_constant<int, 2>{}); break;
+        case 4: fixed(b, std::integral_constant<int, 4>{}); break;
+        case 6: fixed(b, std::integral_constant<int, 6>{}); break;
+        case 8: fixed(b, std::integral_constant<int, 8>{}); break;
+        case 10: fixed(b, std::integral_constant<int, 10>{}); break;
+        case 12: fixed(b, std::integral_constant<int, 12>{}); break;
+        case 14: fixed(b, std::integral_constant<int, 14>{}); break;
+        default: fixed(b, std::integral_constant<int, 16>{}); break;
+      }
+    };
+    if (len <= (uint32_t)kRegCells) {
+      cells(sb.r, len);
     } else {
+      // more cells per EC than the registers hold (the stream has not fetched this slice): chunks of
+      // kRegCells records through the same registers and the same straight-line code; the other
+      // wavefronts of the workgroup cover each chunk's load latency
+      // (registers of their own: a load into the stream's buffers inside process() would make the
+      // compiler's path-insensitive waitcnt bookkeeping drain the prefetch on the short path too)
       const size_t base = (size_t)sb.o * 64 + lane;
-      for (uint32_t k = 0; k < len; k += 2) {
-        const RT r0 = R::load(S.rec, base + (size_t)k * 64);
-        const RT r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
-        const double2 a0 = EW_(r0), a1 = EW_(r1);
-        const double2 x0 = XT_(r0), x1 = XT_(r1);
-        cellA(c, p0, a0.x, a0.y, x0.x, x0.y);
-        cellA(c, p0, a1.x, a1.y, x1.x, x1.y);
+      RT t[kRegCells];
+      uint32_t k0 = 0;
+      for (; k0 + (uint32_t)kRegCells <= len; k0 += kRegCells) {
+        load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, kRegCells, t);
+        fixed(t, std::integral_constant<int, kRegCells>{});
+      }
+      if (k0 < len) {  // the last chunk: pair by pair (a second copy of the per-count code costs the
+                       // short path 5 % through its sheer size)
+        const uint32_t n = len - k0;
+        load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, n, t);
+#pragma unroll
+        for (int k = 0; k < kRegCells; k += 2) {
+          if ((uint32_t)k < n) {
+            const double2 a0 = EW_(t[k]), a1 = EW_(t[k + 1]);
+            const double2 x0 = XT_(t[k]), x1 = XT_(t[k + 1]);
+            cellA(c, p0, a0.x, a0.y, x0.x, x0.y);
+            cellA(c, p0, a1.x, a1.y, x1.x, x1.y);
+          }
+        }
       }
     }
     if (sb.sl * 64 + lane < n_sell) {
@@ -288,16 +307,19 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
     }
   };
   stream.run(issue, process, [] {});
-  // long ECs: the whole workgroup strides over one EC's cells
-  for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
+  // long ECs (plain CSR): one wavefront per EC, a cell per lane and step -- the groups of one EC are
+  // distinct, so the gathers of a step never meet on an address, and the three sums are wave
+  // reductions (no barrier)
+  for (uint32_t r = stream.s_first; r < S.n_long; r += stream.nw) {
     AccA c = {0.0, 0.0, 0.0};
-    for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreads) {
+    const uint32_t k1 = S.long_ptr[r + 1];
+    for (uint32_t k = S.long_ptr[r] + lane; k < k1; k += 64) {
       const RT rc = R::load(S.rec_long, k);
       const double2 a0 = EW_(rc), x0 = XT_(rc);
       cellA(c, p0, a0.x, a0.y, x0.x, x0.y);
     }
-    const double zs = block_sum(c.zs, sh), t1 = block_sum(c.t1, sh), t2 = block_sum(c.t2, sh);
-    if (tid == 0) {
+    const double zs = wave_sum(c.zs), t1 = wave_sum(c.t1), t2 = wave_sum(c.t2);
+    if (lane == 0) {
       const double iZ = 1.0 / (zbase + zs);
       const double S1 = (b1 + t1) * iZ, S2 = (b2 + t2) * iZ;
       nn += S2 - S1 * S1;
@@ -393,68 +415,76 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     sb.c8 = q < n_sell ? cj : 0u;
   };
   auto process = [&](SliceBuf<WIDE> &sb) {
-    RT(&b)[kRegCells] = sb.r;
     const uint32_t o = sb.o, len = sb.len;
     double c = (double)sb.c8;
     if (sb.c8 == kC8Escape) c = S.cvec[S.n_long + sb.sl * 64 + lane];  // not a small integer: rare
     double zs = 0.0, hs = 0.0;
-    if (len <= (uint32_t)kRegCells) {
-      // row sums: straight-line code per slice length (wave-uniform, even).  x - p0 of the first
-      // KEEPN cells stays in registers for the scatter, any others are gathered a second time (with
-      // 16 wavefronts per workgroup all 16 would push the kernel into scratch, and a scratch reload
-      // drains the record prefetch: hence 12 wavefronts, common.hpp).
-      constexpr int KEEPN = MSW_B_KEEPN;  // x - p0 of the first KEEPN cells stay in registers
-      double xv[KEEPN > 0 ? KEEPN : 1];
-      auto fixed = [&](auto LEN) {
-        constexpr int L = decltype(LEN)::value;
-        constexpr int B = MSW_PASSB_BATCH;  // cells whose gathers are issued together
+    // row sums: straight-line code per cell count (wave-uniform, even).  x - p0 of the first KEEPN
+    // cells stays in registers for the scatter, any others are gathered a second time (with 16
+    // wavefronts per workgroup all 16 would push the kernel into scratch, and a scratch reload
+    // drains the record prefetch: hence 12 wavefronts, common.hpp).
+    constexpr int KEEPN = WIDE ? 4 : MSW_B_KEEPN;  // 8-byte records take twice the registers
+    double xv[KEEPN > 0 ? KEEPN : 1];
+    auto fixed = [&](RT(&b)[kRegCells], auto LEN, auto KEEP) {
+      constexpr int L = decltype(LEN)::value;
+      constexpr bool KP = decltype(KEEP)::value;
+      constexpr int B = MSW_PASSB_BATCH;  // cells whose gathers are issued together
 #pragma unroll
-        for (int k0 = 0; k0 < L; k0 += B) {
-          double ev[B];
-          double2 xt[B];
+      for (int k0 = 0; k0 < L; k0 += B) {
+        double ev[B];
+        double2 xt[B];
 #pragma unroll
-          for (int k = 0; k < B; ++k) {
-            if (k0 + k < L) {
-              ev[k] = E_(b[k0 + k]);
-              xt[k] = XT_(b[k0 + k]);
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < B; ++k) {
-            if (k0 + k < L) {
-              zs = fma(ev[k], xt[k].x, zs);
-              hs = fma(ev[k], xt[k].y, hs);
-              if constexpr (KEEPN > 0) if (k0 + k < KEEPN) xv[k0 + k] = xt[k].x;
-            }
+        for (int k = 0; k < B; ++k) {
+          if (k0 + k < L) {
+            ev[k] = E_(b[k0 + k]);
+            xt[k] = XT_(b[k0 + k]);
           }
         }
-      };
-      switch (len) {
-        case 0: break;
-        case 2: fixed(std::integral_constant<int, 2>{}); break;
-        case 4: fixed(std::integral_constant<int, 4>{}); break;
-        case 6: fixed(std::integral_constant<int, 6>{}); break;
-        case 8: fixed(std::integral_constant<int, 8>{}); break;
-        case 10: fixed(std::integral_constant<int, 10>{}); break;
-        case 12: fixed(std::integral_constant<int, 12>{}); break;
-        case 14: fixed(std::integral_constant<int, 14>{}); break;
-        default: fixed(std::integral_constant<int, 16>{}); break;
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+          if (k0 + k < L) {
+            zs = fma(ev[k], xt[k].x, zs);
+            hs = fma(ev[k], xt[k].y, hs);
+            if constexpr (KP && KEEPN > 0) if (k0 + k < KEEPN) xv[k0 + k] = xt[k].x;
+          }
+        }
       }
+    };
+    auto cells = [&](RT(&b)[kRegCells], uint32_t n, auto KEEP) {
+      switch (n) {
+        case 0: break;
+        case 2: fixed(b, std::integral_constant<int, 2>{}, KEEP); break;
+        case 4: fixed(b, std::integral_constant<int, 4>{}, KEEP); break;
+        case 6: fixed(b, std::integral_constant<int, 6>{}, KEEP); break;
+        case 8: fixed(b, std::integral_constant<int, 8>{}, KEEP); break;
+        case 10: fixed(b, std::integral_constant<int, 10>{}, KEEP); break;
+        case 12: fixed(b, std::integral_constant<int, 12>{}, KEEP); break;
+        case 14: fixed(b, std::integral_constant<int, 14>{}, KEEP); break;
+        default: fixed(b, std::integral_constant<int, 16>{}, KEEP); break;
+      }
+    };
+    // scatter of up to kRegCells cells held in b; padding records point at the lane's own sentinel
+    // group: no test, no shared address
+    auto scatter = [&](RT(&b)[kRegCells], uint32_t n, double rj, auto KEPT) {
+      constexpr bool KP = decltype(KEPT)::value;
+#pragma unroll
+      for (int k = 0; k < kRegCells; k += 2) {
+        if ((uint32_t)k < n) {
+          const double x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : XM_(b[k]);
+          const double x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : XM_(b[k + 1]);
+          addACC(b[k], rj * x0);
+          addACC(b[k + 1], rj * x1);
+        }
+      }
+    };
+    if (len <= (uint32_t)kRegCells) {
+      cells(sb.r, len, std::true_type{});
       if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
         const double rj = c / Z;
         s_rH += rj * H;
         s_W += rj;
-        // padding records point at the lane's own sentinel group: no test, no shared address
-#pragma unroll
-        for (int k = 0; k < kRegCells; k += 2) {
-          if ((uint32_t)k < len) {
-            const double x0 = k < KEEPN ? xv[k < KEEPN ? k : 0] : XM_(b[k]);
-            const double x1 = k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : XM_(b[k + 1]);
-            addACC(b[k], rj * x0);
-            addACC(b[k + 1], rj * x1);
-          }
-        }
+        scatter(sb.r, len, rj, std::true_type{});
         // sum c log Z after the scatter (its registers are free by now).  For the multiplicities
         // 1..3 -- nearly all ECs -- the logarithm is deferred: the mantissas are multiplied up per
         // lane and one log per 64 slices is taken of the product (flush_logs): ~8 operations per
@@ -473,16 +503,31 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         }
       }
     } else {
+      // more cells per EC than the registers hold (the stream has not fetched this slice): chunks of
+      // kRegCells records through the same registers -- once for the row sums, once more (from L2)
+      // for the scatter; the other wavefronts of the workgroup cover each chunk's load latency
+      // (registers of their own: see pass A)
       const size_t base = (size_t)o * 64 + lane;
-      for (uint32_t k = 0; k < len; k += 2) {
-        const RT r0 = R::load(S.rec, base + (size_t)k * 64);
-        const RT r1 = R::load(S.rec, base + (size_t)(k + 1) * 64);
-        const double e0 = E_(r0), e1 = E_(r1);
-        const double2 t0 = XT_(r0), t1 = XT_(r1);
-        zs = fma(e0, t0.x, zs);
-        hs = fma(e0, t0.y, hs);
-        zs = fma(e1, t1.x, zs);
-        hs = fma(e1, t1.y, hs);
+      RT t[kRegCells];
+      uint32_t k0 = 0;
+      for (; k0 + (uint32_t)kRegCells <= len; k0 += kRegCells) {
+        load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, kRegCells, t);
+        fixed(t, std::integral_constant<int, kRegCells>{}, std::false_type{});
+      }
+      if (k0 < len) {
+        const uint32_t n = len - k0;
+        load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, n, t);
+#pragma unroll
+        for (int k = 0; k < kRegCells; k += 2) {
+          if ((uint32_t)k < n) {
+            const double e0 = E_(t[k]), e1 = E_(t[k + 1]);
+            const double2 t0 = XT_(t[k]), t1 = XT_(t[k + 1]);
+            zs = fma(e0, t0.x, zs);
+            hs = fma(e0, t0.y, hs);
+            zs = fma(e1, t1.x, zs);
+            hs = fma(e1, t1.y, hs);
+          }
+        }
       }
       if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
@@ -490,37 +535,40 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         s_clogZ += c * log(Z);
         s_rH += rj * H;
         s_W += rj;
-        for (uint32_t k = 0; k < len; ++k) {
-          const RT r = R::load(S.rec, base + (size_t)k * 64);
-          addACC(r, rj * XT_(r).x);
+        for (k0 = 0; k0 < len; k0 += kRegCells) {
+          const uint32_t n = len - k0 < (uint32_t)kRegCells ? len - k0 : (uint32_t)kRegCells;
+          load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, n, t);
+          scatter(t, n, rj, std::false_type{});
         }
       }
     }
   };
   stream.run(issue, process, flush_logs);
-  for (uint32_t r = blockIdx.x; r < S.n_long; r += gridDim.x) {
+  // long ECs (plain CSR): one wavefront per EC, a cell per lane and step (see pass A)
+  for (uint32_t r = stream.s_first; r < S.n_long; r += stream.nw) {
     double zs = 0.0, hs = 0.0;
-    for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreadsB) {
+    const uint32_t kb = S.long_ptr[r] + lane, k1 = S.long_ptr[r + 1];
+    for (uint32_t k = kb; k < k1; k += 64) {
       const RT rc = R::load(S.rec_long, k);
       const double eg = E_(rc);
       const double2 t = XT_(rc);
       zs = fma(eg, t.x, zs);
       hs = fma(eg, t.y, hs);
     }
-    zs = block_sum(zs, sh);
-    hs = block_sum(hs, sh);
+    zs = wave_sum(zs);
+    hs = wave_sum(hs);
     const double c = S.cvec[r];
     if (c != 0.0) {
       const double Z = zbase + zs, H = hbase + hs;
       const double rj = c / Z;
-      if (tid == 0) {
+      if (lane == 0) {
         s_clogZ += c * log(Z);
         s_rH += rj * H;
         s_W += rj;
       }
-      for (uint32_t k = S.long_ptr[r] + tid; k < S.long_ptr[r + 1]; k += kPassThreadsB) {
+      for (uint32_t k = kb; k < k1; k += 64) {
         const RT rc = R::load(S.rec_long, k);
-        addACC(rc, rj * XT_(rc).x);
+        addACC(rc, rj * XM_(rc));
       }
     }
   }
