@@ -50,6 +50,7 @@ struct msw_core {
   int gmodeB = 1;  // k_passB GMODE (sweep_kernels.hpp)
   uint32_t enc_shift = 0, enc_mask = 0, enc_bhi = 0;  // record encoding (sell.hpp)
   uint32_t n_area = 0;                                  // 16-byte entries of the slot area
+  uint32_t long_row = kLongRow;                         // ECs with more cells go one per wavefront (<= kLongRow)
   DevBuf<uint32_t> area_slot;
   DevBuf<double> lut_area;  // lut[area_slot[i]]: what the per-slot tables are built from, in their order
   DevBuf<int> tab_built;    // k_tables bookkeeping

@@ -21,12 +21,12 @@ __device__ __constant__ uint8_t kRPosDev[64] = {0,  1,  2,  3,  0,  1,  2,  3,  
                                                 8,  9,  10, 11, 8,  9,  10, 11, 12, 13, 14, 15, 12, 13, 14, 15};
 
 // sort key of an EC: 0 = long (plain CSR part), else 1 + (kLongRow - cells): ascending = SELL order
-__global__ __launch_bounds__(256) void k_pack_keys(const uint32_t *rowptr, uint32_t E, uint32_t *key,
-                                                  uint32_t *val, uint32_t *n_long) {
+__global__ __launch_bounds__(256) void k_pack_keys(const uint32_t *rowptr, uint32_t E, uint32_t long_row,
+                                                  uint32_t *key, uint32_t *val, uint32_t *n_long) {
   uint32_t mine = 0;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < E; j += gridDim.x * blockDim.x) {
     const uint32_t len = rowptr[j + 1] - rowptr[j];
-    const bool lg = len > (uint32_t)kLongRow;
+    const bool lg = len > long_row;  // long_row <= kLongRow
     key[j] = lg ? 0u : 1u + ((uint32_t)kLongRow - len);
     val[j] = j;
     mine += lg;

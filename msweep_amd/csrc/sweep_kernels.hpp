@@ -65,6 +65,13 @@ __device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uin
   }
 }
 
+// a record that contributes nothing: group offset hi (a sentinel group: e = 0), slot entry 0
+template <bool WIDE>
+__device__ __forceinline__ typename Rec<WIDE>::T null_record(uint32_t hi, uint32_t shift) {
+  if constexpr (WIDE) return make_uint2(hi, 0u);
+  else return hi << shift;
+}
+
 // s_waitcnt vmcnt(0), leaving the other counters alone (gfx9 layout: vmcnt = imm[3:0] | imm[15:14] << 4)
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
@@ -310,13 +317,20 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step -- the groups of one EC are
   // distinct, so the gathers of a step never meet on an address, and the three sums are wave
   // reductions (no barrier)
+  // (four records per lane in flight; lanes past the end take a record of their own sentinel group)
+  const RT null_rec = null_record<WIDE>(S.bhi + 8u * (G + (uint32_t)lane), shift);
   for (uint32_t r = stream.s_first; r < S.n_long; r += stream.nw) {
     AccA c = {0.0, 0.0, 0.0};
     const uint32_t k1 = S.long_ptr[r + 1];
-    for (uint32_t k = S.long_ptr[r] + lane; k < k1; k += 64) {
-      const RT rc = R::load(S.rec_long, k);
-      const double2 a0 = EW_(rc), x0 = XT_(rc);
-      cellA(c, p0, a0.x, a0.y, x0.x, x0.y);
+    for (uint32_t k = S.long_ptr[r] + lane; k < k1; k += 4 * 64) {
+      RT rc[4];
+      double2 a0[4], x0[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rc[u] = k + 64u * u < k1 ? R::load(S.rec_long, k + 64u * u) : null_rec;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a0[u] = EW_(rc[u]), x0[u] = XT_(rc[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cellA(c, p0, a0[u].x, a0[u].y, x0[u].x, x0[u].y);
     }
     const double zs = wave_sum(c.zs), t1 = wave_sum(c.t1), t2 = wave_sum(c.t2);
     if (lane == 0) {
@@ -545,15 +559,23 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   };
   stream.run(issue, process, flush_logs);
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step (see pass A)
+  const RT null_rec = null_record<WIDE>(bhi + 8u * (G + (uint32_t)lane), shift);
   for (uint32_t r = stream.s_first; r < S.n_long; r += stream.nw) {
     double zs = 0.0, hs = 0.0;
     const uint32_t kb = S.long_ptr[r] + lane, k1 = S.long_ptr[r + 1];
-    for (uint32_t k = kb; k < k1; k += 64) {
-      const RT rc = R::load(S.rec_long, k);
-      const double eg = E_(rc);
-      const double2 t = XT_(rc);
-      zs = fma(eg, t.x, zs);
-      hs = fma(eg, t.y, hs);
+    for (uint32_t k = kb; k < k1; k += 4 * 64) {
+      RT rc[4];
+      double eg[4];
+      double2 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rc[u] = k + 64u * u < k1 ? R::load(S.rec_long, k + 64u * u) : null_rec;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) eg[u] = E_(rc[u]), t[u] = XT_(rc[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        zs = fma(eg[u], t[u].x, zs);
+        hs = fma(eg[u], t[u].y, hs);
+      }
     }
     zs = wave_sum(zs);
     hs = wave_sum(hs);
@@ -566,9 +588,15 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         s_rH += rj * H;
         s_W += rj;
       }
-      for (uint32_t k = kb; k < k1; k += 64) {
-        const RT rc = R::load(S.rec_long, k);
-        addACC(rc, rj * XM_(rc));
+      for (uint32_t k = kb; k < k1; k += 4 * 64) {
+        RT rc[4];
+        double xm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rc[u] = k + 64u * u < k1 ? R::load(S.rec_long, k + 64u * u) : null_rec;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xm[u] = XM_(rc[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) addACC(rc[u], rj * xm[u]);
       }
     }
   }

@@ -9,7 +9,11 @@ from msweep_amd.core import Core
 from msweep_amd.likelihood import from_grouped_counts
 
 core = Core(0)
-for R, G, mo in [(2_000_000, 1000, 6), (2_000_000, 1000, 40), (1_000_000, 1000, 200), (400_000, 1000, 800), (200_000, 3000, 2500)]:
+CASES = [(2_000_000, 1000, 6), (2_000_000, 1000, 40), (1_000_000, 1000, 200), (400_000, 1000, 800), (200_000, 3000, 2500)]
+if len(sys.argv) > 1:
+    CASES = CASES[int(sys.argv[1]):]
+print("MSWEEP_LONG_ROW =", os.environ.get("MSWEEP_LONG_ROW", "(default)"))
+for R, G, mo in CASES:
     p = synth.make_csr_problem(R, G, seed=2, max_other=mo)
     E, nnz = len(p["rowptr"]) - 1, len(p["grp"])
     lik = from_grouped_counts(core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
