@@ -48,10 +48,18 @@ struct DevBuf {
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
+  bool borrowed = false;  // a view of another handle's buffer: never freed here
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !borrowed) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    borrowed = false;
+  }
+  void borrow(const DevBuf &o) {
+    release();
+    p = o.p;
+    n = o.n;
+    borrowed = o.p != nullptr;
   }
   void alloc(size_t count) {
     if (count <= n && p) return;

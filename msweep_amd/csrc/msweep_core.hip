@@ -98,6 +98,9 @@ struct msw_core {
   bool mt_valid = false;
   int32_t mt_seed = 0;
   uint64_t mt_pos = 0;
+  // further solver states on the same resident likelihood (borrowed buffers, streams of their own):
+  // the bootstrap driver runs several replicates at a time (host_bootstrap.inc)
+  std::vector<std::unique_ptr<msw_core>> clones;
 
   // ---- measurement ---------------------------------------------------------------------------
   bool profiling = false, fixed_iters = false;

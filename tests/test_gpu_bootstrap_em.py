@@ -146,3 +146,24 @@ def test_large_slot_area_em_and_bootstrap(gpu_core, oracle):
         assert abs(iters[b] - rb["iters"]) <= 2
         assert_theta(theta[b], rb["theta"])
 
+
+@pytest.mark.parametrize("streams", ["1", "3", "16"])
+def test_replicates_in_flight_do_not_change_results(gpu_core, monkeypatch, streams):
+    """The driver runs several replicates at a time (solver states sharing the resident likelihood,
+    one stream each, contiguous blocks of the one random stream): same counts, same solves."""
+    p = synth.make_csr_problem(20000, 50, seed=41, max_other=6)
+    G = 50
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    w = p["ec_counts"].astype(np.uint32)
+    draws = int(w.sum())
+    monkeypatch.setenv("MSWEEP_BOOTSTRAP_STREAMS", "1")
+    ref, it_ref = gpu_core.bootstrap(w, 5, draws, 1, 8, np.ones(G))
+    monkeypatch.setenv("MSWEEP_BOOTSTRAP_STREAMS", streams)
+    got, it = gpu_core.bootstrap(w, 5, draws, 1, 8, np.ones(G))
+    assert it.tolist() == it_ref.tolist()
+    for b in range(7):
+        assert_theta(got[b], ref[b])
+    # the handle's own state still serves a plain solve afterwards
+    res = gpu_core.solve(lik.log_counts(), np.ones(G))
+    assert res["theta"].sum() == pytest.approx(1.0, abs=1e-12)
+
