@@ -212,7 +212,7 @@ def main():
         # collected offline on this exact workload and committed under profiles/
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc_v6.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc_v7.json")))
             if (a.reads, G, a.seed) == (10_000_000, 5000, 2) and n_gpus == 1:  # the profiled workload
                 traffic = next(v["hbm_bytes_per_launch"] for k, v in tj.items() if dom in k)
         except Exception:
