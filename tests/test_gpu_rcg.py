@@ -166,6 +166,29 @@ def test_reference_shaped_dense_matrix_takes_the_csr_sweeps(gpu_core, oracle, R,
         np.testing.assert_allclose(res2["theta"], res["theta"], rtol=1e-9, atol=1e-15)
 
 
+def test_dense_boundary_edge_matrices(gpu_core, oracle):
+    """Shapes the re-expression must get right or leave alone: nothing listed at all, a background that
+    holds under half of the cells (stays dense).  (-inf cells turn the RCG update into NaN in the
+    reference-shaped oracle as well: not an input of this path.)"""
+    G, E = 12, 300
+    alpha0 = np.ones(G)
+    logc = np.zeros(E)
+    # every cell the background: a valid likelihood with nothing listed -> theta = prior mean
+    L = np.full((G, E), np.log(0.01))
+    from_dense(gpu_core, L, logc)
+    assert gpu_core.shape() == (G, E, 0)
+    res = gpu_core.solve(logc, alpha0)
+    np.testing.assert_allclose(res["theta"], np.full(G, 1.0 / G), rtol=1e-12)
+    np.testing.assert_array_equal(gpu_core.get_dense_logl(), L)
+    # no value holds half of the sample: kept dense
+    rng = np.random.default_rng(8)
+    L = rng.normal(-3.0, 1.0, (G, E))
+    from_dense(gpu_core, L, logc)
+    assert gpu_core.shape()[2] == G * E
+    ref = oracle.rcg_optl_dense(L, logc, alpha0)
+    assert_theta(gpu_core.solve(logc, alpha0)["theta"], oracle.mixture_components(ref["gamma"], logc))
+
+
 def test_dense_strided_input_and_gamma(gpu_core, oracle, dense_mode):
     p = synth.make_dense_problem(700, 33, seed=9)
     big = np.zeros((33, 1000))
