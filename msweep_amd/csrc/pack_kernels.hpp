@@ -158,14 +158,14 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
             if (taken >> c & 1) continue;
             const uint32_t g = cg[c][lane], i = ce[c][lane];
             int score = 0;
-            if (!(at[C] >> (g & 15) & 1)) score += 8;                              // atomic: bank pair free
-            if (rg[R][g & 15] == 0xffffffffu || rg[R][g & 15] == g) score += 6;   // {e,w} b128
-            if (rs[R][i & 15] == 0xffffffffu || rs[R][i & 15] == i) score += 4;   // slot entry b128
-            if (hg[H][g & 31] == 0xffffffffu || hg[H][g & 31] == g) score += 2;   // e_g b64
+            if (!(at[C] >> (g & 15) & 1)) score += MSW_W_AT;                              // atomic: bank pair free
+            if (rg[R][g & 15] == 0xffffffffu || rg[R][g & 15] == g) score += MSW_W_EW;   // {e,w} b128
+            if (rs[R][i & 15] == 0xffffffffu || rs[R][i & 15] == i) score += MSW_W_XT;   // slot entry b128
+            if (hg[H][g & 31] == 0xffffffffu || hg[H][g & 31] == g) score += MSW_W_E;   // e_g b64
             if (score > best_score) {
               best_score = score;
               best = (int)c;
-              if (score == 20) break;
+              if (score == MSW_W_AT + MSW_W_EW + MSW_W_XT + MSW_W_E) break;
             }
           }
           if (best >= 0) {

@@ -39,6 +39,14 @@ struct SellDev {
 };
 
 constexpr uint32_t kC8Escape = 255;
+// weights of the greedy LDS-bank scheduler (both packers): a cell scores a weight for every access it
+// can make without a bank conflict in the current step -- column-sum atomic, {e,w} b128, slot b128, e_g b64
+#ifndef MSW_W_AT
+#define MSW_W_AT 8
+#define MSW_W_EW 6
+#define MSW_W_XT 4
+#define MSW_W_E 2
+#endif
 constexpr int kLongRow = 256;  // ECs with more cells than this take the workgroup path
 
 template <bool WIDE>
