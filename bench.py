@@ -196,6 +196,17 @@ def main():
     core.run(max_iters=a.steps)
     tm = core.last_timing()
     core.set_profiling(False)
+    # SURVEY 8(d), second figure: time to convergence at the reference's defaults (--tol 1e-6,
+    # --max-iters 5000), host inputs handed over per call as at the reference's boundary (PCIe-inclusive)
+    conv = None
+    if not shard:
+        core.set_fixed_iters(False)
+        t1 = time.perf_counter()
+        rc = core.solve(logc, alpha0, tol=1e-6, max_iters=5000)
+        t_conv = time.perf_counter() - t1
+        conv = {"iters": int(rc["iters"]), "ms": t_conv * 1e3, "device_ms": core.last_timing()["solve_ms"],
+                "tol": 1e-6, "includes": "upload of log counts and prior, download of theta"}
+        core.set_fixed_iters(True)
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64).cuda()
@@ -239,6 +250,8 @@ def main():
                          "algorithmic_bytes_per_launch": b_dom, "avg_launch_ms": ms_dom},
             "setup_s": {"generate": t_gen},
         }
+        if conv is not None:
+            line["time_to_convergence"] = conv
         if not a.no_cpu_baseline:
             log("cpu baseline ...")
             try:
