@@ -196,6 +196,16 @@ def main():
     core.run(max_iters=a.steps)
     tm = core.last_timing()
     core.set_profiling(False)
+    # the EM optimiser (--algorithm emgpu: one pass-B sweep + one O(G) kernel per iteration), same K
+    # steps on the same resident inputs; reported beside the headline, which is the default RCG
+    em = None
+    if not shard:
+        from msweep_amd.core import ALGO_EM
+        core.run(max_iters=max(a.warmup, 1), algo=ALGO_EM)
+        t1 = time.perf_counter()
+        core.run(max_iters=a.steps, algo=ALGO_EM)
+        t_em = time.perf_counter() - t1
+        em = {"ms_per_step": t_em * 1e3 / a.steps, "iters_per_sec": a.steps / t_em}
     # SURVEY 8(d), second figure: time to convergence at the reference's defaults (--tol 1e-6,
     # --max-iters 5000), host inputs handed over per call as at the reference's boundary (PCIe-inclusive)
     conv = None
@@ -252,6 +262,8 @@ def main():
         }
         if conv is not None:
             line["time_to_convergence"] = conv
+        if em is not None:
+            line["em_algorithm"] = em
         if not a.no_cpu_baseline:
             log("cpu baseline ...")
             try:
