@@ -167,3 +167,27 @@ def test_replicates_in_flight_do_not_change_results(gpu_core, monkeypatch, strea
     res = gpu_core.solve(lik.log_counts(), np.ones(G))
     assert res["theta"].sum() == pytest.approx(1.0, abs=1e-12)
 
+
+def test_replicates_in_flight_across_likelihood_changes(gpu_core, monkeypatch):
+    """The extra solver states outlive a likelihood: a larger CSR likelihood, then a dense one (kept on
+    the dense sweeps), on the same handle -- each time the same replicates as with one in flight."""
+    def both(w, draws, G):
+        monkeypatch.setenv("MSWEEP_BOOTSTRAP_STREAMS", "1")
+        ref, it_ref = gpu_core.bootstrap(w, 9, draws, 0, 5, np.ones(G))
+        monkeypatch.setenv("MSWEEP_BOOTSTRAP_STREAMS", "3")
+        got, it = gpu_core.bootstrap(w, 9, draws, 0, 5, np.ones(G))
+        assert it.tolist() == it_ref.tolist()
+        for b in range(5):
+            assert_theta(got[b], ref[b])
+
+    for R, G, seed in [(5000, 20, 51), (60000, 120, 52)]:
+        p = synth.make_csr_problem(R, G, seed=seed, max_other=5)
+        from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+        w = p["ec_counts"].astype(np.uint32)
+        both(w, int(w.sum()), G)
+    monkeypatch.setenv("MSWEEP_DENSE_COMPRESS", "0")
+    d = synth.make_dense_problem(3000, 70, seed=53)
+    from_dense(gpu_core, d["logl"], d["logc"])
+    w = np.random.default_rng(2).integers(1, 9, 3000).astype(np.uint32)
+    both(w, int(w.sum()), 70)
+
