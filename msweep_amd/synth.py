@@ -75,7 +75,7 @@ def make_csr_problem(n_reads, n_groups, seed=2, max_other=15, dirichlet=0.05, th
                 h = h * mul + v[:, c]
                 h ^= h >> np.uint64(29)
         hashes.append(h)
-        lens_all.append(valid.sum(1).astype(np.uint8))
+        lens_all.append(valid.sum(1).astype(np.uint16))
         grp_all.append(cols[valid].astype(np.uint32))
         cnt_all.append(cnt[valid].astype(np.uint32))
     h = np.concatenate(hashes)

@@ -9,7 +9,7 @@ from msweep_amd.core import Core
 from msweep_amd.likelihood import from_grouped_counts
 
 core = Core(0)
-CASES = [(2_000_000, 1000, 6), (2_000_000, 1000, 40), (1_000_000, 1000, 200), (400_000, 1000, 800), (200_000, 3000, 2500)]
+CASES = [(2_000_000, 1000, 6), (2_000_000, 1000, 40), (1_000_000, 1000, 200), (200_000, 1000, 800), (60_000, 3000, 2500)]
 if len(sys.argv) > 1:
     CASES = CASES[int(sys.argv[1]):]
 print("MSWEEP_LONG_ROW =", os.environ.get("MSWEEP_LONG_ROW", "(default)"))
