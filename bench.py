@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--groups", type=int, default=5000)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the EM and time-to-convergence runs after the timed region (profiling runs)")
     ap.add_argument("--cpu-sample-ecs", type=int, default=50000)
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--mode", choices=["replicates", "shard"], default="replicates",
@@ -199,7 +201,7 @@ def main():
     # the EM optimiser (--algorithm emgpu: one pass-B sweep + one O(G) kernel per iteration), same K
     # steps on the same resident inputs; reported beside the headline, which is the default RCG
     em = None
-    if not shard:
+    if not shard and not a.no_extras:
         from msweep_amd.core import ALGO_EM
         core.run(max_iters=max(a.warmup, 1), algo=ALGO_EM)
         t1 = time.perf_counter()
@@ -209,7 +211,7 @@ def main():
     # SURVEY 8(d), second figure: time to convergence at the reference's defaults (--tol 1e-6,
     # --max-iters 5000), host inputs handed over per call as at the reference's boundary (PCIe-inclusive)
     conv = None
-    if not shard:
+    if not shard and not a.no_extras:
         core.set_fixed_iters(False)
         t1 = time.perf_counter()
         rc = core.solve(logc, alpha0, tol=1e-6, max_iters=5000)
