@@ -21,6 +21,10 @@
 namespace msw {
 
 constexpr int kRegCells = 16;  // cells per EC a wave keeps in registers (longer slices stream)
+#ifndef MSW_LONG_STEP
+#define MSW_LONG_STEP 8
+#endif
+constexpr int kLongStep = MSW_LONG_STEP;  // records per lane and step on the wavefront-per-EC path (multiple of 4)
 // tuning knobs (defaults measured on MI355X; tools/ab_build.py builds variants)
 #ifndef MSW_REVERSE_B
 #define MSW_REVERSE_B true
@@ -317,20 +321,32 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step -- the groups of one EC are
   // distinct, so the gathers of a step never meet on an address, and the three sums are wave
   // reductions (no barrier)
-  // (four records per lane in flight; lanes past the end take a record of their own sentinel group)
+  // (lanes past the end take a record of their own sentinel group)
   const RT null_rec = null_record<WIDE>(S.bhi + 8u * (G + (uint32_t)lane), shift);
   for (uint32_t r = stream.s_first; r < S.n_long; r += stream.nw) {
     AccA c = {0.0, 0.0, 0.0};
     const uint32_t k1 = S.long_ptr[r + 1];
-    for (uint32_t k = S.long_ptr[r] + lane; k < k1; k += 4 * 64) {
-      RT rc[4];
-      double2 a0[4], x0[4];
+    // LS records per lane in flight per step (with 4, a wavefront keeps 1 KB in flight and the
+    // path sits at its load latency: 2.7 TB/s of records whatever else it does; 8-byte records
+    // stay at 4: twice the registers)
+    constexpr int LS = WIDE ? 4 : kLongStep;
+    for (uint32_t kb = S.long_ptr[r]; kb < k1; kb += LS * 64) {
+      RT rc[LS];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) rc[u] = k + 64u * u < k1 ? R::load(S.rec_long, k + 64u * u) : null_rec;
+      for (int u = 0; u < LS; ++u) {
+        rc[u] = null_rec;
+        if (kb + 64u * u < k1 && kb + 64u * u + lane < k1) rc[u] = R::load(S.rec_long, kb + 64u * u + lane);
+      }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a0[u] = EW_(rc[u]), x0[u] = XT_(rc[u]);
+      for (int q = 0; q < LS; q += 4) {
+        if (kb + 64u * q < k1) {  // wave-uniform: quads past the end are skipped
+          double2 a0[4], x0[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) cellA(c, p0, a0[u].x, a0[u].y, x0[u].x, x0[u].y);
+          for (int u = 0; u < 4; ++u) a0[u] = EW_(rc[q + u]), x0[u] = XT_(rc[q + u]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) cellA(c, p0, a0[u].x, a0[u].y, x0[u].x, x0[u].y);
+        }
+      }
     }
     const double zs = wave_sum(c.zs), t1 = wave_sum(c.t1), t2 = wave_sum(c.t2);
     if (lane == 0) {
@@ -560,41 +576,52 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   stream.run(issue, process, flush_logs);
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step (see pass A)
   const RT null_rec = null_record<WIDE>(bhi + 8u * (G + (uint32_t)lane), shift);
-  // The current EC's first 256 records stay in registers for the scatter (one reload less: 10 % on
-  // ECs of 300..1000 cells), and the next EC's first 256 are fetched before the current one is
+  // The current EC's first kLongStep * 64 records stay in registers for the scatter (one reload less: 10 % on
+  // ECs of 300..1000 cells), and the next EC's first ones are fetched before the current one is
   // processed.  (The same prefetch changes nothing in pass A, which keeps the plain loop: the
   // wavefront-per-EC path is not bound by its load latency -- DESIGN.md 7.)
   {
     uint32_t r = stream.s_first, c0 = 0, c1 = 0;
     if (r < S.n_long) c0 = S.long_ptr[r], c1 = S.long_ptr[r + 1];
-    RT pre[4];
+    // kLongStep records per lane starting at cell kb of an EC that ends at k1 (wave-uniform test
+    // first: whole 64-cell groups past the end cost nothing)
+    auto load_long = [&](uint32_t kb, uint32_t k1, RT(&dst)[kLongStep]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) pre[u] = c0 + lane + 64u * u < c1 ? R::load(S.rec_long, c0 + lane + 64u * u) : null_rec;
+      for (int u = 0; u < kLongStep; ++u) {
+        dst[u] = null_rec;
+        if (kb + 64u * u < k1 && kb + 64u * u + lane < k1) dst[u] = R::load(S.rec_long, kb + 64u * u + lane);
+      }
+    };
+    RT pre[kLongStep];
+    load_long(c0, c1, pre);
     while (r < S.n_long) {
       const uint32_t rn = r + stream.nw;
       uint32_t n0 = 0, n1 = 0;
       if (rn < S.n_long) n0 = S.long_ptr[rn], n1 = S.long_ptr[rn + 1];
       const double c = S.cvec[r];
-      RT first[4], rc[4];
+      RT first[kLongStep], rc[kLongStep];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) first[u] = rc[u] = pre[u];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) pre[u] = n0 + lane + 64u * u < n1 ? R::load(S.rec_long, n0 + lane + 64u * u) : null_rec;
+      for (int u = 0; u < kLongStep; ++u) first[u] = rc[u] = pre[u];
+      load_long(n0, n1, pre);
       double zs = 0.0, hs = 0.0;
-      for (uint32_t k = c0 + lane;;) {
-        double eg[4];
-        double2 t[4];
+      for (uint32_t kb = c0;;) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) eg[u] = E_(rc[u]), t[u] = XT_(rc[u]);
+        for (int q = 0; q < kLongStep; q += 4) {
+          if (kb + 64u * q < c1) {  // wave-uniform: quads past the end are skipped
+            double eg[4];
+            double2 t[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          zs = fma(eg[u], t[u].x, zs);
-          hs = fma(eg[u], t[u].y, hs);
+            for (int u = 0; u < 4; ++u) eg[u] = E_(rc[q + u]), t[u] = XT_(rc[q + u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              zs = fma(eg[u], t[u].x, zs);
+              hs = fma(eg[u], t[u].y, hs);
+            }
+          }
         }
-        k += 4 * 64;
-        if (k - lane >= c1) break;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) rc[u] = k + 64u * u < c1 ? R::load(S.rec_long, k + 64u * u) : null_rec;
+        kb += kLongStep * 64;
+        if (kb >= c1) break;
+        load_long(kb, c1, rc);
       }
       zs = wave_sum(zs);
       hs = wave_sum(hs);
@@ -607,17 +634,21 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
           s_W += rj;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rc[u] = first[u];
-        for (uint32_t k = c0 + lane;;) {
-          double xm[4];
+        for (int u = 0; u < kLongStep; ++u) rc[u] = first[u];
+        for (uint32_t kb = c0;;) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) xm[u] = XM_(rc[u]);
+          for (int q = 0; q < kLongStep; q += 4) {
+            if (kb + 64u * q < c1) {
+              double xm[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) addACC(rc[u], rj * xm[u]);
-          k += 4 * 64;
-          if (k - lane >= c1) break;
+              for (int u = 0; u < 4; ++u) xm[u] = XM_(rc[q + u]);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) rc[u] = k + 64u * u < c1 ? R::load(S.rec_long, k + 64u * u) : null_rec;
+              for (int u = 0; u < 4; ++u) addACC(rc[q + u], rj * xm[u]);
+            }
+          }
+          kb += kLongStep * 64;
+          if (kb >= c1) break;
+          load_long(kb, c1, rc);
         }
       }
       r = rn, c0 = n0, c1 = n1;
