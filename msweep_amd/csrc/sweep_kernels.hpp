@@ -323,36 +323,57 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   // reductions (no barrier)
   // (lanes past the end take a record of their own sentinel group)
   const RT null_rec = null_record<WIDE>(S.bhi + 8u * (G + (uint32_t)lane), shift);
-  for (uint32_t r = stream.s_first; r < S.n_long; r += stream.nw) {
-    AccA c = {0.0, 0.0, 0.0};
-    const uint32_t k1 = S.long_ptr[r + 1];
-    // LS records per lane in flight per step (with 4, a wavefront keeps 1 KB in flight and the
-    // path sits at its load latency: 2.7 TB/s of records whatever else it does; 8-byte records
-    // stay at 4: twice the registers)
-    constexpr int LS = WIDE ? 4 : kLongStep;
-    for (uint32_t kb = S.long_ptr[r]; kb < k1; kb += LS * 64) {
-      RT rc[LS];
+  // The wavefront's ECs are one sequence of steps of LS * 64 cells; the records of the NEXT step (of
+  // this EC or of the next one) are always in flight while a step is processed -- a step costs a
+  // full memory round trip otherwise, and a wavefront walks some sixty of them one after the other.
+  {
+    constexpr int LS = WIDE ? 4 : kLongStep;  // 8-byte records: twice the registers
+    auto load_long = [&](uint32_t kb, uint32_t k1, RT(&dst)[LS]) {
 #pragma unroll
       for (int u = 0; u < LS; ++u) {
-        rc[u] = null_rec;
-        if (kb + 64u * u < k1 && kb + 64u * u + lane < k1) rc[u] = R::load(S.rec_long, kb + 64u * u + lane);
+        dst[u] = null_rec;  // wave-uniform test first: whole 64-cell groups past the end cost nothing
+        if (kb + 64u * u < k1 && kb + 64u * u + lane < k1) dst[u] = R::load(S.rec_long, kb + 64u * u + lane);
       }
+    };
+    uint32_t r = stream.s_first, kb = 0, k1 = 0;
+    bool have = r < S.n_long;
+    if (have) kb = S.long_ptr[r], k1 = S.long_ptr[r + 1];
+    RT cur[LS], nxt[LS];
+    load_long(kb, k1, cur);
+    AccA c = {0.0, 0.0, 0.0};
+    while (have) {
+      // where the next step is
+      uint32_t nr = r, nkb = kb + LS * 64, nk1 = k1;
+      bool nhave = true;
+      if (nkb >= k1) {
+        nr = r + stream.nw;
+        nhave = nr < S.n_long;
+        nkb = nk1 = 0;
+        if (nhave) nkb = S.long_ptr[nr], nk1 = S.long_ptr[nr + 1];
+      }
+      load_long(nkb, nk1, nxt);
 #pragma unroll
       for (int q = 0; q < LS; q += 4) {
         if (kb + 64u * q < k1) {  // wave-uniform: quads past the end are skipped
           double2 a0[4], x0[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) a0[u] = EW_(rc[q + u]), x0[u] = XT_(rc[q + u]);
+          for (int u = 0; u < 4; ++u) a0[u] = EW_(cur[q + u]), x0[u] = XT_(cur[q + u]);
 #pragma unroll
           for (int u = 0; u < 4; ++u) cellA(c, p0, a0[u].x, a0[u].y, x0[u].x, x0[u].y);
         }
       }
-    }
-    const double zs = wave_sum(c.zs), t1 = wave_sum(c.t1), t2 = wave_sum(c.t2);
-    if (lane == 0) {
-      const double iZ = 1.0 / (zbase + zs);
-      const double S1 = (b1 + t1) * iZ, S2 = (b2 + t2) * iZ;
-      nn += S2 - S1 * S1;
+      if (nr != r) {  // that was the EC's last step
+        const double zs = wave_sum(c.zs), t1 = wave_sum(c.t1), t2 = wave_sum(c.t2);
+        if (lane == 0) {
+          const double iZ = 1.0 / (zbase + zs);
+          const double S1 = (b1 + t1) * iZ, S2 = (b2 + t2) * iZ;
+          nn += S2 - S1 * S1;
+        }
+        c = {0.0, 0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < LS; ++u) cur[u] = nxt[u];
+      r = nr, kb = nkb, k1 = nk1, have = nhave;
     }
   }
   nn = block_sum(nn, sh);
