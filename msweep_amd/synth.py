@@ -117,7 +117,7 @@ def make_dense_problem(n_ecs, n_groups, seed=1, zi=0.01, max_support=20):
     return dict(logl=L, logc=np.zeros(E), theta_true=theta, n_groups=G, n_ecs=E)
 
 
-def csr_to_targets(prob, seed=7):
+def csr_to_targets(prob, seed=7, shuffle=True):
     """Expand a CSR problem into the pseudoalignment form the reference starts from: for each
     EC the list of aligned target ids, plus target -> group indicators.  Targets of a group are
     scattered over the id space (group indicators need not be contiguous)."""
@@ -145,6 +145,8 @@ def csr_to_targets(prob, seed=7):
     cs = np.zeros(nnz + 1, np.int64)
     np.cumsum(cnt, out=cs[1:])
     tptr = cs[rowptr].astype(np.uint64)
+    if not shuffle:  # full-size inputs: the lexsort below costs more than everything else together
+        return dict(ec_tptr=tptr, ec_targets=targets, target_group=target_group.astype(np.uint32), n_targets=T)
     # shuffle targets inside each EC so group members are not adjacent
     E = len(rowptr) - 1
     ec_of = np.repeat(np.arange(E), np.diff(tptr.astype(np.int64)))

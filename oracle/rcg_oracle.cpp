@@ -342,6 +342,16 @@ struct CsrL {
   size_t G, E;
 };
 
+// The EC loops of the structured passes run over FIXED chunks of ECs (a function of E alone, not
+// of the thread count): every chunk keeps its own partial sums and the chunks are combined in
+// chunk order, so the result does not depend on OMP_NUM_THREADS and the full BASELINE sizes cost
+// minutes instead of hours on the test box.
+inline size_t n_chunks_of(size_t E) { return std::max<size_t>(1, std::min<size_t>(256, (E + 8191) / 8192)); }
+inline void chunk_range(size_t E, size_t nch, size_t c, size_t *j0, size_t *j1) {
+  *j0 = E * c / nch;
+  *j1 = E * (c + 1) / nch;
+}
+
 // B pass on CSR: returns Nc_g (without alpha) and the bound's data terms.
 void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double *Nc,
                 long double *bound_data, double *lse_out /*E or null*/) {
@@ -359,32 +369,48 @@ void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double
     xm[i] = x - p0;
     xTm[i] = x * S.lut[i] - p0 * S.logzi;
   }
-  std::vector<double> A(G, 0.0);
+  const double zbase = p0 * U, hbase = p0 * S.logzi * U;
+  const size_t nch = n_chunks_of(E);
+  std::vector<double> Apart(nch * G, 0.0), Wpart(nch, 0.0);
+  std::vector<long double> clogZ(nch, 0.0L), rH(nch, 0.0L);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (size_t ch = 0; ch < nch; ++ch) {
+    size_t j0, j1;
+    chunk_range(E, nch, ch, &j0, &j1);
+    double *A = Apart.data() + ch * G;
+    long double sum_clogZ = 0.0L, sum_rH = 0.0L;
+    double W = 0.0;
+    for (size_t j = j0; j < j1; ++j) {
+      double zs = 0.0, hs = 0.0;
+      for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
+        const double eg = e[S.grp[k]];
+        zs += eg * xm[S.lutidx[k]];
+        hs += eg * xTm[S.lutidx[k]];
+      }
+      const double Z = zbase + zs;
+      const double H = hbase + hs;
+      const double c = cvec[j];
+      const double r = c / Z;
+      if (lse_out) lse_out[j] = M + std::log(Z);
+      if (c != 0.0) {
+        sum_clogZ += (long double)c * std::log(Z);
+        sum_rH += (long double)r * H;
+      }
+      W += r;
+      for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) A[S.grp[k]] += r * xm[S.lutidx[k]];
+    }
+    clogZ[ch] = sum_clogZ;
+    rH[ch] = sum_rH;
+    Wpart[ch] = W;
+  }
   long double sum_clogZ = 0.0L, sum_rH = 0.0L;
   double W = 0.0;
-  const double zbase = p0 * U, hbase = p0 * S.logzi * U;
-  for (size_t j = 0; j < E; ++j) {
-    double zs = 0.0, hs = 0.0;
-    for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
-      const double eg = e[S.grp[k]];
-      zs += eg * xm[S.lutidx[k]];
-      hs += eg * xTm[S.lutidx[k]];
-    }
-    const double Z = zbase + zs;
-    const double H = hbase + hs;
-    const double c = cvec[j];
-    const double r = c / Z;
-    if (lse_out) lse_out[j] = M + std::log(Z);
-    if (c != 0.0) {
-      sum_clogZ += (long double)c * std::log(Z);
-      sum_rH += (long double)r * H;
-    }
-    W += r;
-    for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) A[S.grp[k]] += r * xm[S.lutidx[k]];
-  }
+  for (size_t ch = 0; ch < nch; ++ch) { sum_clogZ += clogZ[ch]; sum_rH += rH[ch]; W += Wpart[ch]; }
   long double mu = 0.0L;
   for (size_t g = 0; g < G; ++g) {
-    Nc[g] = e[g] * (p0 * W + A[g]);
+    double A = 0.0;
+    for (size_t ch = 0; ch < nch; ++ch) A += Apart[ch * G + g];
+    Nc[g] = e[g] * (p0 * W + A);
     mu += (long double)(M - st.u[g]) * Nc[g];
   }
   *bound_data = sum_clogZ + (long double)(1.0 - a) * sum_rH + mu;
@@ -422,71 +448,106 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
     D[i] = oma * (T - S.logzi);
   }
   const double zbase = p0 * U, b1 = p0 * V1c, b2 = p0 * V2c;
-  long double newnorm = 0.0L;
-  for (size_t j = 0; j < E; ++j) {
-    double zs = 0.0, t1 = 0.0, t2 = 0.0;
-    for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
-      const uint32_t g = S.grp[k], i = S.lutidx[k];
-      const double eg = e[g], wg = wc[g];
-      const double xm = x[i] - p0;
-      const double xD = x[i] * D[i];
-      const double wx = wg * xm;
-      zs += eg * xm;
-      t1 += eg * (xD + wx);
-      t2 += eg * (xD * D[i] + wg * (2.0 * xD + wx));
+  const size_t nch = n_chunks_of(E);
+  std::vector<long double> part(nch, 0.0L);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (size_t ch = 0; ch < nch; ++ch) {
+    size_t j0, j1;
+    chunk_range(E, nch, ch, &j0, &j1);
+    long double nn = 0.0L;
+    for (size_t j = j0; j < j1; ++j) {
+      double zs = 0.0, t1 = 0.0, t2 = 0.0;
+      for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
+        const uint32_t g = S.grp[k], i = S.lutidx[k];
+        const double eg = e[g], wg = wc[g];
+        const double xm = x[i] - p0;
+        const double xD = x[i] * D[i];
+        const double wx = wg * xm;
+        zs += eg * xm;
+        t1 += eg * (xD + wx);
+        t2 += eg * (xD * D[i] + wg * (2.0 * xD + wx));
+      }
+      const double iZ = 1.0 / (zbase + zs);
+      const double S1 = (b1 + t1) * iZ;
+      const double S2 = (b2 + t2) * iZ;
+      nn += (long double)(S2 - S1 * S1);
     }
-    const double iZ = 1.0 / (zbase + zs);
-    const double S1 = (b1 + t1) * iZ;
-    const double S2 = (b2 + t2) * iZ;
-    newnorm += (long double)(S2 - S1 * S1);
+    part[ch] = nn;
   }
+  long double newnorm = 0.0L;
+  for (size_t ch = 0; ch < nch; ++ch) newnorm += part[ch];
   return (double)newnorm;
 }
 
 // dense-L structured passes (rows = groups, G x E)
 void dense_pass_B(const double *L, size_t G, size_t E, const StructState &st,
                   const double *cvec, double *Nc, long double *bound_data) {
-  std::vector<double> Acc(G, 0.0);
-  long double bd = 0.0L;
-  std::vector<double> y(G), p(G);
-  for (size_t j = 0; j < E; ++j) {
-    double m = -std::numeric_limits<double>::infinity();
-    for (size_t g = 0; g < G; ++g) { y[g] = st.a * L[g * E + j] + st.u[g]; m = std::max(m, y[g]); }
-    double Z = 0.0, hs = 0.0;
-    for (size_t g = 0; g < G; ++g) {
-      p[g] = std::exp(y[g] - m);
-      Z += p[g];
-      hs += p[g] * (L[g * E + j] - (y[g] - m));
+  const size_t nch = n_chunks_of(E);
+  std::vector<double> Apart(nch * G, 0.0);
+  std::vector<long double> bpart(nch, 0.0L);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (size_t ch = 0; ch < nch; ++ch) {
+    size_t j0, j1;
+    chunk_range(E, nch, ch, &j0, &j1);
+    double *Acc = Apart.data() + ch * G;
+    long double bd = 0.0L;
+    std::vector<double> y(G), p(G);
+    for (size_t j = j0; j < j1; ++j) {
+      double m = -std::numeric_limits<double>::infinity();
+      for (size_t g = 0; g < G; ++g) { y[g] = st.a * L[g * E + j] + st.u[g]; m = std::max(m, y[g]); }
+      double Z = 0.0, hs = 0.0;
+      for (size_t g = 0; g < G; ++g) {
+        p[g] = std::exp(y[g] - m);
+        Z += p[g];
+        hs += p[g] * (L[g * E + j] - (y[g] - m));
+      }
+      const double c = cvec[j];
+      const double r = c / Z;
+      if (c != 0.0) bd += (long double)c * std::log(Z) + (long double)r * hs;
+      for (size_t g = 0; g < G; ++g) Acc[g] += r * p[g];
     }
-    const double c = cvec[j];
-    const double r = c / Z;
-    if (c != 0.0) bd += (long double)c * std::log(Z) + (long double)r * hs;
-    for (size_t g = 0; g < G; ++g) Acc[g] += r * p[g];
+    bpart[ch] = bd;
   }
-  for (size_t g = 0; g < G; ++g) Nc[g] = Acc[g];
+  long double bd = 0.0L;
+  for (size_t ch = 0; ch < nch; ++ch) bd += bpart[ch];
+  for (size_t g = 0; g < G; ++g) {
+    double A = 0.0;
+    for (size_t ch = 0; ch < nch; ++ch) A += Apart[ch * G + g];
+    Nc[g] = A;
+  }
   *bound_data = bd;
 }
 
 double dense_pass_A(const double *L, size_t G, size_t E, const StructState &st, const double *w) {
-  long double nn = 0.0L;
   const double oma = 1.0 - st.a;
-  std::vector<double> p(G), s(G);
-  for (size_t j = 0; j < E; ++j) {
-    double m = -std::numeric_limits<double>::infinity();
-    for (size_t g = 0; g < G; ++g) { p[g] = st.a * L[g * E + j] + st.u[g]; m = std::max(m, p[g]); }
-    double Z = 0.0, S1 = 0.0;
-    for (size_t g = 0; g < G; ++g) {
-      p[g] = std::exp(p[g] - m);
-      s[g] = oma * L[g * E + j] + w[g];
-      Z += p[g];
-      S1 += p[g] * s[g];
+  const size_t nch = n_chunks_of(E);
+  std::vector<long double> part(nch, 0.0L);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (size_t ch = 0; ch < nch; ++ch) {
+    size_t j0, j1;
+    chunk_range(E, nch, ch, &j0, &j1);
+    long double nn = 0.0L;
+    std::vector<double> p(G), s(G);
+    for (size_t j = j0; j < j1; ++j) {
+      double m = -std::numeric_limits<double>::infinity();
+      for (size_t g = 0; g < G; ++g) { p[g] = st.a * L[g * E + j] + st.u[g]; m = std::max(m, p[g]); }
+      double Z = 0.0, S1 = 0.0;
+      for (size_t g = 0; g < G; ++g) {
+        p[g] = std::exp(p[g] - m);
+        s[g] = oma * L[g * E + j] + w[g];
+        Z += p[g];
+        S1 += p[g] * s[g];
+      }
+      const double iZ = 1.0 / Z;
+      const double sbar = S1 * iZ;
+      double v = 0.0;
+      for (size_t g = 0; g < G; ++g) { const double d = s[g] - sbar; v += p[g] * d * d; }
+      nn += (long double)(v * iZ);
     }
-    const double iZ = 1.0 / Z;
-    const double sbar = S1 * iZ;
-    double v = 0.0;
-    for (size_t g = 0; g < G; ++g) { const double d = s[g] - sbar; v += p[g] * d * d; }
-    nn += (long double)(v * iZ);
+    part[ch] = nn;
   }
+  long double nn = 0.0L;
+  for (size_t ch = 0; ch < nch; ++ch) nn += part[ch];
   return (double)nn;
 }
 
