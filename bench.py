@@ -8,11 +8,14 @@ region.  A "step" = ONE RCG iteration of the hot path over the whole likelihood:
 digamma / Fletcher-Reeves / bound kernels.  `value` = cells of the EC x group likelihood matrix
 the reference would hold (E * G) processed per second, summed over all ranks.
 
-N > 1 (one process per GPU, launched by torch.distributed.run): the path shards over bootstrap
-replicates (src/mSWEEP.cpp:496-518, independent solves on the same likelihood): rank r runs K
-iterations on replicate r's resampled EC counts -- no data-path collective; the per-replicate
-abundances are exchanged with one RCCL all-gather at the end (inside the timed region).
-Scaling is "weak" (per-GPU work fixed).
+N > 1 (one process per GPU): the path shards over bootstrap replicates (src/mSWEEP.cpp:496-518,
+independent solves on the same likelihood): rank r runs K iterations on replicate r's resampled EC
+counts -- no data-path collective; the per-replicate abundances are exchanged with one RCCL
+all-gather at the end (msw_comm_allgather, inside the timed region).  Scaling is "weak" (per-GPU
+work fixed).  Launched either by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+the environment) or plainly as `python bench.py --gpus N`: the parent then starts the N rank
+processes itself BEFORE anything touches the GPU (it never initialises HIP), relays rank 0's line
+and exits non-zero if any rank fails.
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+TRAFFIC_JSON = "r01_traffic_pmc_v7.json"  # HBM bytes per launch of the sweeps (rocprofv3 PMC, committed)
 
 
 def parse():
@@ -39,8 +43,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the EM and time-to-convergence runs after the timed region (profiling runs)")
-    ap.add_argument("--cpu-sample-ecs", type=int, default=50000)
-    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--cpu-sample-ecs", type=int, default=500_000)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="(tests) exercise the rank launcher and the rendezvous on CPU/gloo only: no GPU, no workload")
     ap.add_argument("--mode", choices=["replicates", "shard"], default="replicates",
                     help="N > 1: 'replicates' = one bootstrap replicate per GPU (weak scaling, default); "
                          "'shard' = ONE solve with the ECs sharded over the GPUs, RCCL all-reduce of the "
@@ -48,6 +54,33 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed / RCCL even with one rank (exercises the N > 1 code path)")
     return ap.parse_args()
+
+
+def cpu_share():
+    """CPUs this process may really use: the cgroup quota when there is one (a GPU box exposes all its
+    logical CPUs but grants a share), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_info():
+    info = {"logical_cpus": os.cpu_count(), "usable_cpus": cpu_share()}
+    try:
+        txt = open("/proc/cpuinfo").read()
+        models = [ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("model name")]
+        phys = {ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("physical id")}
+        cores = [ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("cpu cores")]
+        info["model"] = models[0] if models else None
+        info["sockets_x_cores"] = f"{max(len(phys), 1)} x {cores[0]}" if cores else None
+    except OSError:
+        pass
+    return info
 
 
 def cpu_baseline(prob, lut, n_ecs, iters):
@@ -66,16 +99,23 @@ def cpu_baseline(prob, lut, n_ecs, iters):
     rows = np.repeat(np.arange(E), np.diff(rp[:E + 1]))
     L[prob["grp"][:nz], rows] = lut[prob["grp"][:nz], prob["cnt"][:nz]]
     logc = np.log(prob["ec_counts"][:E].astype(float))
-    cores = min(O.num_threads(), os.cpu_count() or 1)
+    cores = cpu_share()
     O.set_num_threads(cores)
-    O.rcg_optl_dense(L, logc, np.ones(G), tol=0.0, max_iters=1)  # touch pages / warm up
+    # per-iteration time = (run of `iters` + 1 iterations) - (run of 1 iteration): the one-off cost of
+    # allocating and first-touching the three G x E state matrices is not an iteration
     t0 = time.perf_counter()
-    r = O.rcg_optl_dense(L, logc, np.ones(G), tol=-1.0, max_iters=iters)
-    dt = time.perf_counter() - t0
-    return {"value": E * G * r["iters"] / dt, "unit": "cells/s", "cores": cores, "kind": "port",
-            "sample": f"first {E} ECs of the cfg3 workload x {G} groups as a dense fp64 matrix, "
-                      f"{r['iters']} RCG iterations of the dense-state restatement (4 G x E matrices), "
-                      f"{dt:.1f} s; iters/s on the sample = {r['iters'] / dt:.3f}"}
+    O.rcg_optl_dense(L, logc, np.ones(G), tol=-1.0, max_iters=1)
+    t1 = time.perf_counter()
+    r = O.rcg_optl_dense(L, logc, np.ones(G), tol=-1.0, max_iters=iters + 1)
+    t2 = time.perf_counter()
+    dt = max((t2 - t1) - (t1 - t0), 1e-9)
+    out = {"value": E * G * iters / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+           "sample": f"first {E} ECs of the cfg3 workload x {G} groups as a dense fp64 matrix "
+                     f"({E * G * 8 / 1e9:.1f} GB; the reference's four G x E matrices), {iters} RCG iterations of "
+                     f"the dense-state restatement of rcgpar::rcg_optl_omp on {cores} OpenMP threads, {dt:.1f} s "
+                     f"(+ {t1 - t0:.1f} s for set-up and one iteration); iters/s on the sample = {iters / dt:.3f}",
+           "cpu": cpu_info()}
+    return out
 
 
 def cpu_baseline_structured(prob, lut, iters):
@@ -89,13 +129,20 @@ def cpu_baseline_structured(prob, lut, iters):
     E = len(prob["rowptr"]) - 1
     lutidx = (prob["grp"].astype(np.uint32) * lut.shape[1] + prob["cnt"]).astype(np.uint32)
     logc = np.log(prob["ec_counts"].astype(float))
+    cores = cpu_share()
+    O.set_num_threads(cores)
     t0 = time.perf_counter()
+    O.rcg_optl_csr(prob["rowptr"], prob["grp"], lutidx, lut, np.log(0.01), G, logc, np.ones(G), tol=-1.0, max_iters=1)
+    t1 = time.perf_counter()
     r = O.rcg_optl_csr(prob["rowptr"], prob["grp"], lutidx, lut, np.log(0.01), G, logc, np.ones(G), tol=-1.0,
-                       max_iters=iters)
-    dt = time.perf_counter() - t0
-    return {"value": float(E) * G * r["iters"] / dt, "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": f"full cfg3 workload, {r['iters']} iterations of the structured CSR restatement "
-                      f"(oracle/rcg_oracle.cpp orc_rcg_optl_csr), {dt:.1f} s; iters/s = {r['iters'] / dt:.3f}"}
+                       max_iters=iters + 1)
+    t2 = time.perf_counter()
+    dt = max((t2 - t1) - (t1 - t0), 1e-9)
+    return {"value": float(E) * G * iters / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+            "listed_cells_per_sec": float(len(prob["grp"])) * iters / dt,
+            "sample": f"full cfg3 workload, {iters} iterations of the structured CSR restatement "
+                      f"(oracle/rcg_oracle.cpp orc_rcg_optl_csr: the O(nnz) algorithm the GPU runs) on {cores} "
+                      f"OpenMP threads, {dt:.1f} s; iters/s = {iters / dt:.3f}"}
 
 
 def log(msg):
@@ -103,11 +150,60 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters,
+    one GPU each) from a parent that never touches the GPU, relay rank 0's JSON line, and fail if any
+    rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        sys.exit(1)
+    sys.exit(0)
+
+
+def launch_selftest(a, rank, world):
+    """CPU-only rehearsal of the launcher + rendezvous (tests/test_parallel_cpu.py): gloo, no GPU."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "gathered": [float(x.item()) for x in out]}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        launch_ranks(a)          # never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:          # before anything touches the GPU
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch {a.gpus} ranks "
+                 f"(plain `python bench.py --gpus {a.gpus}` starts them itself)")
+    if a.launch_selftest:
+        return launch_selftest(a, rank, world)
     dist = None
     if world > 1 or a.force_dist:
         import torch
@@ -116,8 +212,6 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if a.gpus != world and world > 1 and rank == 0:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     n_gpus = world
 
     import numpy as np
@@ -136,12 +230,19 @@ def main():
     core = Core(local_rank)
     shard = dist is not None and a.mode == "shard"
     comm = None
-    if shard:
+    rccl_ranks = None
+    if dist is not None:
+        # the library's own RCCL communicator (C ABI: msw_comm_create_rccl); torch.distributed only
+        # carries the unique id and the barriers around the timed region
         from msweep_amd.core import Comm
-        from msweep_amd.parallel import csr_block, shard_ecs
         uid = [Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = Comm.rccl(uid[0], rank, world, local_rank)
+        rccl_ranks = comm.rccl_count()     # ncclCommCount
+        if rccl_ranks != world:
+            sys.exit(f"bench.py: RCCL communicator spans {rccl_ranks} ranks, expected {world}")
+    if shard:
+        from msweep_amd.parallel import csr_block, shard_ecs
         b = shard_ecs(prob["rowptr"], world)
         blk = csr_block(prob, b[rank], b[rank + 1])
         lik = from_grouped_counts(core, blk["rowptr"], blk["grp"], blk["cnt"], blk["ec_counts"], prob["group_sizes"])
@@ -163,6 +264,17 @@ def main():
     else:
         logc = lik.log_counts()
     log("likelihood resident")
+    # SURVEY 8(d), second figure, measured FIRST: time to convergence at the reference's defaults
+    # (--tol 1e-6, --max-iters 5000), host inputs handed over per call as at the reference's boundary
+    # (PCIe-inclusive).  Two hundred iterations of the same sweeps: the timed region below then starts
+    # on a GPU that is already at its working clocks, as it is in any real run of the path.
+    conv = None
+    if not shard and not a.no_extras:
+        t1 = time.perf_counter()
+        rc = core.solve(logc, alpha0, tol=1e-6, max_iters=5000)
+        t_conv = time.perf_counter() - t1
+        conv = {"iters": int(rc["iters"]), "ms": t_conv * 1e3, "device_ms": core.last_timing()["solve_ms"],
+                "tol": 1e-6, "includes": "upload of log counts and prior, download of theta"}
     core.set_fixed_iters(True)
     core.prepare(logc, alpha0)               # inputs resident in HBM before the timed region
     core.run(max_iters=max(a.warmup, 1))     # W untimed warm-up steps
@@ -181,11 +293,8 @@ def main():
     t0 = time.perf_counter()
     res = core.run(max_iters=a.steps)         # exactly K steps
     if dist is not None and not shard:
-        import torch
-        th = torch.from_numpy(res["theta"]).cuda()
-        out = [torch.empty_like(th) for _ in range(world)]
-        dist.all_gather(out, th)
-        torch.cuda.synchronize()
+        gathered = comm.allgather(res["theta"])   # (world, G): the per-replicate abundances, RCCL all-gather
+        assert gathered.shape == (world, G)
     sync()
     dt = time.perf_counter() - t0
     tm0 = core.last_timing()
@@ -208,17 +317,6 @@ def main():
         core.run(max_iters=a.steps, algo=ALGO_EM)
         t_em = time.perf_counter() - t1
         em = {"ms_per_step": t_em * 1e3 / a.steps, "iters_per_sec": a.steps / t_em}
-    # SURVEY 8(d), second figure: time to convergence at the reference's defaults (--tol 1e-6,
-    # --max-iters 5000), host inputs handed over per call as at the reference's boundary (PCIe-inclusive)
-    conv = None
-    if not shard and not a.no_extras:
-        core.set_fixed_iters(False)
-        t1 = time.perf_counter()
-        rc = core.solve(logc, alpha0, tol=1e-6, max_iters=5000)
-        t_conv = time.perf_counter() - t1
-        conv = {"iters": int(rc["iters"]), "ms": t_conv * 1e3, "device_ms": core.last_timing()["solve_ms"],
-                "tol": 1e-6, "includes": "upload of log counts and prior, download of theta"}
-        core.set_fixed_iters(True)
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64).cuda()
@@ -233,11 +331,12 @@ def main():
         achieved = b_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
         # collected offline on this exact workload and committed under profiles/
-        traffic = None
+        traffic, traffic_src = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc_v7.json")))
-            if (a.reads, G, a.seed) == (10_000_000, 5000, 2) and n_gpus == 1:  # the profiled workload
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))
+            if (a.reads, G, a.seed) == (10_000_000, 5000, 2):  # the profiled workload
                 traffic = next(v["hbm_bytes_per_launch"] for k, v in tj.items() if dom in k)
+                traffic_src = f"profiles/{TRAFFIC_JSON} (offline rocprofv3 --pmc passes on this workload, not this run)"
         except Exception:
             traffic = None
         line = {
@@ -248,17 +347,21 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg3: synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB "
                                    "(--algorithm rcggpu), fixed iteration count",
-                       "reads": a.reads, "groups": G, "ecs": E, "nnz": nnz, "seed": a.seed,
+                       "algorithm": "rcg", "reads": a.reads, "groups": G, "ecs": E, "nnz": nnz, "seed": a.seed,
                        "sharding": "single solve" if n_gpus == 1 else (
                            f"one solve, ECs sharded over {n_gpus} GPUs, RCCL all-reduce of (G+4) fp64 per iteration"
                            if shard else f"bootstrap replicates, 1 per GPU x {n_gpus}")},
             "iters_per_sec": a.steps * (1 if shard else n_gpus) / dt,
+            "listed_cells_per_sec": float(nnz) * a.steps * (1 if shard else n_gpus) / dt,
+            "value_counts": "logical EC x group cells of the matrix the reference holds (E * G per iteration); "
+                            "listed_cells_per_sec counts the cells the CSR-of-ECs form stores (nnz per iteration)",
+            "rccl_ranks": rccl_ranks,
             "reads_x_groups_cells_per_sec": float(a.reads) * G * a.steps * (1 if shard else n_gpus) / dt,
             "device_ms_per_step": tm0["solve_ms"] / a.steps,
             "kernels": {"k_passA_ms": msA, "k_passB_ms": msB, "passA_launches": tm["passA_launches"],
                         "passB_launches": tm["passB_launches"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_dom, "avg_launch_ms": ms_dom},
             "setup_s": {"generate": t_gen},
         }
@@ -275,14 +378,16 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {ex}"}
             try:
-                line["cpu_baseline_structured"] = cpu_baseline_structured(prob, precalc_lls(prob["group_sizes"]), 3)
+                line["cpu_baseline_structured"] = cpu_baseline_structured(prob, precalc_lls(prob["group_sizes"]), 5)
             except Exception as ex:
                 line["cpu_baseline_structured"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port",
                                                    "sample": f"failed: {ex}"}
         print(json.dumps(line), flush=True)
+    core.set_comm(None) if shard else None
     core.close()
     if dist is not None:
         dist.barrier()
+        comm.close()
         dist.destroy_process_group()
 
 

@@ -144,6 +144,22 @@ int msw_core_bootstrap(msw_handle h, const uint32_t *ec_counts, int32_t seed,
                        const double *alpha0, double tol, size_t max_iters, int algo,
                        int prec, double *theta_out, size_t *iters_out);
 
+/* The whole replicate loop of src/mSWEEP.cpp:496-518 over the GPUs of one node: rank r of `comm`
+ * (msw_comm_create_rccl: one process per GPU; msw_comm_create_local: thread-ranks) solves the contiguous
+ * block [n_replicates * r / P, n_replicates * (r + 1) / P) of the one sequential stream and ONE all-gather
+ * (RCCL over xGMI) leaves the complete n_replicates x G block in replicate order -- the rows
+ * 1..n_replicates of bootstrap_results (include/Sample.hpp:157,180) -- on EVERY rank; results do not
+ * depend on the number of ranks.  Every rank holds the same resident likelihood and passes the same
+ * arguments.  iters_out[n_replicates] optional. */
+struct msw_comm;
+int msw_core_bootstrap_dist(msw_handle h, struct msw_comm *comm, const uint32_t *ec_counts, int32_t seed,
+                            size_t bootstrap_count, size_t n_replicates, const double *alpha0, double tol,
+                            size_t max_iters, int algo, int prec, double *theta_out, size_t *iters_out);
+
+/* msw_core_bootstrap and msw_core_bootstrap_dist solve the replicates on solver states of their own:
+ * msw_core_gamma / msw_core_trace afterwards still describe the last msw_core_solve on the handle (the
+ * reference writes the probabilities of the un-resampled estimate, src/mSWEEP.cpp:437-493). */
+
 /* Only the resampling step: counts_out is (rep_end-rep_begin) x E uint32, bit-exact with
  * std::discrete_distribution<uint32_t> driven by std::mt19937_64(seed). */
 int msw_core_resample_counts(msw_handle h, const uint32_t *ec_counts, size_t n_ecs,
@@ -166,6 +182,14 @@ int msw_comm_unique_id(unsigned char id_out[128]);
 int msw_comm_create_rccl(const unsigned char id[128], int rank, int nranks, int device, msw_comm_t *out);
 int msw_comm_create_local(int nranks, msw_comm_t *out);
 void msw_comm_destroy(msw_comm_t c);
+/* ranks of the communicator and this rank's index (either pointer may be NULL) */
+int msw_comm_size(msw_comm_t c, int *nranks, int *rank);
+/* what RCCL itself reports for the communicator (ncclCommCount); 0 for an in-process communicator */
+int msw_comm_rccl_count(msw_comm_t c, int *count);
+/* recv[r * n .. (r + 1) * n) = rank r's send[0 .. n); host buffers, blocking (ncclAllGather through
+ * device staging buffers).  The exchange step of the bootstrap (src/mSWEEP.cpp:513-517 stores every
+ * replicate's abundances in one table, include/Sample.hpp:157). */
+int msw_comm_allgather(msw_comm_t c, const double *send, size_t n, double *recv);
 /* comm == NULL detaches.  The communicator must outlive the solves that use it. */
 int msw_core_set_comm(msw_handle h, msw_comm_t comm);
 /* last error text of the msw_comm_* calls of this thread */

@@ -26,7 +26,8 @@ EXPORTS = [
     "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
     "msw_core_set_fixed_iters", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
-    "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error",
+    "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
+    "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather",
 ]
 
 
@@ -74,6 +75,10 @@ def load_library():
     L.msw_core_set_trace_theta.argtypes = [vp, sz]
     L.msw_core_bootstrap.argtypes = [vp, vp, C.c_int32, sz, sz, sz, vp, dp, sz, C.c_int, C.c_int, vp, vp]
     L.msw_core_resample_counts.argtypes = [vp, vp, sz, C.c_int32, sz, sz, sz, vp]
+    L.msw_core_bootstrap_dist.argtypes = [vp, vp, vp, C.c_int32, sz, sz, vp, dp, sz, C.c_int, C.c_int, vp, vp]
+    L.msw_comm_size.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.msw_comm_rccl_count.argtypes = [vp, C.POINTER(C.c_int)]
+    L.msw_comm_allgather.argtypes = [vp, vp, sz, vp]
     L.msw_core_set_profiling.argtypes = [vp, C.c_int]
     L.msw_core_set_fixed_iters.argtypes = [vp, C.c_int]
     L.msw_core_last_timing.argtypes = [vp, C.POINTER(Timing)]
@@ -286,6 +291,23 @@ class Core:
                                                int(max_iters), int(algo), int(prec), _ptr(theta), _ptr(iters)))
         return theta, iters
 
+    def bootstrap_dist(self, comm, ec_counts, seed, bootstrap_count, n_replicates, alpha0, tol=1e-6,
+                       max_iters=5000, algo=ALGO_RCG, prec=PREC_DOUBLE):
+        """msw_core_bootstrap_dist: all replicates over the ranks of `comm`; every rank gets the whole
+        n_replicates x G table (replicate order) and the iteration counts."""
+        G, E, _ = self.shape()
+        ec_counts = _arr(ec_counts, np.uint32)
+        alpha0 = _arr(alpha0, np.float64)
+        if len(ec_counts) != E or len(alpha0) != G:
+            raise MswError("bootstrap_dist: ec_counts / alpha0 length mismatch")
+        n = int(n_replicates)
+        theta = np.empty((n, G))
+        iters = np.zeros(n, np.uint64)
+        self._check(self._L.msw_core_bootstrap_dist(self._h, comm._c, _ptr(ec_counts), int(seed),
+                                                    int(bootstrap_count), n, _ptr(alpha0), float(tol),
+                                                    int(max_iters), int(algo), int(prec), _ptr(theta), _ptr(iters)))
+        return theta, iters
+
     def resample_counts(self, ec_counts, seed, bootstrap_count, rep_begin, rep_end):
         ec_counts = _arr(ec_counts, np.uint32)
         n = int(rep_end) - int(rep_begin)
@@ -347,6 +369,27 @@ class Comm:
         if L.msw_comm_create_local(int(nranks), arr) != 0:
             raise MswError(L.msw_comm_last_error().decode())
         return [cls(C.c_void_p(arr[i])) for i in range(nranks)]
+
+    def size(self):
+        n, r = C.c_int(), C.c_int()
+        if self._L.msw_comm_size(self._c, C.byref(n), C.byref(r)) != 0:
+            raise MswError(self._L.msw_comm_last_error().decode())
+        return n.value, r.value
+
+    def rccl_count(self):
+        """ncclCommCount of the communicator (0 for an in-process one)."""
+        n = C.c_int()
+        if self._L.msw_comm_rccl_count(self._c, C.byref(n)) != 0:
+            raise MswError(self._L.msw_comm_last_error().decode())
+        return n.value
+
+    def allgather(self, send):
+        """(nranks, len(send)) array: row r = rank r's `send` (host buffers; ncclAllGather underneath)."""
+        send = _arr(send, np.float64).ravel()
+        out = np.empty((self.size()[0], len(send)))
+        if self._L.msw_comm_allgather(self._c, _ptr(send), len(send), _ptr(out)) != 0:
+            raise MswError(self._L.msw_comm_last_error().decode())
+        return out
 
     def close(self):
         if self._c and self._owner:

@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <cstring>
 #include <memory>
 #include <mutex>
 
@@ -22,6 +23,13 @@ struct msw_comm {
   virtual int size() const = 0;
   // in-place sum over ranks of n doubles in device memory, ordered on `stream`
   virtual void allreduce(double *dev, size_t n, hipStream_t stream) = 0;
+  // the same for unsigned 64-bit integers (group hit counts of the sharded likelihood build)
+  virtual void allreduce_u64(uint64_t *dev, size_t n, hipStream_t stream) = 0;
+  // recv[r * n .. (r + 1) * n) = rank r's send[0 .. n); HOST buffers (the bootstrap abundances live on
+  // the host: include/Sample.hpp:157), blocking
+  virtual void allgather_host(const double *send, size_t n, double *recv) = 0;
+  // a rank that fails outside a collective calls this so that its peers do not wait for ever
+  virtual void abort() {}
 };
 
 namespace msw {
@@ -42,6 +50,32 @@ struct RcclComm final : msw_comm {
     const ncclResult_t rc = ncclAllReduce(dev, dev, cnt, ncclDouble, ncclSum, comm, stream);
     if (rc != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
   }
+  void allreduce_u64(uint64_t *dev, size_t cnt, hipStream_t stream) override {
+    const ncclResult_t rc = ncclAllReduce(dev, dev, cnt, ncclUint64, ncclSum, comm, stream);
+    if (rc != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
+  }
+  void allgather_host(const double *send, size_t cnt, double *recv) override {
+    DevBuf<double> s, d;
+    s.alloc(cnt);
+    d.alloc(cnt * (size_t)n);
+    hipStream_t st;
+    MSW_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    try {
+      MSW_HIP(hipMemcpyAsync(s.p, send, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+      const ncclResult_t rc = ncclAllGather(s.p, d.p, cnt, ncclDouble, comm, st);
+      if (rc != ncclSuccess) throw HipError(std::string("ncclAllGather: ") + ncclGetErrorString(rc));
+      MSW_HIP(hipMemcpyAsync(recv, d.p, cnt * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+      MSW_HIP(hipStreamSynchronize(st));
+    } catch (...) {
+      (void)hipStreamDestroy(st);
+      throw;
+    }
+    (void)hipStreamDestroy(st);
+  }
+  int count() const {  // what RCCL itself says the communicator spans
+    int c = 0;
+    return ncclCommCount(comm, &c) == ncclSuccess ? c : -1;
+  }
 };
 
 struct LocalGroup {
@@ -50,18 +84,27 @@ struct LocalGroup {
   std::condition_variable cv;
   int arrived = 0;
   uint64_t generation = 0;
+  bool failed = false;  // a rank gave up: every waiter (now and later) fails instead of blocking
   std::vector<std::vector<double>> stage;
-  explicit LocalGroup(int n_) : n(n_), stage(n_) {}
+  std::vector<const double *> gather_src;
+  explicit LocalGroup(int n_) : n(n_), stage(n_), gather_src(n_, nullptr) {}
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
+    if (failed) throw HipError("LocalComm: another rank of the group failed");
     const uint64_t g = generation;
     if (++arrived == n) {
       arrived = 0;
       ++generation;
       cv.notify_all();
     } else {
-      cv.wait(lk, [&] { return generation != g; });
+      cv.wait(lk, [&] { return generation != g || failed; });
+      if (generation == g) throw HipError("LocalComm: another rank of the group failed");
     }
+  }
+  void fail() {
+    std::lock_guard<std::mutex> lk(mu);
+    failed = true;
+    cv.notify_all();
   }
 };
 
@@ -71,20 +114,36 @@ struct LocalComm final : msw_comm {
   LocalComm(std::shared_ptr<LocalGroup> g, int rank_) : grp(std::move(g)), r(rank_) {}
   int rank() const override { return r; }
   int size() const override { return grp->n; }
-  void allreduce(double *dev, size_t cnt, hipStream_t stream) override {
+  void abort() override { grp->fail(); }
+  // T = double: summed in rank order; T = uint64_t: exact
+  template <class T>
+  void allreduce_t(T *dev, size_t cnt, hipStream_t stream) {
+    static_assert(sizeof(T) == sizeof(double), "staged as 8-byte words");
     std::vector<double> &mine = grp->stage[r];
     mine.resize(cnt);
-    MSW_HIP(hipMemcpyAsync(mine.data(), dev, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+    MSW_HIP(hipMemcpyAsync(mine.data(), dev, cnt * sizeof(T), hipMemcpyDeviceToHost, stream));
     MSW_HIP(hipStreamSynchronize(stream));
     grp->barrier();
-    std::vector<double> sum(cnt, 0.0);
+    std::vector<T> sum(cnt, T(0));
+    bool same = true;
     for (int k = 0; k < grp->n; ++k) {
-      if (grp->stage[k].size() != cnt) throw HipError("LocalComm: ranks disagree on the message size");
-      for (size_t i = 0; i < cnt; ++i) sum[i] += grp->stage[k][i];
+      same = same && grp->stage[k].size() == cnt;
+      if (!same) break;
+      const T *src = reinterpret_cast<const T *>(grp->stage[k].data());
+      for (size_t i = 0; i < cnt; ++i) sum[i] += src[i];
     }
-    grp->barrier();  // everyone has read the staging buffers
-    MSW_HIP(hipMemcpyAsync(dev, sum.data(), cnt * sizeof(double), hipMemcpyHostToDevice, stream));
+    grp->barrier();  // everyone has read the staging buffers (and reached the same verdict on the sizes)
+    if (!same) throw HipError("LocalComm: ranks disagree on the message size");
+    MSW_HIP(hipMemcpyAsync(dev, sum.data(), cnt * sizeof(T), hipMemcpyHostToDevice, stream));
     MSW_HIP(hipStreamSynchronize(stream));
+  }
+  void allreduce(double *dev, size_t cnt, hipStream_t stream) override { allreduce_t(dev, cnt, stream); }
+  void allreduce_u64(uint64_t *dev, size_t cnt, hipStream_t stream) override { allreduce_t(dev, cnt, stream); }
+  void allgather_host(const double *send, size_t cnt, double *recv) override {
+    grp->gather_src[r] = send;
+    grp->barrier();
+    for (int k = 0; k < grp->n; ++k) std::memcpy(recv + (size_t)k * cnt, grp->gather_src[k], cnt * sizeof(double));
+    grp->barrier();  // every rank has copied: the send buffers may go
   }
 };
 

@@ -138,6 +138,7 @@ int guarded(msw_handle h, F &&f) {
   } catch (const std::exception &ex) {
     h->err = ex.what();
     (void)hipGetLastError();
+    if (h->comm) h->comm->abort();  // peers of a sharded solve must not wait for this rank for ever
     return 1;
   }
 }
@@ -767,7 +768,54 @@ int msw_core_resample_counts(msw_handle h, const uint32_t *ec_counts, size_t n_e
   });
 }
 
+int msw_core_bootstrap_dist(msw_handle h, msw_comm_t comm, const uint32_t *ec_counts, int32_t seed,
+                            size_t bootstrap_count, size_t n_replicates, const double *alpha0, double tol,
+                            size_t max_iters, int algo, int prec, double *theta_out, size_t *iters_out) {
+  const int rc = guarded(h, [&] {
+    bootstrap_dist_impl(h, comm, ec_counts, seed, bootstrap_count, n_replicates, alpha0, tol, max_iters, algo,
+                        prec, theta_out, iters_out);
+  });
+  if (rc && comm) comm->abort();
+  return rc;
+}
+
 const char *msw_comm_last_error(void) { return g_create_error.c_str(); }
+
+int msw_comm_size(msw_comm_t c, int *nranks, int *rank) {
+  if (!c) {
+    g_create_error = "msw_comm_size: null communicator";
+    return 1;
+  }
+  if (nranks) *nranks = c->size();
+  if (rank) *rank = c->rank();
+  return 0;
+}
+
+int msw_comm_rccl_count(msw_comm_t c, int *count) {
+  if (!c || !count) {
+    g_create_error = "msw_comm_rccl_count: null argument";
+    return 1;
+  }
+  const RcclComm *rc = dynamic_cast<const RcclComm *>(c);
+  *count = rc ? rc->count() : 0;
+  return 0;
+}
+
+int msw_comm_allgather(msw_comm_t c, const double *send, size_t n, double *recv) {
+  if (!c || (n && (!send || !recv))) {
+    g_create_error = "msw_comm_allgather: null argument";
+    return 1;
+  }
+  try {
+    c->allgather_host(send, n, recv);
+    return 0;
+  } catch (const std::exception &ex) {
+    g_create_error = ex.what();
+    (void)hipGetLastError();
+    c->abort();
+    return 1;
+  }
+}
 
 int msw_comm_unique_id(unsigned char id_out[128]) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");

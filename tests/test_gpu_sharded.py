@@ -93,3 +93,66 @@ def test_rccl_transport_single_rank(gpu_core):
         comm.close()
     assert sharded["iters"] == plain["iters"]
     assert_theta(sharded["theta"], plain["theta"])
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_bootstrap_dist_gathers_every_replicate_on_every_rank(gpu_core, n_ranks):
+    """msw_core_bootstrap_dist (the replicate loop of src/mSWEEP.cpp:496-518 over the GPUs of a node):
+    thread-ranks with the in-process communicator; every rank ends with the whole B x G table in
+    replicate order, equal to the single-handle run whatever the number of ranks."""
+    p = synth.make_csr_problem(30000, 80, seed=44, max_other=6)
+    G, B = 80, 7                                     # 7 replicates over 2 / 3 ranks: ragged blocks
+    alpha0 = np.ones(G)
+    w = p["ec_counts"].astype(np.uint32)
+    draws = int(w.sum())
+    from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    single, it_single = gpu_core.bootstrap(w, 42, draws, 0, B, alpha0)
+    comms = Comm.local(n_ranks)
+    out, err = [None] * n_ranks, []
+
+    def work(r):
+        try:
+            core = Core(0)
+            from_grouped_counts(core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+            out[r] = core.bootstrap_dist(comms[r], w, 42, draws, B, alpha0)
+            assert comms[r].size() == (n_ranks, r) and comms[r].rccl_count() == 0
+            core.close()
+        except Exception as ex:
+            err.append(ex)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not err, err
+    for r in range(n_ranks):
+        theta, iters = out[r]
+        assert theta.shape == (B, G)
+        np.testing.assert_array_equal(theta, out[0][0])          # the gathered table is the same everywhere
+        np.testing.assert_array_equal(iters, it_single)
+        for b in range(B):
+            assert_theta(theta[b], single[b])
+
+
+def test_bootstrap_leaves_the_original_estimate_on_the_handle(gpu_core):
+    """The reference writes the probabilities of the UN-resampled estimate (src/mSWEEP.cpp:437-493 come
+    before the replicate loop at :496): msw_core_gamma after msw_core_bootstrap still describes it."""
+    p = synth.make_csr_problem(5000, 30, seed=45, max_other=4)
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    res = gpu_core.solve(lik.log_counts(), np.ones(30))
+    g0 = gpu_core.gamma()
+    w = p["ec_counts"].astype(np.uint32)
+    gpu_core.bootstrap(w, 3, int(w.sum()), 0, 3, np.ones(30))
+    np.testing.assert_array_equal(gpu_core.gamma(), g0)
+    assert gpu_core.trace(res["iters"])["n"] == res["iters"]
+
+
+def test_rccl_allgather_single_rank():
+    comm = Comm.rccl(Comm.unique_id(), 0, 1, 0)
+    try:
+        assert comm.size() == (1, 0) and comm.rccl_count() == 1
+        x = np.arange(5, dtype=np.float64)
+        np.testing.assert_array_equal(comm.allgather(x), x[None, :])
+    finally:
+        comm.close()

@@ -53,3 +53,86 @@ def test_world2_gloo_matches_single_process(n_rep):
     np.testing.assert_array_equal(res[0], single)
     np.testing.assert_array_equal(res[1], single)
     np.testing.assert_array_equal(all_gather_rows(single, n_rep), single)
+
+
+# ---- the EC-sharded exchange: one scalar after pass A, one (G + 4)-vector after
+# pass B, summed over the ranks.  Two gloo processes hold one EC block each (parallel.shard_ecs /
+# csr_block, what bench.py --mode shard and tests/test_gpu_sharded.py hand to the handles) and form the
+# per-block terms of one structured pass B in numpy; the all-reduced vector must equal the unsharded one.
+def _pass_b_terms(p, lut, u, a, logzi=np.log(0.01)):
+    G = len(p["group_sizes"])
+    rp = p["rowptr"].astype(np.int64)
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    e = np.exp(u - u.max())
+    p0 = np.exp(a * logzi)
+    T = lut[p["grp"], p["cnt"]]
+    x = np.exp(a * T)
+    Z = p0 * e.sum() + np.bincount(rows, e[p["grp"]] * (x - p0), minlength=len(rp) - 1)
+    H = p0 * logzi * e.sum() + np.bincount(rows, e[p["grp"]] * (x * T - p0 * logzi), minlength=len(rp) - 1)
+    c = p["ec_counts"].astype(np.float64)
+    r = c / Z
+    A = np.bincount(p["grp"], r[rows] * (x - p0), minlength=G)
+    return np.concatenate([A, [np.sum(c * np.log(Z)), np.sum(r * H), r.sum(), 0.0]])
+
+
+def _shard_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from msweep_amd import synth
+    from msweep_amd.likelihood import precalc_lls
+    from msweep_amd.parallel import csr_block, shard_ecs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = synth.make_csr_problem(20000, 50, seed=9, max_other=5)
+    lut = precalc_lls(p["group_sizes"])
+    u = np.random.default_rng(1).normal(0, 2, 50)
+    b = shard_ecs(p["rowptr"], world)
+    t = torch.from_numpy(_pass_b_terms(csr_block(p, b[rank], b[rank + 1]), lut, u, 0.8))
+    dist.all_reduce(t)
+    q.put((rank, t.numpy(), _pass_b_terms(p, lut, u, 0.8)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_ec_sharded_exchange_is_additive():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, summed, full in res:
+        np.testing.assert_allclose(summed, full, rtol=1e-12, atol=1e-300)
+    np.testing.assert_array_equal(res[0][1], res[1][1])      # every rank holds the same totals
+
+
+# ---- bench.py --gpus N starts its own ranks (no torchrun); rehearsed on CPU / gloo -------------------
+def _bench(args, env_extra=None, drop=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    import json
+    r = _bench(["--gpus", "2", "--launch-selftest"])
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["gathered"] == [1.0, 2.0]
+
+
+def test_bench_gpus_mismatch_is_an_error():
+    r = _bench(["--gpus", "2", "--launch-selftest"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
