@@ -25,6 +25,11 @@ struct msw_comm {
   virtual void allreduce(double *dev, size_t n, hipStream_t stream) = 0;
   // the same for unsigned 64-bit integers (group hit counts of the sharded likelihood build)
   virtual void allreduce_u64(uint64_t *dev, size_t n, hipStream_t stream) = 0;
+  // both at once (one fused launch under RCCL): na integers and nb doubles, in place
+  virtual void allreduce_mixed(uint64_t *a, size_t na, double *b, size_t nb, hipStream_t stream) {
+    allreduce_u64(a, na, stream);
+    allreduce(b, nb, stream);
+  }
   // recv[r * n .. (r + 1) * n) = rank r's send[0 .. n); HOST buffers (the bootstrap abundances live on
   // the host: include/Sample.hpp:157), blocking
   virtual void allgather_host(const double *send, size_t n, double *recv) = 0;
@@ -53,6 +58,14 @@ struct RcclComm final : msw_comm {
   void allreduce_u64(uint64_t *dev, size_t cnt, hipStream_t stream) override {
     const ncclResult_t rc = ncclAllReduce(dev, dev, cnt, ncclUint64, ncclSum, comm, stream);
     if (rc != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
+  }
+  void allreduce_mixed(uint64_t *a, size_t na, double *b, size_t nb, hipStream_t stream) override {
+    ncclResult_t rc = ncclGroupStart();
+    if (rc == ncclSuccess) rc = ncclAllReduce(a, a, na, ncclUint64, ncclSum, comm, stream);
+    if (rc == ncclSuccess) rc = ncclAllReduce(b, b, nb, ncclDouble, ncclSum, comm, stream);
+    const ncclResult_t rc2 = ncclGroupEnd();
+    if (rc == ncclSuccess) rc = rc2;
+    if (rc != ncclSuccess) throw HipError(std::string("ncclAllReduce (grouped): ") + ncclGetErrorString(rc));
   }
   void allgather_host(const double *send, size_t cnt, double *recv) override {
     DevBuf<double> s, d;

@@ -23,6 +23,12 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kPassThreads = MSW_PASS_THREADS_A;
 constexpr int kPassThreadsB = MSW_PASS_THREADS_B;
 constexpr int kMaxTrace = 4096;
+// column sums of the CSR sweeps as 64-bit fixed point + integer atomics (sweep_kernels.hpp); 0 = fp64
+// atomics, an A/B timing build only
+#ifndef MSW_FX
+#define MSW_FX 1
+#endif
+constexpr bool kFx = MSW_FX != 0;
 
 struct HipError : std::runtime_error {
   using std::runtime_error::runtime_error;
@@ -95,6 +101,8 @@ struct Scalars {
   // per-pass shared quantities
   double M, U, p0, V1c, V2c, kappa;
   double logzi;
+  // fixed-point column sums (sweep_kernels.hpp kFx): units per read and its reciprocal, powers of two
+  double fx_scale, fx_inv;
   int32_t didreset, reset_pending, done, iter;
   int32_t max_iters, fixed_iters, trace_theta, flavor;  // flavor: 0 csr, 1 dense
   int32_t tab_ver, pad_;  // bumped whenever (a) changes the per-slot tables: k_tables (large slot areas) follows

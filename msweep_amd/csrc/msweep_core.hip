@@ -407,18 +407,24 @@ void launch_passB(msw_core *h) {
   // column sums across workgroups + N_g / lgamma / digamma, spread over G/16 workgroups
   const bool partials = (h->flavor == 1) || h->gmodeB > 0;
   const int nb = h->npart_rows();
+  const int fxrows = h->flavor == 0 ? 1 : 0;  // the CSR sweeps leave fixed-point integer rows (kFx)
   if (h->comm) {
-    // EC-sharded: local column sums + ELBO terms -> one all-reduce -> k_redfin on the totals
+    // EC-sharded: local column sums + ELBO terms -> one all-reduce -> k_redfin on the totals.  The
+    // fixed-point column sums are all-reduced as INTEGERS: exact, so the totals -- and with them every
+    // N_g -- are the same bits whatever the number of ranks the ECs are spread over.
     hipLaunchKernelGGL(k_colsum, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, (int)h->G,
-                       partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->commB.p);
-    h->comm->allreduce(h->commB.p, (size_t)h->G + 4, h->stream);
+                       partials ? nb : 0, fxrows, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->commB.p);
+    if (kFx && fxrows)
+      h->comm->allreduce_mixed(reinterpret_cast<uint64_t *>(h->commB.p), (size_t)h->G, h->commB.p + h->G, 4, h->stream);
+    else
+      h->comm->allreduce(h->commB.p, (size_t)h->G + 4, h->stream);
     hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(1024), 0, h->stream,
-                       h->sc.p, (int)h->G, 0, 1, h->partAcc.p, h->commB.p, h->commB.p + h->G, h->e.p, h->u.p,
+                       h->sc.p, (int)h->G, 0, fxrows, 1, h->partAcc.p, h->commB.p, h->commB.p + h->G, h->e.p, h->u.p,
                        h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p, h->totS.p);
     return;
   }
   hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(1024), 0, h->stream,
-                     h->sc.p, (int)h->G, partials ? nb : 0, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->e.p,
+                     h->sc.p, (int)h->G, partials ? nb : 0, fxrows, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->e.p,
                      h->u.p, h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p, h->totS.p);
 }
 

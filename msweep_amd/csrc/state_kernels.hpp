@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
 // Block 0 also leaves the totals of the per-workgroup ELBO terms for k_fin in totS[0..2].
 constexpr int kRedfinParts = 5;
 constexpr int kRedfinGroups = 16;
-__global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int nblk,
+__global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int nblk, int fxrows,
                                                 int npartS, const double *partAcc, const double *Acc,
                                                 const double *partS, const double *e, const double *u,
                                                 const double *alpha0, double *Nc, double *N, double *w,
@@ -240,14 +240,25 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
   const int tid = threadIdx.x, gl = tid & (kRedfinGroups - 1), rs = tid >> 4;
   const int g = blockIdx.x * kRedfinGroups + gl;
   const Scalars s0 = *sc;  // in flight together with the partial rows below
+  // CSR flavour: the rows are 64-bit fixed-point integers (sweep_kernels.hpp kFx) -- summed as integers,
+  // exactly, whatever the number of rows; dense flavour: fp64 rows in fixed order
+  const bool fx = kFx && fxrows;
   double s = 0.0;
+  long long si = 0;
   if (g < G) {
     if (nblk > 0) {
-      for (int b = rs; b < nblk; b += 64) s += partAcc[(size_t)b * G + g];
+      if (fx) {
+        const long long *pi = reinterpret_cast<const long long *>(partAcc);
+        for (int b = rs; b < nblk; b += 64) si += pi[(size_t)b * G + g];
+      } else {
+        for (int b = rs; b < nblk; b += 64) s += partAcc[(size_t)b * G + g];
+      }
     } else if (rs == 0) {
-      s = Acc[g];
+      if (fx) si = reinterpret_cast<const long long *>(Acc)[g];
+      else s = Acc[g];
     }
   }
+  if (fx) s = __longlong_as_double(si);  // carried through the LDS exchange as bits
   // per-group operands of the math below: loaded now, needed after the reductions
   double ug0 = 0.0, eg0 = 0.0, al0 = 0.0;
   if (tid < kRedfinGroups && g < G) {
@@ -276,13 +287,20 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
   double lgv = 0.0, muv = 0.0, s0v = 0.0, s1v = 0.0, s2v = 0.0;
   if (tid < kRedfinGroups && g < G) {
     double A = 0.0;
+    if (fx) {
+      long long ai = 0;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) A += accs[i][gl];
+      for (int i = 0; i < 64; ++i) ai += __double_as_longlong(accs[i][gl]);
+      A = (double)ai * s0.fx_inv;  // sum_j e_g r_j (x_gj - p0), in reads
+    } else {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) A += accs[i][gl];
+    }
     double nc;
     const double ug = ug0;
     const int flavor = s0.flavor;
     if (flavor == 0) {
-      nc = eg0 * (s0.p0 * W + A);
+      nc = fx ? fma(eg0, s0.p0 * W, A) : eg0 * (s0.p0 * W + A);
       muv = (s0.M - ug) * nc;
     } else {
       nc = A;
@@ -434,7 +452,7 @@ __global__ __launch_bounds__(1024) void k_sum_scalar(const Scalars *sc, int gate
 
 // out[g] = column sum of this rank's ECs (g < G); out[G .. G+3] = {sum c log Z, sum r H, sum r, 0}
 // in the layout of one partS entry, so that k_redfin / k_fin consume `out` as totals.
-__global__ __launch_bounds__(1024) void k_colsum(const Scalars *sc, int G, int nrows, int npartS,
+__global__ __launch_bounds__(1024) void k_colsum(const Scalars *sc, int G, int nrows, int fxrows, int npartS,
                                                 const double *partAcc, const double *Acc,
                                                 const double *partS, double *out) {
   __shared__ double sh[32];
@@ -459,21 +477,36 @@ __global__ __launch_bounds__(1024) void k_colsum(const Scalars *sc, int G, int n
       out[G + 3] = 0.0;
     }
   }
+  const bool fx = kFx && fxrows;  // fixed-point rows: integer sums, handed on as bits (all-reduced as integers)
   double s = 0.0;
+  long long si = 0;
   if (g < G) {
     if (nrows > 0) {
-      for (int b = wv; b < nrows; b += 16) s += partAcc[(size_t)b * G + g];
+      if (fx) {
+        const long long *pi = reinterpret_cast<const long long *>(partAcc);
+        for (int b = wv; b < nrows; b += 16) si += pi[(size_t)b * G + g];
+      } else {
+        for (int b = wv; b < nrows; b += 16) s += partAcc[(size_t)b * G + g];
+      }
     } else if (wv == 0) {
-      s = Acc[g];
+      if (fx) si = reinterpret_cast<const long long *>(Acc)[g];
+      else s = Acc[g];
     }
   }
-  accs[wv][lane] = s;
+  accs[wv][lane] = fx ? __longlong_as_double(si) : s;
   __syncthreads();
   if (wv == 0 && g < G) {
-    double A = 0.0;
+    if (fx) {
+      long long ai = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) A += accs[i][lane];
-    out[g] = A;
+      for (int i = 0; i < 16; ++i) ai += __double_as_longlong(accs[i][lane]);
+      out[g] = __longlong_as_double(ai);
+    } else {
+      double A = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) A += accs[i][lane];
+      out[g] = A;
+    }
   }
 }
 
@@ -556,6 +589,13 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
     z.fixed_iters = fixed_iters;
     z.trace_theta = trace_theta;
     z.flavor = flavor;
+    // units per read of the fixed-point column sums: sum c * SCALE < 2^61, and at most 2^38 so that a
+    // single addend has 13 bits of headroom below the 2^51 of the fast conversion (sweep_kernels.hpp)
+    int ex = 0;
+    frexp(csum > 1.0 ? csum : 1.0, &ex);  // csum < 2^ex
+    const int k = 61 - ex < 38 ? 61 - ex : 38;
+    z.fx_scale = ldexp(1.0, k);
+    z.fx_inv = ldexp(1.0, -k);
     *sc = z;
     tab_built[0] = -1;  // no tables yet
     tab_built[1] = 0;

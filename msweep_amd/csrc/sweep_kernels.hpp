@@ -38,6 +38,24 @@ constexpr int kLongStep = MSW_LONG_STEP;  // records per lane and step on the wa
 #ifndef MSW_PASSB_BATCH
 #define MSW_PASSB_BATCH 4
 #endif
+// Column sums in 64-bit FIXED POINT (default): every cell adds rint(SCALE * e_g * r_j * (x - p0)) -- its
+// contribution to N_g in reads, SCALE = Scalars::fx_scale, a power of two -- with an INTEGER LDS atomic.
+// Integer addition is associative: the sums no longer depend on the order in which the wavefronts of a
+// workgroup reach the atomics, so two runs of a solve are bit-identical (fp64 atomics: the stop test
+// sits in their rounding noise and a 10 M-read run stopped at 209 or 210 iterations), and the totals are
+// the same whatever the number of workgroups or ranks the ECs are spread over.
+// MSW_FX=0 builds the fp64-atomic sweeps (A/B timing only); kFx lives in common.hpp.
+// double -> integer by the magic-number trick: for |q| < 2^51 the low 52 bits of (q + 1.5 * 2^52) hold
+// rint(q) in two's complement; subtracting the magic's bit pattern leaves it as a 64-bit integer.  The
+// magic's low dword is zero: the subtraction is ONE 32-bit operation on the high dword.
+constexpr double kFxMagic = 6755399441055744.0;             // 1.5 * 2^52 = 0x4338000000000000
+constexpr unsigned long long kFxMagicBits = 0x4338000000000000ull;
+constexpr double kFxLimit = 2251799813685248.0;             // 2^51
+__device__ __forceinline__ unsigned long long fx_bits(double scaled_r, double pk) {
+  const double v = fma(scaled_r, pk, kFxMagic);
+  const uint32_t hi = (uint32_t)__double2hiint(v) - (uint32_t)(kFxMagicBits >> 32);
+  return ((unsigned long long)hi << 32) | (uint32_t)__double2loint(v);
+}
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 // a wave-uniform double that was loaded through a vector load: move it to SGPRs
@@ -430,24 +448,43 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   auto E_ = [&](RT r) -> double { return tab8<GLDS>(e_b, R::hi(r, shift)); };
   auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
   auto XM_ = [&](RT r) -> double { return tab8<TLDS>(xt_b, R::lo(r, mask)); };
-  auto addACC = [&](RT r, double v) {
+  typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+  // one column-sum update: v = the value to add (fp64 build), or its fixed-point image (kFx)
+  auto addACC = [&](RT r, auto v) {
+    using V = decltype(v);
+    using LT = typename std::conditional<std::is_same<V, double>::value, lds_d_t, lds_u64_t>::type;
     const uint32_t off = R::hi(r, shift);
     if constexpr (GMODE == 2)
-      __hip_atomic_fetch_add((lds_d_t *)(size_t)(off + kAccFixed), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add((LT *)(size_t)(off + kAccFixed), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if constexpr (GMODE == 1)
-      __hip_atomic_fetch_add((lds_d_t *)(size_t)(off + acc_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add((LT *)(size_t)(off + acc_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if constexpr (GMODE == 3)
-      __hip_atomic_fetch_add((lds_d_t *)(size_t)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add((LT *)(size_t)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if constexpr (GMODE == 4) {
       const uint32_t d = off - bhi - 8u * rg.g0;  // unsigned: groups below the range wrap around
       if (d < 8u * rg.n)
-        __hip_atomic_fetch_add((lds_d_t *)(size_t)(bhi + d), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add((LT *)(size_t)(bhi + d), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     else
-      atomicAdd(reinterpret_cast<double *>(acc_b + off), v);
+      atomicAdd(reinterpret_cast<V *>(acc_b + off), v);
+  };
+  // kFx: a cell adds rint(rs * pk), rs = SCALE * r_j, pk = e_g * (x - p0).  |rs * pk| < 2^51 is what the
+  // magic-number conversion needs; |pk| <= Z + zbase for every cell of the EC, so ONE test per EC
+  // (rs * (Z + zbase) < 2^51) covers all its cells.  ECs that fail it -- a multiplicity in the
+  // thousands, or Z thousands of times below the background sum -- split each addend into two parts
+  // of 32 and 51 bits (two atomics; sums are modulo 2^64, so the parts need not be added together).
+  auto addFX = [&](RT r, double rs, double pk) { addACC(r, fx_bits(rs, pk)); };
+  auto addFXwide = [&](RT r, double rs, double pk) {
+    const double q = rs * pk;
+    const double vh = fma(q, 0x1p-32, kFxMagic);
+    const double qh = vh - kFxMagic;                       // rint(q / 2^32), exact
+    const double ql = fma(-qh, 0x1p32, q);                 // |ql| <= 2^31, exact
+    addACC(r, (unsigned long long)(uint32_t)__double2loint(vh) << 32);
+    addACC(r, fx_bits(1.0, ql));
   };
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, hbase = p0 * uniform_d(sc->logzi) * U;
+  const double fxs = uniform_d(sc->fx_scale);
   double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;
   double lp_mant = 1.0;  // deferred logarithms: product of mantissas in [2^-192, 1] ...
   int lp_exp = 0;        // ... and sum of exponents, per lane
@@ -494,9 +531,15 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
 #pragma unroll
         for (int k = 0; k < B; ++k) {
           if (k0 + k < L) {
-            zs = fma(ev[k], xt[k].x, zs);
+            if constexpr (kFx && KP) {  // the scatter adds r_j * (e_g * (x - p0)): keep the product
+              const double pk = ev[k] * xt[k].x;
+              zs += pk;
+              if constexpr (KEEPN > 0) if (k0 + k < KEEPN) xv[k0 + k] = pk;
+            } else {
+              zs = fma(ev[k], xt[k].x, zs);
+              if constexpr (KP && KEEPN > 0) if (k0 + k < KEEPN) xv[k0 + k] = xt[k].x;
+            }
             hs = fma(ev[k], xt[k].y, hs);
-            if constexpr (KP && KEEPN > 0) if (k0 + k < KEEPN) xv[k0 + k] = xt[k].x;
           }
         }
       }
@@ -516,15 +559,30 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     };
     // scatter of up to kRegCells cells held in b; padding records point at the lane's own sentinel
     // group: no test, no shared address
-    auto scatter = [&](RT(&b)[kRegCells], uint32_t n, double rj, auto KEPT) {
+    // (kFx: rj is SCALE * r_j, the kept values are e_g * (x - p0); WIDE_ADD: the two-part adds)
+    auto scatter = [&](RT(&b)[kRegCells], uint32_t n, double rj, auto KEPT, auto WIDE_ADD) {
       constexpr bool KP = decltype(KEPT)::value;
+      constexpr bool WA = decltype(WIDE_ADD)::value;
 #pragma unroll
       for (int k = 0; k < kRegCells; k += 2) {
         if ((uint32_t)k < n) {
-          const double x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : XM_(b[k]);
-          const double x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : XM_(b[k + 1]);
-          addACC(b[k], rj * x0);
-          addACC(b[k + 1], rj * x1);
+          double x0, x1;
+          if constexpr (kFx) {
+            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : E_(b[k]) * XM_(b[k]);
+            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : E_(b[k + 1]) * XM_(b[k + 1]);
+            if constexpr (WA) {
+              addFXwide(b[k], rj, x0);
+              addFXwide(b[k + 1], rj, x1);
+            } else {
+              addFX(b[k], rj, x0);
+              addFX(b[k + 1], rj, x1);
+            }
+          } else {
+            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : XM_(b[k]);
+            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : XM_(b[k + 1]);
+            addACC(b[k], rj * x0);
+            addACC(b[k + 1], rj * x1);
+          }
         }
       }
     };
@@ -535,7 +593,13 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         const double rj = c / Z;
         s_rH += rj * H;
         s_W += rj;
-        scatter(sb.r, len, rj, std::true_type{});
+        if constexpr (kFx) {
+          const double rs = rj * fxs;
+          if (rs * (Z + zbase) < kFxLimit) scatter(sb.r, len, rs, std::true_type{}, std::false_type{});
+          else scatter(sb.r, len, rs, std::true_type{}, std::true_type{});
+        } else {
+          scatter(sb.r, len, rj, std::true_type{}, std::false_type{});
+        }
         // sum c log Z after the scatter (its registers are free by now).  For the multiplicities
         // 1..3 -- nearly all ECs -- the logarithm is deferred: the mantissas are multiplied up per
         // lane and one log per 64 slices is taken of the product (flush_logs): ~8 operations per
@@ -586,10 +650,13 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         s_clogZ += c * log(Z);
         s_rH += rj * H;
         s_W += rj;
+        const double rs = kFx ? rj * fxs : rj;
+        const bool narrow = !kFx || rs * (Z + zbase) < kFxLimit;
         for (k0 = 0; k0 < len; k0 += kRegCells) {
           const uint32_t n = len - k0 < (uint32_t)kRegCells ? len - k0 : (uint32_t)kRegCells;
           load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, n, t);
-          scatter(t, n, rj, std::false_type{});
+          if (narrow) scatter(t, n, rs, std::false_type{}, std::false_type{});
+          else scatter(t, n, rs, std::false_type{}, std::true_type{});
         }
       }
     }
@@ -656,15 +723,24 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         }
 #pragma unroll
         for (int u = 0; u < kLongStep; ++u) rc[u] = first[u];
+        const double rs = kFx ? rj * fxs : rj;
+        const bool narrow = !kFx || rs * (Z + zbase) < kFxLimit;  // wave-uniform
         for (uint32_t kb = c0;;) {
 #pragma unroll
           for (int q = 0; q < kLongStep; q += 4) {
             if (kb + 64u * q < c1) {
               double xm[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) xm[u] = XM_(rc[q + u]);
+              for (int u = 0; u < 4; ++u) xm[u] = kFx ? E_(rc[q + u]) * XM_(rc[q + u]) : XM_(rc[q + u]);
 #pragma unroll
-              for (int u = 0; u < 4; ++u) addACC(rc[q + u], rj * xm[u]);
+              for (int u = 0; u < 4; ++u) {
+                if constexpr (kFx) {
+                  if (narrow) addFX(rc[q + u], rs, xm[u]);
+                  else addFXwide(rc[q + u], rs, xm[u]);
+                } else {
+                  addACC(rc[q + u], rj * xm[u]);
+                }
+              }
             }
           }
           kb += kLongStep * 64;

@@ -497,3 +497,29 @@ def test_mid_length_ecs_streaming_path(gpu_core, oracle):
     assert res["iters"] == ref["iters"]
     assert_theta(res["theta"], ref["theta"])
     np.testing.assert_allclose(np.exp(gpu_core.gamma()), np.exp(ref["gamma"]), atol=1e-7)
+
+
+def test_solves_are_bit_reproducible(gpu_core):
+    """Fixed-point integer column sums (sweep_kernels.hpp kFx): the order in which the wavefronts of a
+    workgroup reach the LDS atomics no longer matters -- repeated solves, and bootstrap replicates run
+    with different numbers of replicates in flight, give the same bits."""
+    p = synth.make_csr_problem(400_000, 1500, seed=51, max_other=10)
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    alpha0 = np.ones(1500)
+    first = gpu_core.solve(lik.log_counts(), alpha0)
+    for _ in range(4):
+        r = gpu_core.solve(lik.log_counts(), alpha0)
+        assert r["iters"] == first["iters"] and r["bound"] == first["bound"]
+        np.testing.assert_array_equal(r["theta"], first["theta"])
+    w = p["ec_counts"].astype(np.uint32)
+    runs = []
+    for streams in ("1", "4", "2"):
+        import os
+        os.environ["MSWEEP_BOOTSTRAP_STREAMS"] = streams
+        try:
+            runs.append(gpu_core.bootstrap(w, 5, int(w.sum()), 0, 5, alpha0))
+        finally:
+            del os.environ["MSWEEP_BOOTSTRAP_STREAMS"]
+    for th, it in runs[1:]:
+        np.testing.assert_array_equal(th, runs[0][0])
+        np.testing.assert_array_equal(it, runs[0][1])
