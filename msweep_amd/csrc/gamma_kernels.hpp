@@ -25,7 +25,18 @@ __global__ __launch_bounds__(256) void k_lse_sell(SellDev S, double a, double lo
   for (uint32_t p = blockIdx.x * blockDim.x + tid; p < S.n_ecs; p += gridDim.x * blockDim.x) {
     double zs = 0.0;
     for_each_cell<WIDE>(S, p, [&](uint32_t g, uint32_t i) { zs += exp(u[g] - M) * (exp(a * lut[i]) - p0); });
-    lse[S.perm[p]] = M + log(p0 * U + zs);
+    double Z = p0 * U + zs;
+    if (!(Z >= p0 * U * kGuardRatio)) {
+      // guarded EC (sell.hpp): background and listed cells cancel -- every group visited instead
+      // (a thread per EC scanning its own cells for each group: utility kernel, rare path)
+      Z = 0.0;
+      for (uint32_t g = 0; g < S.n_groups; ++g) {
+        double xg = p0;
+        for_each_cell<WIDE>(S, p, [&](uint32_t gg, uint32_t i) { if (gg == g) xg = exp(a * lut[i]); });
+        Z += exp(u[g] - M) * xg;
+      }
+    }
+    lse[S.perm[p]] = M + log(Z);
   }
 }
 

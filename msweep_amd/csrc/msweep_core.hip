@@ -76,6 +76,13 @@ struct msw_core {
   size_t lds_attr[2][20] = {};  // dynamic-LDS limit already granted per sweep instantiation
   msw_comm *comm = nullptr;
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
+  // guarded ECs (sell.hpp): per-workgroup lists, per-wavefront bitmaps, error flag
+  DevBuf<uint32_t> guard_list, guard_bits;
+  DevBuf<int> guard_err;
+  uint32_t guard_cap = 0, guard_words = 0;
+  GuardDev guard_view() const {
+    return GuardDev{guard_list.p, guard_bits.p, lut_area.p, guard_err.p, guard_cap, guard_words};
+  }
   DevBuf<Scalars> sc;
   Scalars *sc_host = nullptr;  // pinned
   DevBuf<double> tr_bound, tr_newnorm, tr_beta, tr_theta;
@@ -251,6 +258,16 @@ void alloc_solve_state(msw_core *h) {
   h->commB.alloc((size_t)G + 4);
   h->partAcc.alloc((size_t)std::max(nb, 1) * G);
   h->partC.alloc(1024);
+  if (h->flavor == 0) {
+    const uint32_t nb0 = (uint32_t)std::max(h->nblk, 1);
+    h->guard_cap = 64u * ((h->nslices + nb0 - 1) / nb0 + 16u) + (h->n_long + nb0 - 1) / nb0 + 16u;
+    h->guard_words = (G + 31u) / 32u;
+    h->guard_list.alloc((size_t)nb0 * h->guard_cap);
+    h->guard_bits.alloc((size_t)nb0 * 16 * h->guard_words);
+    h->guard_bits.zero(h->stream);
+  }
+  h->guard_err.alloc(1);
+  h->guard_err.zero(h->stream);
   h->sc.alloc(1);
   h->tr_bound.alloc(kMaxTrace);
   h->tr_newnorm.alloc(kMaxTrace);
@@ -282,7 +299,7 @@ void launch_passA_t(msw_core *h) {
   auto k = k_passA<W, GL, TL>;
   prepare_sweep(k, lds, h->lds_attr[0][(W ? 4 : 0) | (GL ? 2 : 0) | (TL ? 1 : 0)]);
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h),
-                     h->ew.p, h->tabA.p, h->partA.p);
+                     h->ew.p, h->tabA.p, h->partA.p, h->guard_view());
 }
 template <bool W, int GM, bool TL>
 void launch_passB_t(msw_core *h) {
@@ -293,11 +310,11 @@ void launch_passB_t(msw_core *h) {
     for (uint32_t g0 = 0; g0 < h->G; g0 += kRangeGroups)
       hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreadsB), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
                          h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p,
-                         RangeB{g0, std::min<uint32_t>(kRangeGroups, h->G - g0), g0 == 0 ? 1 : 0});
+                         RangeB{g0, std::min<uint32_t>(kRangeGroups, h->G - g0), g0 == 0 ? 1 : 0}, h->guard_view());
     return;
   }
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreadsB), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
-                     h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p, RangeB{0, 0, 1});
+                     h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p, RangeB{0, 0, 1}, h->guard_view());
 }
 
 #define MSW_DISPATCH3(fn, ...)                                                       \
@@ -550,6 +567,15 @@ void run_rcg(msw_core *h, size_t max_iters) {
 void finish_solve(msw_core *h, double *theta_out, size_t *iters_out, double *bound_out) {
   poll(h);
   const uint32_t G = h->G;
+  int gerr = 0;
+  MSW_HIP(hipMemcpy(&gerr, h->guard_err.p, sizeof gerr, hipMemcpyDeviceToHost));
+  if (gerr) {
+    MSW_HIP(hipMemset(h->guard_err.p, 0, sizeof gerr));
+    throw Fail("likelihood underflow: an equivalence class has zero probability under every group "
+               "(exp(a * log-likelihood) and the group weights underflow fp64 together)");
+  }
+  if (!std::isfinite(h->sc_host->bound))
+    throw Fail("the evidence lower bound is not finite: the likelihood or the prior counts are out of range");
   if (theta_out) {
     if (h->last_algo == MSW_ALGO_EM) {
       MSW_HIP(hipMemcpy(theta_out, h->logth.p, G * sizeof(double), hipMemcpyDeviceToHost));  // theta of the last M-step

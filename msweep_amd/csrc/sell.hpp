@@ -99,6 +99,48 @@ __device__ __forceinline__ void for_each_cell(const SellDev &S, uint32_t p, F f)
   }
 }
 
+// The cells of the EC at permuted position p, one per lane and step, for a whole wavefront:
+// f(group id, slot-area entry).  Sentinel padding is skipped.  (Rare-path code: the guarded ECs.)
+template <bool WIDE, class F>
+__device__ __forceinline__ void wave_cells(const SellDev &S, uint32_t p, uint32_t lane, F f) {
+  using R = Rec<WIDE>;
+  if (p < S.n_long) {
+    const uint32_t k0 = S.long_ptr[p], k1 = S.long_ptr[p + 1];
+    for (uint32_t k = k0 + lane; k < k1; k += 64) {
+      const typename R::T r = R::load(S.rec_long, k);
+      f(rec_grp<WIDE>(S, r), R::lo(r, S.mask) >> 4);
+    }
+  } else {
+    const uint32_t q = p - S.n_long, s = q >> 6, le = q & 63;
+    const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;
+    for (uint32_t k = lane; k < len; k += 64) {
+      const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + le);
+      const uint32_t g = rec_grp<WIDE>(S, r);
+      if (g < S.n_groups) f(g, R::lo(r, S.mask) >> 4);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Guarded ECs (SURVEY.md 7.3 ii).  The sweeps form Z_j = p0 * U + sum_listed e_g (x_gj - p0): when
+// the listed groups hold nearly all of U and their cells sit far below the background (x << p0:
+// an isolate's read that hits the dominant lineage with one k-mer, priors << 1) the two parts cancel
+// and Z_j, r_j = c_j / Z_j and the listed groups' column sums lose their digits -- or their sign.
+// An EC whose Z_j comes out below 2^-20 of the background sum (the unguarded relative error is thus
+// at most 2^-33) is set aside by the sweep (its position appended to the workgroup's list) and
+// evaluated WITHOUT the background trick at the end of the workgroup, a wavefront per EC:
+// Z_j = sum_listed e_g x_gj + p0 * (sum over the groups NOT listed, one by one), and every group's
+// share of c_j added directly.  O(G) per guarded EC; none exist in ordinary inputs.
+// ---------------------------------------------------------------------------------------
+constexpr double kGuardRatio = 0x1p-20;
+struct GuardDev {
+  uint32_t *list;          // [workgroups * cap] positions of the ECs set aside, per workgroup
+  uint32_t *bits;          // [workgroups * 16 * words] one bitmap of listed groups per wavefront
+  const double *lut_area;  // table value of every slot-area entry
+  int *err;                // set when an EC has no probability under any group
+  uint32_t cap, words;
+};
+
 // LDS image of the sweeps (byte offsets; bhi = sell_bhi()):
 //   [0, 16 * n_area)                    slot area: 16-byte per-slot entries of the pass (tlds)
 //   pass A: [2 * bhi, 2 * bhi + 16 * Gp)  {e_g, wc_g}                         (glds)

@@ -226,7 +226,7 @@ __device__ __forceinline__ void cellA(AccA &c, const double p0, const double e, 
 template <bool WIDE, bool GLDS, bool TLDS>
 __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellDev S,
                                                        const double2 *ew_g, const double2 *tabA_g,
-                                                       double *partA) {
+                                                       double *partA, GuardDev GD) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
   using RT = typename R::T;
@@ -257,8 +257,16 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, b1 = p0 * uniform_d(sc->V1c), b2 = p0 * uniform_d(sc->V2c);
+  const double gthr = zbase * kGuardRatio;  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
+  const uint32_t gcnt_off = (uint32_t)pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true) + 128u;
+  typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+  auto defer = [&](uint32_t p) {
+    const uint32_t i = __hip_atomic_fetch_add((lds_u32_t *)(size_t)gcnt_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    GD.list[(size_t)blockIdx.x * GD.cap + i] = p;
+  };
   double nn = 0.0;
   if (skip) return;
+  if (tid == 0) *(lds_u32_t *)(size_t)gcnt_off = 0u;
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
@@ -330,9 +338,14 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
       }
     }
     if (sb.sl * 64 + lane < n_sell) {
-      const double iZ = 1.0 / (zbase + c.zs);
-      const double S1 = (b1 + c.t1) * iZ, S2 = (b2 + c.t2) * iZ;
-      nn += S2 - S1 * S1;
+      const double Zt = zbase + c.zs;
+      if (Zt >= gthr) {
+        const double iZ = 1.0 / Zt;
+        const double S1 = (b1 + c.t1) * iZ, S2 = (b2 + c.t2) * iZ;
+        nn += S2 - S1 * S1;
+      } else {
+        defer(S.n_long + sb.sl * 64 + lane);
+      }
     }
   };
   stream.run(issue, process, [] {});
@@ -383,15 +396,65 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
       if (nr != r) {  // that was the EC's last step
         const double zs = wave_sum(c.zs), t1 = wave_sum(c.t1), t2 = wave_sum(c.t2);
         if (lane == 0) {
-          const double iZ = 1.0 / (zbase + zs);
-          const double S1 = (b1 + t1) * iZ, S2 = (b2 + t2) * iZ;
-          nn += S2 - S1 * S1;
+          const double Zt = zbase + zs;
+          if (Zt >= gthr) {
+            const double iZ = 1.0 / Zt;
+            const double S1 = (b1 + t1) * iZ, S2 = (b2 + t2) * iZ;
+            nn += S2 - S1 * S1;
+          } else {
+            defer(r);
+          }
         }
         c = {0.0, 0.0, 0.0};
       }
 #pragma unroll
       for (int u = 0; u < LS; ++u) cur[u] = nxt[u];
       r = nr, kb = nkb, k1 = nk1, have = nhave;
+    }
+  }
+  // guarded ECs (sell.hpp): a wavefront each, every group visited -- no background term to cancel against
+  __syncthreads();
+  const uint32_t n_guard = *(lds_u32_t *)(size_t)gcnt_off;
+  if (n_guard) {
+    const uint32_t wv = uniform(tid >> 6), nwv = kPassThreads / 64;
+    uint32_t *bits = GD.bits + (size_t)(blockIdx.x * 16 + wv) * GD.words;
+    const double a = uniform_d(sc->a), oma = 1.0 - a, logzi = uniform_d(sc->logzi);
+    for (uint32_t i = wv; i < n_guard; i += nwv) {
+      const uint32_t p = GD.list[(size_t)blockIdx.x * GD.cap + i];
+      double z = 0.0, t1 = 0.0, t2 = 0.0;
+      wave_cells<WIDE>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
+        const double T = GD.lut_area[ent], x = exp(a * T), sv = oma * (T - logzi) + ew_g[g].y;
+        const double q = ew_g[g].x * x;
+        atomicOr(&bits[g >> 5], 1u << (g & 31));
+        z += q;
+        t1 = fma(q, sv, t1);
+        t2 = fma(q * sv, sv, t2);
+      });
+      __builtin_amdgcn_s_waitcnt(0);  // the bitmap updates have reached memory before it is read back
+      for (uint32_t w0 = lane; w0 < GD.words; w0 += 64) {
+        const uint32_t listed = atomicOr(&bits[w0], 0u);
+        for (uint32_t b = 0; b < 32; ++b) {
+          const uint32_t g = w0 * 32 + b;
+          if (g < G && !((listed >> b) & 1u)) {
+            const double2 ev = ew_g[g];
+            const double q = ev.x * p0;
+            z += q;
+            t1 = fma(q, ev.y, t1);
+            t2 = fma(q * ev.y, ev.y, t2);
+          }
+        }
+        atomicAnd(&bits[w0], 0u);
+      }
+      z = wave_sum(z), t1 = wave_sum(t1), t2 = wave_sum(t2);
+      if (lane == 0) {
+        if (z > 0.0) {
+          const double S1 = t1 / z, S2 = t2 / z;
+          nn += S2 - S1 * S1;
+        } else {
+          *GD.err = 1;  // no probability under any group: the solve reports it
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
     }
   }
   nn = block_sum(nn, sh);
@@ -414,7 +477,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
 template <bool WIDE, int GMODE, bool TLDS>
 __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
                                                        const double2 *tabB_g, double *partAcc,
-                                                       double *partS, double *accGlobal, RangeB rg) {
+                                                       double *partS, double *accGlobal, RangeB rg, GuardDev GD) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<WIDE>;
   using RT = typename R::T;
@@ -485,6 +548,13 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, hbase = p0 * uniform_d(sc->logzi) * U;
   const double fxs = uniform_d(sc->fx_scale);
+  const double gthr = zbase * kGuardRatio;  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
+  const uint32_t gcnt_off = (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 128u;
+  typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+  auto defer = [&](uint32_t p) {
+    const uint32_t i = __hip_atomic_fetch_add((lds_u32_t *)(size_t)gcnt_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    GD.list[(size_t)blockIdx.x * GD.cap + i] = p;
+  };
   double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;
   double lp_mant = 1.0;  // deferred logarithms: product of mantissas in [2^-192, 1] ...
   int lp_exp = 0;        // ... and sum of exponents, per lane
@@ -494,6 +564,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     lp_exp = 0;
   };
   if (skip) return;
+  if (tid == 0) *(lds_u32_t *)(size_t)gcnt_off = 0u;
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
@@ -588,7 +659,9 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     };
     if (len <= (uint32_t)kRegCells) {
       cells(sb.r, len, std::true_type{});
-      if (c != 0.0) {
+      if (c != 0.0 && !(zbase + zs >= gthr)) {
+        defer(S.n_long + sb.sl * 64 + lane);
+      } else if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
         const double rj = c / Z;
         s_rH += rj * H;
@@ -644,7 +717,9 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
           }
         }
       }
-      if (c != 0.0) {
+      if (c != 0.0 && !(zbase + zs >= gthr)) {
+        defer(S.n_long + sb.sl * 64 + lane);
+      } else if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
         const double rj = c / Z;
         s_clogZ += c * log(Z);
@@ -713,7 +788,9 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
       }
       zs = wave_sum(zs);
       hs = wave_sum(hs);
-      if (c != 0.0) {
+      if (c != 0.0 && !(zbase + zs >= gthr)) {  // wave-uniform
+        if (lane == 0) defer(r);
+      } else if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
         const double rj = c / Z;
         if (lane == 0) {
@@ -749,6 +826,65 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         }
       }
       r = rn, c0 = n0, c1 = n1;
+    }
+  }
+  // guarded ECs (sell.hpp): a wavefront each, every group visited.  Each group receives its share of the
+  // EC's c_j directly -- listed: c e_g x / Z, not listed: c e_g p0 / Z -- and the EC stays out of
+  // W = sum r_j (the background share of the ordinary ECs).
+  __syncthreads();
+  const uint32_t n_guard = *(lds_u32_t *)(size_t)gcnt_off;
+  if (n_guard) {
+    const uint32_t wv = uniform(tid >> 6), nwv = kPassThreadsB / 64;
+    uint32_t *bits = GD.bits + (size_t)(blockIdx.x * 16 + wv) * GD.words;
+    const double a = uniform_d(sc->a), logzi = uniform_d(sc->logzi);
+    // one column-sum update by group id: val = the group's share divided by e_g
+    auto add_share = [&](uint32_t g, double eg, double val) {
+      const RT rr = null_record<WIDE>(bhi + 8u * g, shift);
+      if constexpr (kFx) addFXwide(rr, fxs, eg * val);
+      else addACC(rr, val);
+    };
+    for (uint32_t i = wv; i < n_guard; i += nwv) {
+      const uint32_t p = GD.list[(size_t)blockIdx.x * GD.cap + i];
+      const double c = S.cvec[p];
+      double z = 0.0, h = 0.0;
+      wave_cells<WIDE>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
+        const double T = GD.lut_area[ent], q = e_g[g] * exp(a * T);
+        atomicOr(&bits[g >> 5], 1u << (g & 31));
+        z += q;
+        h = fma(q, T, h);
+      });
+      __builtin_amdgcn_s_waitcnt(0);  // the bitmap updates have reached memory before it is read back
+      double r0 = 0.0;
+      for (uint32_t w0 = lane; w0 < GD.words; w0 += 64) {
+        const uint32_t listed = atomicOr(&bits[w0], 0u);
+        for (uint32_t b = 0; b < 32; ++b) {
+          const uint32_t g = w0 * 32 + b;
+          if (g < G && !((listed >> b) & 1u)) r0 += e_g[g];
+        }
+      }
+      z = wave_sum(z), h = wave_sum(h), r0 = wave_sum(r0);
+      const double Z = fma(p0, r0, z), H = fma(p0 * logzi, r0, h);
+      if (Z > 0.0) {
+        const double rj = c / Z;
+        if (lane == 0) {
+          s_clogZ += c * log(Z);
+          s_rH += rj * H;
+        }
+        wave_cells<WIDE>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
+          add_share(g, e_g[g], rj * exp(a * GD.lut_area[ent]));
+        });
+        for (uint32_t w0 = lane; w0 < GD.words; w0 += 64) {
+          const uint32_t listed = atomicAnd(&bits[w0], 0u);  // read and clear
+          for (uint32_t b = 0; b < 32; ++b) {
+            const uint32_t g = w0 * 32 + b;
+            if (g < G && !((listed >> b) & 1u)) add_share(g, e_g[g], rj * p0);
+          }
+        }
+      } else {
+        if (lane == 0) *GD.err = 1;  // no probability under any group: the solve reports it
+        for (uint32_t w0 = lane; w0 < GD.words; w0 += 64) atomicAnd(&bits[w0], 0u);
+      }
+      __builtin_amdgcn_s_waitcnt(0);
     }
   }
   s_clogZ = block_sum(s_clogZ, sh);

@@ -332,6 +332,10 @@ struct PassOut {
   double W = 0.0;                // B pass: sum_j r_j
 };
 
+// ECs whose Z comes out below this fraction of the background sum p0 * U are evaluated without the
+// background trick (the HIP sweeps use the same threshold, msweep_amd/csrc/sell.hpp)
+constexpr double kGuardRatio = 0x1p-20;
+
 struct CsrL {
   const uint64_t *rowptr;
   const uint32_t *grp;
@@ -380,6 +384,7 @@ void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double
     double *A = Apart.data() + ch * G;
     long double sum_clogZ = 0.0L, sum_rH = 0.0L;
     double W = 0.0;
+    std::vector<uint64_t> mark;  // guarded ECs: mark[g] == j + 1 <=> EC j lists group g
     for (size_t j = j0; j < j1; ++j) {
       double zs = 0.0, hs = 0.0;
       for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
@@ -387,9 +392,35 @@ void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double
         zs += eg * xm[S.lutidx[k]];
         hs += eg * xTm[S.lutidx[k]];
       }
+      const double c = cvec[j];
+      if (!(zbase + zs >= zbase * kGuardRatio)) {
+        // Guarded EC (SURVEY.md 7.3 ii): background and listed cells cancel.  No background trick:
+        // Z = sum_listed e x + p0 * (sum of e over the groups not listed, one by one); every group's
+        // share of c_j added directly; the EC stays out of W.
+        if (mark.empty()) mark.assign(G, 0);
+        double z = 0.0, h = 0.0, r0 = 0.0;
+        for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
+          const double T = S.lut[S.lutidx[k]], q = e[S.grp[k]] * std::exp(a * T);
+          mark[S.grp[k]] = j + 1;
+          z += q;
+          h += q * T;
+        }
+        for (size_t g = 0; g < G; ++g) if (mark[g] != j + 1) r0 += e[g];
+        const double Zg = z + p0 * r0, Hg = h + p0 * S.logzi * r0;
+        if (lse_out) lse_out[j] = M + std::log(Zg);
+        if (c != 0.0) {
+          const double rg = c / Zg;
+          sum_clogZ += (long double)c * std::log(Zg);
+          sum_rH += (long double)rg * Hg;
+          // A holds sum_j r_j (x - p0) per group, N_g = e_g (p0 W + A_g): a share s_g enters as s_g / e_g
+          for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k)
+            A[S.grp[k]] += rg * std::exp(a * S.lut[S.lutidx[k]]);
+          for (size_t g = 0; g < G; ++g) if (mark[g] != j + 1) A[g] += rg * p0;
+        }
+        continue;
+      }
       const double Z = zbase + zs;
       const double H = hbase + hs;
-      const double c = cvec[j];
       const double r = c / Z;
       if (lse_out) lse_out[j] = M + std::log(Z);
       if (c != 0.0) {
@@ -455,6 +486,7 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
     size_t j0, j1;
     chunk_range(E, nch, ch, &j0, &j1);
     long double nn = 0.0L;
+    std::vector<uint64_t> mark;
     for (size_t j = j0; j < j1; ++j) {
       double zs = 0.0, t1 = 0.0, t2 = 0.0;
       for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
@@ -466,6 +498,28 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
         zs += eg * xm;
         t1 += eg * (xD + wx);
         t2 += eg * (xD * D[i] + wg * (2.0 * xD + wx));
+      }
+      if (!(zbase + zs >= zbase * kGuardRatio)) {  // guarded EC: every group visited (see csr_pass_B)
+        if (mark.empty()) mark.assign(G, 0);
+        double z = 0.0, u1 = 0.0, u2 = 0.0;
+        for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
+          const uint32_t g = S.grp[k], i = S.lutidx[k];
+          const double q = e[g] * x[i], sv = D[i] + wc[g];
+          mark[g] = j + 1;
+          z += q;
+          u1 += q * sv;
+          u2 += q * sv * sv;
+        }
+        for (size_t g = 0; g < G; ++g)
+          if (mark[g] != j + 1) {
+            const double q = e[g] * p0;
+            z += q;
+            u1 += q * wc[g];
+            u2 += q * wc[g] * wc[g];
+          }
+        const double S1 = u1 / z, S2 = u2 / z;
+        nn += (long double)(S2 - S1 * S1);
+        continue;
       }
       const double iZ = 1.0 / (zbase + zs);
       const double S1 = (b1 + t1) * iZ;
