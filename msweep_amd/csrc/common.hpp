@@ -101,8 +101,9 @@ struct Scalars {
   // per-pass shared quantities
   double M, U, p0, V1c, V2c, kappa;
   double logzi;
-  // fixed-point column sums (sweep_kernels.hpp kFx): units per read and its reciprocal, powers of two
-  double fx_scale, fx_inv;
+  // fixed-point column sums (sweep_kernels.hpp kFx): 2^K and 2^-K; 2^t / 2^-t of the guarded ECs' shares
+  // (sell.hpp); xb >= every table value x_i = exp(a T_i) and p0 of the current pass; extreme table values
+  double fx_scale, fx_inv, fx_tscale, fx_tinv, xb, tmax, tmin;
   int32_t didreset, reset_pending, done, iter;
   int32_t max_iters, fixed_iters, trace_theta, flavor;  // flavor: 0 csr, 1 dense
   int32_t tab_ver, pad_;  // bumped whenever (a) changes the per-slot tables: k_tables (large slot areas) follows

@@ -84,6 +84,17 @@ __device__ __forceinline__ double block_max(double v, double *sh) {
   return r;
 }
 
+// e = fx_mant(e) * fx_pow2(e) for a positive normal double: mantissa in [1, 2) and binary exponent as
+// doubles (fixed-point column sums, sweep_kernels.hpp; 0 -> pow2 0: such a group receives nothing, and
+// denormal weights are flushed to 0 where e_g is formed)
+__device__ __forceinline__ double fx_mant(double e) {
+  return __hiloint2double((__double2hiint(e) & 0x000FFFFF) | 0x3FF00000, __double2loint(e));
+}
+__device__ __forceinline__ double fx_pow2(double e) {
+  return __hiloint2double(__double2hiint(e) & 0x7FF00000, 0);
+}
+__device__ __forceinline__ double flush_denormal(double e) { return e < 0x1p-1000 ? 0.0 : e; }
+
 // digamma: the 7-shift asymptotic series of the reference (src/Sample.cpp:87-97; rcgpar
 // carries the same function for the RCG gradient).
 __device__ __forceinline__ double digamma_ref(double x) {

@@ -78,10 +78,12 @@ struct msw_core {
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
   // guarded ECs (sell.hpp): per-workgroup lists, per-wavefront bitmaps, error flag
   DevBuf<uint32_t> guard_list, guard_bits;
+  DevBuf<unsigned long long> guard_tail;  // [2 G] the guarded ECs' shares per group, two fixed-point limbs
   DevBuf<int> guard_err;
+  DevBuf<double> trange;  // {max, min} of the table values (bounds x_i = exp(a T_i) per pass: Scalars::xb)
   uint32_t guard_cap = 0, guard_words = 0;
   GuardDev guard_view() const {
-    return GuardDev{guard_list.p, guard_bits.p, lut_area.p, guard_err.p, guard_cap, guard_words};
+    return GuardDev{guard_list.p, guard_bits.p, guard_tail.p, lut_area.p, guard_err.p, guard_cap, guard_words};
   }
   DevBuf<Scalars> sc;
   Scalars *sc_host = nullptr;  // pinned
@@ -255,7 +257,7 @@ void alloc_solve_state(msw_core *h) {
   h->partR.alloc(kRedfinParts * ((size_t)G / kRedfinGroups + 2));
   h->totS.alloc(4);
   h->commA.alloc(1);
-  h->commB.alloc((size_t)G + 4);
+  h->commB.alloc(3 * (size_t)G + 4);  // column sums, two limbs of the guarded ECs' shares, ELBO terms
   h->partAcc.alloc((size_t)std::max(nb, 1) * G);
   h->partC.alloc(1024);
   if (h->flavor == 0) {
@@ -265,6 +267,12 @@ void alloc_solve_state(msw_core *h) {
     h->guard_list.alloc((size_t)nb0 * h->guard_cap);
     h->guard_bits.alloc((size_t)nb0 * 16 * h->guard_words);
     h->guard_bits.zero(h->stream);
+    h->guard_tail.alloc(2 * (size_t)G);
+    h->guard_tail.zero(h->stream);
+  }
+  if (!h->trange.p) {  // dense flavour: no tables
+    h->trange.alloc(2);
+    h->trange.zero(h->stream);
   }
   h->guard_err.alloc(1);
   h->guard_err.zero(h->stream);
@@ -429,24 +437,31 @@ void launch_passB(msw_core *h) {
     // EC-sharded: local column sums + ELBO terms -> one all-reduce -> k_redfin on the totals.  The
     // fixed-point column sums are all-reduced as INTEGERS: exact, so the totals -- and with them every
     // N_g -- are the same bits whatever the number of ranks the ECs are spread over.
+    const size_t G3 = 3 * (size_t)h->G;
     hipLaunchKernelGGL(k_colsum, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, (int)h->G,
-                       partials ? nb : 0, fxrows, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->commB.p);
-    if (kFx && fxrows)
-      h->comm->allreduce_mixed(reinterpret_cast<uint64_t *>(h->commB.p), (size_t)h->G, h->commB.p + h->G, 4, h->stream);
-    else
-      h->comm->allreduce(h->commB.p, (size_t)h->G + 4, h->stream);
+                       partials ? nb : 0, fxrows, nb, h->partAcc.p, h->Acc.p, h->partS.p,
+                       fxrows ? h->guard_tail.p : nullptr, h->commB.p);
+    if (kFx && fxrows) {
+      h->comm->allreduce_mixed(reinterpret_cast<uint64_t *>(h->commB.p), G3, h->commB.p + G3, 4, h->stream);
+    } else {  // fp64 column sums (dense flavour, MSW_FX=0 builds): doubles, then the integer limbs
+      h->comm->allreduce(h->commB.p, (size_t)h->G, h->stream);
+      h->comm->allreduce_mixed(reinterpret_cast<uint64_t *>(h->commB.p) + h->G, 2 * (size_t)h->G, h->commB.p + G3, 4,
+                               h->stream);
+    }
     hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(1024), 0, h->stream,
-                       h->sc.p, (int)h->G, 0, fxrows, 1, h->partAcc.p, h->commB.p, h->commB.p + h->G, h->e.p, h->u.p,
+                       h->sc.p, (int)h->G, 0, fxrows, reinterpret_cast<unsigned long long *>(h->commB.p) + h->G, 0, 1,
+                       h->partAcc.p, h->commB.p, h->commB.p + G3, h->e.p, h->u.p,
                        h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p, h->totS.p);
     return;
   }
   hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(1024), 0, h->stream,
-                     h->sc.p, (int)h->G, partials ? nb : 0, fxrows, nb, h->partAcc.p, h->Acc.p, h->partS.p, h->e.p,
+                     h->sc.p, (int)h->G, partials ? nb : 0, fxrows, fxrows ? h->guard_tail.p : nullptr, 1, nb,
+                     h->partAcc.p, h->Acc.p, h->partS.p, h->e.p,
                      h->u.p, h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p, h->totS.p);
 }
 
 // partS as seen by k_fin / k_em_fin: the all-reduced totals when sharded
-const double *fin_partS(msw_core *h) { return h->comm ? h->commB.p + h->G : h->partS.p; }
+const double *fin_partS(msw_core *h) { return h->comm ? h->commB.p + 3 * (size_t)h->G : h->partS.p; }
 int fin_npartS(msw_core *h) { return h->comm ? 1 : h->npart_rows(); }
 
 // slot areas beyond kTabInline entries: the tables are rebuilt by their own kernel after every
@@ -517,7 +532,8 @@ void begin_solve(msw_core *h, double tol, size_t max_iters) {
   }
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1024), 0, h->stream, h->sc.p, (int)G, ncpart,
                      cpart, h->alpha0.p, h->u.p, h->os_u.p, h->step_u.p, tol, (int)max_iters,
-                     h->fixed_iters ? 1 : 0, (int)h->trace_theta, h->flavor, h->logzi, kInitBound, h->tab_built.p);
+                     h->fixed_iters ? 1 : 0, (int)h->trace_theta, h->flavor, h->logzi, kInitBound, h->tab_built.p,
+                     h->trange.p);
   MSW_HIP(hipGetLastError());
 }
 

@@ -126,16 +126,18 @@ __device__ __forceinline__ void wave_cells(const SellDev &S, uint32_t p, uint32_
 // the listed groups hold nearly all of U and their cells sit far below the background (x << p0:
 // an isolate's read that hits the dominant lineage with one k-mer, priors << 1) the two parts cancel
 // and Z_j, r_j = c_j / Z_j and the listed groups' column sums lose their digits -- or their sign.
-// An EC whose Z_j comes out below 2^-20 of the background sum (the unguarded relative error is thus
-// at most 2^-33) is set aside by the sweep (its position appended to the workgroup's list) and
+// An EC whose Z_j comes out below 2^-8 of the background sum (the unguarded relative error is thus
+// at most 2^-45; with the reference's WOR21 tables, whose values stay within e^-1 of log(zi) up to
+// groups of 400 sequences, no EC comes near it) is set aside by the sweep (its position appended to the workgroup's list) and
 // evaluated WITHOUT the background trick at the end of the workgroup, a wavefront per EC:
 // Z_j = sum_listed e_g x_gj + p0 * (sum over the groups NOT listed, one by one), and every group's
 // share of c_j added directly.  O(G) per guarded EC; none exist in ordinary inputs.
 // ---------------------------------------------------------------------------------------
-constexpr double kGuardRatio = 0x1p-20;
+constexpr double kGuardRatio = 0x1p-8;
 struct GuardDev {
   uint32_t *list;          // [workgroups * cap] positions of the ECs set aside, per workgroup
   uint32_t *bits;          // [workgroups * 16 * words] one bitmap of listed groups per wavefront
+  unsigned long long *tail;  // [2 * G] the guarded ECs' shares per group, two fixed-point limbs (pass B)
   const double *lut_area;  // table value of every slot-area entry
   int *err;                // set when an EC has no probability under any group
   uint32_t cap, words;

@@ -28,13 +28,14 @@ __device__ inline void prepB_block(Scalars *sc, double a, int G, int n_lut, cons
   const double M = block_max(m, sh);
   double su = 0.0;
   for (int g = tid; g < G; g += nt) {
-    const double eg = exp(u[g] - M);
+    const double eg = flush_denormal(exp(u[g] - M));
     e[g] = eg;
     su += eg;
   }
   const double U = block_sum(su, sh);
   const double logzi = sc->logzi, oma = 1.0 - a;
   const double p0 = exp(a * logzi);
+  const double xtop = exp(a * (a >= 0.0 ? sc->tmax : sc->tmin));
   for (int i = tid; i < n_lut; i += nt) {
     const double T = lut[i], x = exp(a * T);
     X.A[i] = make_double2(x, oma * (T - logzi));
@@ -44,6 +45,7 @@ __device__ inline void prepB_block(Scalars *sc, double a, int G, int n_lut, cons
     sc->M = M;
     sc->U = U;
     sc->p0 = p0;
+    sc->xb = fmax(xtop, p0);
     sc->tab_ver = sc->tab_ver + 1;
   }
 }
@@ -69,6 +71,22 @@ __global__ __launch_bounds__(256) void k_tables(const Scalars *sc, int n_tab, co
   if (threadIdx.x == 0 && atomicAdd(&built[1], 1) == (int)gridDim.x - 1) {  // the last workgroup: all have read built[0]
     built[1] = 0;
     built[0] = ver;
+  }
+}
+
+// {max, min} of the table values in the slot area (one workgroup; at upload)
+__global__ __launch_bounds__(1024) void k_minmax(const double *v, uint32_t n, double *out) {
+  __shared__ double sh[32];
+  double mx = -INFINITY, mn = INFINITY;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    mx = fmax(mx, v[i]);
+    mn = fmin(mn, v[i]);
+  }
+  mx = block_max(mx, sh);
+  mn = -block_max(-mn, sh);
+  if (threadIdx.x == 0) {
+    out[0] = mx;
+    out[1] = mn;
   }
 }
 
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
     for (int k = 0; k < kStepRegs; ++k) {
       const int g = tid + k * nt;
       if (g < G) {
-        const double eg = exp(uv[k] - M);
+        const double eg = flush_denormal(exp(uv[k] - M));
         e[g] = eg;
         su += eg;
       }
@@ -214,6 +232,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
       sc->M = M;
       sc->U = U;
       sc->p0 = p0;
+      sc->xb = fmax(exp(a_new * (a_new >= 0.0 ? s0.tmax : s0.tmin)), p0);
     }
   }
 }
@@ -231,6 +250,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
 constexpr int kRedfinParts = 5;
 constexpr int kRedfinGroups = 16;
 __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int nblk, int fxrows,
+                                                unsigned long long *tail, int zero_tail,
                                                 int npartS, const double *partAcc, const double *Acc,
                                                 const double *partS, const double *e, const double *u,
                                                 const double *alpha0, double *Nc, double *N, double *w,
@@ -261,10 +281,15 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
   if (fx) s = __longlong_as_double(si);  // carried through the LDS exchange as bits
   // per-group operands of the math below: loaded now, needed after the reductions
   double ug0 = 0.0, eg0 = 0.0, al0 = 0.0;
+  long long th = 0, tl = 0;  // the guarded ECs' shares of the group (sell.hpp), two fixed-point limbs
   if (tid < kRedfinGroups && g < G) {
     ug0 = u[g];
     eg0 = e[g];
     al0 = alpha0[g];
+    if (tail) {
+      th = (long long)tail[2 * (size_t)g];
+      tl = (long long)tail[2 * (size_t)g + 1];
+    }
   }
   // W = sum_j r_j (and, for k_fin, the other two ELBO sums): every workgroup forms them in the
   // same fixed order
@@ -275,6 +300,10 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
     t[2] += partS[4 * b + 2];
   }
   if (s0.done) return;
+  if (tail && zero_tail && tid < kRedfinGroups && g < G && (th | tl)) {  // consumed: ready for the next pass B
+    tail[2 * (size_t)g] = 0;
+    tail[2 * (size_t)g + 1] = 0;
+  }
   accs[rs][gl] = s;
   block_sum_n<3>(t, sh);  // its barriers also publish accs
   const double W = t[2];
@@ -291,7 +320,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
       long long ai = 0;
 #pragma unroll
       for (int i = 0; i < 64; ++i) ai += __double_as_longlong(accs[i][gl]);
-      A = (double)ai * s0.fx_inv;  // sum_j e_g r_j (x_gj - p0), in reads
+      A = (double)ai * s0.fx_inv * fx_pow2(eg0);  // sum_j e_g r_j (x_gj - p0), in reads
     } else {
 #pragma unroll
       for (int i = 0; i < 64; ++i) A += accs[i][gl];
@@ -301,6 +330,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
     const int flavor = s0.flavor;
     if (flavor == 0) {
       nc = fx ? fma(eg0, s0.p0 * W, A) : eg0 * (s0.p0 * W + A);
+      nc += (double)th * s0.fx_tinv + (double)tl * (s0.fx_tinv * 0x1p-36);
       muv = (s0.M - ug) * nc;
     } else {
       nc = A;
@@ -452,9 +482,10 @@ __global__ __launch_bounds__(1024) void k_sum_scalar(const Scalars *sc, int gate
 
 // out[g] = column sum of this rank's ECs (g < G); out[G .. G+3] = {sum c log Z, sum r H, sum r, 0}
 // in the layout of one partS entry, so that k_redfin / k_fin consume `out` as totals.
+// out = [G column sums][2 G limbs of the guarded ECs' shares (tail; zeroed once read)][4 ELBO terms]
 __global__ __launch_bounds__(1024) void k_colsum(const Scalars *sc, int G, int nrows, int fxrows, int npartS,
                                                 const double *partAcc, const double *Acc,
-                                                const double *partS, double *out) {
+                                                const double *partS, unsigned long long *tail, double *out) {
   __shared__ double sh[32];
   __shared__ double accs[16][64];
   if (sc->done) return;
@@ -471,10 +502,20 @@ __global__ __launch_bounds__(1024) void k_colsum(const Scalars *sc, int G, int n
     p2 = block_sum(p2, sh);
     p3 = block_sum(p3, sh);
     if (tid == 0) {
-      out[G] = p1;
-      out[G + 1] = p2;
-      out[G + 2] = p3;
-      out[G + 3] = 0.0;
+      out[3 * (size_t)G] = p1;
+      out[3 * (size_t)G + 1] = p2;
+      out[3 * (size_t)G + 2] = p3;
+      out[3 * (size_t)G + 3] = 0.0;
+    }
+  }
+  if (wv == 1 && g < G) {
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(out) + G;
+    const unsigned long long a0 = tail ? tail[2 * (size_t)g] : 0ull, a1 = tail ? tail[2 * (size_t)g + 1] : 0ull;
+    o[2 * (size_t)g] = a0;
+    o[2 * (size_t)g + 1] = a1;
+    if (a0 | a1) {
+      tail[2 * (size_t)g] = 0;
+      tail[2 * (size_t)g + 1] = 0;
     }
   }
   const bool fx = kFx && fxrows;  // fixed-point rows: integer sums, handed on as bits (all-reduced as integers)
@@ -559,7 +600,8 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
                                                     const double *alpha0, double *u, double *os_u,
                                                     double *step_u, double tol, int max_iters,
                                                     int fixed_iters, int trace_theta, int flavor,
-                                                    double logzi, double init_bound, int *tab_built) {
+                                                    double logzi, double init_bound, int *tab_built,
+                                                    const double *trange) {
   __shared__ double sh[32];
   const int tid = threadIdx.x, nt = blockDim.x;
   double s = 0.0;
@@ -589,13 +631,17 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
     z.fixed_iters = fixed_iters;
     z.trace_theta = trace_theta;
     z.flavor = flavor;
-    // units per read of the fixed-point column sums: sum c * SCALE < 2^61, and at most 2^38 so that a
-    // single addend has 13 bits of headroom below the 2^51 of the fast conversion (sweep_kernels.hpp)
     int ex = 0;
     frexp(csum > 1.0 ? csum : 1.0, &ex);  // csum < 2^ex
-    const int k = 61 - ex < 38 ? 61 - ex : 38;
+    const int k = 53 - ex < 40 ? 53 - ex : 40;   // 2 * 2^8 * csum * 2^K < 2^62 (sweep_kernels.hpp)
+    const int t = 61 - ex < 40 ? 61 - ex : 40;   // csum * 2^t < 2^61 (guarded ECs' shares, in reads)
     z.fx_scale = ldexp(1.0, k);
     z.fx_inv = ldexp(1.0, -k);
+    z.fx_tscale = ldexp(1.0, t);
+    z.fx_tinv = ldexp(1.0, -t);
+    z.tmax = fmax(trange[0], logzi);
+    z.tmin = fmin(trange[1], logzi);
+    z.xb = 1.0;
     *sc = z;
     tab_built[0] = -1;  // no tables yet
     tab_built[1] = 0;

@@ -38,19 +38,22 @@ constexpr int kLongStep = MSW_LONG_STEP;  // records per lane and step on the wa
 #ifndef MSW_PASSB_BATCH
 #define MSW_PASSB_BATCH 4
 #endif
-// Column sums in 64-bit FIXED POINT (default): every cell adds rint(SCALE * e_g * r_j * (x - p0)) -- its
-// contribution to N_g in reads, SCALE = Scalars::fx_scale, a power of two -- with an INTEGER LDS atomic.
-// Integer addition is associative: the sums no longer depend on the order in which the wavefronts of a
-// workgroup reach the atomics, so two runs of a solve are bit-identical (fp64 atomics: the stop test
-// sits in their rounding noise and a 10 M-read run stopped at 209 or 210 iterations), and the totals are
-// the same whatever the number of workgroups or ranks the ECs are spread over.
+// Column sums in 64-bit FIXED POINT (default), each group in units of its own binary exponent: a cell
+// adds rint(2^K * m_g * r_j * (x - p0)), m_g in [1, 2) the mantissa of e_g (e_g = m_g * 2^ex_g), with an
+// INTEGER LDS atomic; k_redfin scales the total by 2^(ex_g - K).  Integer addition is associative: the
+// sums no longer depend on the order in which the wavefronts of a workgroup reach the atomics, so two
+// runs of a solve are bit-identical (fp64 atomics: the stop test sits in their rounding noise and a
+// 10 M-read run stopped at 209 or 210 iterations), and the totals are the same whatever the number of
+// workgroups or ranks the ECs are spread over.  Taking the exponent from e_g keeps the RELATIVE
+// precision of every N_g near 2^-45 (a fixed grid in reads loses the groups that die out: with priors
+// below one digamma(N_g) has slope 1 / N_g^2 and an absolute 1e-10 reads is felt).  K = Scalars::fx_k:
+// m_g * sum_j r_j x_gj <= 2 * 2^8 * sum c (the guard keeps Z_j >= 2^-8 of the background sum) < 2^62.
 // MSW_FX=0 builds the fp64-atomic sweeps (A/B timing only); kFx lives in common.hpp.
 // double -> integer by the magic-number trick: for |q| < 2^51 the low 52 bits of (q + 1.5 * 2^52) hold
 // rint(q) in two's complement; subtracting the magic's bit pattern leaves it as a 64-bit integer.  The
 // magic's low dword is zero: the subtraction is ONE 32-bit operation on the high dword.
 constexpr double kFxMagic = 6755399441055744.0;             // 1.5 * 2^52 = 0x4338000000000000
 constexpr unsigned long long kFxMagicBits = 0x4338000000000000ull;
-constexpr double kFxLimit = 2251799813685248.0;             // 2^51
 __device__ __forceinline__ unsigned long long fx_bits(double scaled_r, double pk) {
   const double v = fma(scaled_r, pk, kFxMagic);
   const uint32_t hi = (uint32_t)__double2hiint(v) - (uint32_t)(kFxMagicBits >> 32);
@@ -531,11 +534,11 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     else
       atomicAdd(reinterpret_cast<V *>(acc_b + off), v);
   };
-  // kFx: a cell adds rint(rs * pk), rs = SCALE * r_j, pk = e_g * (x - p0).  |rs * pk| < 2^51 is what the
-  // magic-number conversion needs; |pk| <= Z + zbase for every cell of the EC, so ONE test per EC
-  // (rs * (Z + zbase) < 2^51) covers all its cells.  ECs that fail it -- a multiplicity in the
-  // thousands, or Z thousands of times below the background sum -- split each addend into two parts
-  // of 32 and 51 bits (two atomics; sums are modulo 2^64, so the parts need not be added together).
+  // kFx: a cell adds rint(rs * pk), rs = 2^K * r_j, pk = m_g * (x - p0).  |rs * pk| < 2^51 is what the
+  // magic-number conversion needs; |pk| < 2 * max(x, p0) <= 2 * xb (Scalars::xb bounds every table
+  // value of the pass), so ONE test per EC (rs * xb < 2^50) covers all its cells.  ECs that fail it
+  // -- a large multiplicity over a small Z -- split each addend into two parts of 32 and 51 bits (two
+  // atomics; sums are modulo 2^64, so the parts need not be added together).
   auto addFX = [&](RT r, double rs, double pk) { addACC(r, fx_bits(rs, pk)); };
   auto addFXwide = [&](RT r, double rs, double pk) {
     const double q = rs * pk;
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   };
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, hbase = p0 * uniform_d(sc->logzi) * U;
-  const double fxs = uniform_d(sc->fx_scale);
+  const double fxs = uniform_d(sc->fx_scale), fxlim = 0x1p50 / uniform_d(sc->xb);
   const double gthr = zbase * kGuardRatio;  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
   const uint32_t gcnt_off = (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 128u;
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
@@ -602,15 +605,11 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
 #pragma unroll
         for (int k = 0; k < B; ++k) {
           if (k0 + k < L) {
-            if constexpr (kFx && KP) {  // the scatter adds r_j * (e_g * (x - p0)): keep the product
-              const double pk = ev[k] * xt[k].x;
-              zs += pk;
-              if constexpr (KEEPN > 0) if (k0 + k < KEEPN) xv[k0 + k] = pk;
-            } else {
-              zs = fma(ev[k], xt[k].x, zs);
-              if constexpr (KP && KEEPN > 0) if (k0 + k < KEEPN) xv[k0 + k] = xt[k].x;
-            }
+            zs = fma(ev[k], xt[k].x, zs);
             hs = fma(ev[k], xt[k].y, hs);
+            // the scatter adds r_j * (x - p0) -- times the mantissa of e_g in the fixed-point build
+            if constexpr (KP && KEEPN > 0)
+              if (k0 + k < KEEPN) xv[k0 + k] = kFx ? fx_mant(ev[k]) * xt[k].x : xt[k].x;
           }
         }
       }
@@ -630,7 +629,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     };
     // scatter of up to kRegCells cells held in b; padding records point at the lane's own sentinel
     // group: no test, no shared address
-    // (kFx: rj is SCALE * r_j, the kept values are e_g * (x - p0); WIDE_ADD: the two-part adds)
+    // (kFx: rj is 2^K * r_j, the kept values are m_g * (x - p0); WIDE_ADD: the two-part adds)
     auto scatter = [&](RT(&b)[kRegCells], uint32_t n, double rj, auto KEPT, auto WIDE_ADD) {
       constexpr bool KP = decltype(KEPT)::value;
       constexpr bool WA = decltype(WIDE_ADD)::value;
@@ -639,8 +638,8 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         if ((uint32_t)k < n) {
           double x0, x1;
           if constexpr (kFx) {
-            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : E_(b[k]) * XM_(b[k]);
-            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : E_(b[k + 1]) * XM_(b[k + 1]);
+            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : fx_mant(E_(b[k])) * XM_(b[k]);
+            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : fx_mant(E_(b[k + 1])) * XM_(b[k + 1]);
             if constexpr (WA) {
               addFXwide(b[k], rj, x0);
               addFXwide(b[k + 1], rj, x1);
@@ -668,7 +667,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         s_W += rj;
         if constexpr (kFx) {
           const double rs = rj * fxs;
-          if (rs * (Z + zbase) < kFxLimit) scatter(sb.r, len, rs, std::true_type{}, std::false_type{});
+          if (rs < fxlim) scatter(sb.r, len, rs, std::true_type{}, std::false_type{});
           else scatter(sb.r, len, rs, std::true_type{}, std::true_type{});
         } else {
           scatter(sb.r, len, rj, std::true_type{}, std::false_type{});
@@ -726,7 +725,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         s_rH += rj * H;
         s_W += rj;
         const double rs = kFx ? rj * fxs : rj;
-        const bool narrow = !kFx || rs * (Z + zbase) < kFxLimit;
+        const bool narrow = !kFx || rs < fxlim;
         for (k0 = 0; k0 < len; k0 += kRegCells) {
           const uint32_t n = len - k0 < (uint32_t)kRegCells ? len - k0 : (uint32_t)kRegCells;
           load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, n, t);
@@ -801,14 +800,14 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
 #pragma unroll
         for (int u = 0; u < kLongStep; ++u) rc[u] = first[u];
         const double rs = kFx ? rj * fxs : rj;
-        const bool narrow = !kFx || rs * (Z + zbase) < kFxLimit;  // wave-uniform
+        const bool narrow = !kFx || rs < fxlim;  // wave-uniform
         for (uint32_t kb = c0;;) {
 #pragma unroll
           for (int q = 0; q < kLongStep; q += 4) {
             if (kb + 64u * q < c1) {
               double xm[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) xm[u] = kFx ? E_(rc[q + u]) * XM_(rc[q + u]) : XM_(rc[q + u]);
+              for (int u = 0; u < 4; ++u) xm[u] = kFx ? fx_mant(E_(rc[q + u])) * XM_(rc[q + u]) : XM_(rc[q + u]);
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 if constexpr (kFx) {
@@ -832,16 +831,22 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   // EC's c_j directly -- listed: c e_g x / Z, not listed: c e_g p0 / Z -- and the EC stays out of
   // W = sum r_j (the background share of the ordinary ECs).
   __syncthreads();
-  const uint32_t n_guard = *(lds_u32_t *)(size_t)gcnt_off;
+  const uint32_t n_guard = (GMODE != 4 || rg.first) ? *(lds_u32_t *)(size_t)gcnt_off : 0u;  // once, not per range run
   if (n_guard) {
     const uint32_t wv = uniform(tid >> 6), nwv = kPassThreadsB / 64;
     uint32_t *bits = GD.bits + (size_t)(blockIdx.x * 16 + wv) * GD.words;
     const double a = uniform_d(sc->a), logzi = uniform_d(sc->logzi);
-    // one column-sum update by group id: val = the group's share divided by e_g
-    auto add_share = [&](uint32_t g, double eg, double val) {
-      const RT rr = null_record<WIDE>(bhi + 8u * g, shift);
-      if constexpr (kFx) addFXwide(rr, fxs, eg * val);
-      else addACC(rr, val);
+    // A group's share of a guarded EC, in reads, goes to two global 64-bit fixed-point accumulators
+    // of the group (units 2^-t and 2^-(t+36) reads, 2^t = Scalars::fx_tscale): such a share can exceed any
+    // bound the group's own exponent allows for (c e_g p0 / Z with Z far below the background sum),
+    // while the shares of one EC always add up to c_j.  Global integer atomics: rare path.
+    const double tls = uniform_d(sc->fx_tscale);
+    auto add_share = [&](uint32_t g, double share) {
+      const double vh = fma(share, tls, kFxMagic);
+      const double qh = vh - kFxMagic;                     // rint(share * 2^t), exact
+      const double ql = fma(share, tls, -qh) * 0x1p36;     // remainder, |.| <= 2^35
+      atomicAdd(&GD.tail[2 * (size_t)g], fx_bits(1.0, qh));
+      atomicAdd(&GD.tail[2 * (size_t)g + 1], fx_bits(1.0, ql));
     };
     for (uint32_t i = wv; i < n_guard; i += nwv) {
       const uint32_t p = GD.list[(size_t)blockIdx.x * GD.cap + i];
@@ -871,13 +876,13 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
           s_rH += rj * H;
         }
         wave_cells<WIDE>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
-          add_share(g, e_g[g], rj * exp(a * GD.lut_area[ent]));
+          add_share(g, e_g[g] * rj * exp(a * GD.lut_area[ent]));
         });
         for (uint32_t w0 = lane; w0 < GD.words; w0 += 64) {
           const uint32_t listed = atomicAnd(&bits[w0], 0u);  // read and clear
           for (uint32_t b = 0; b < 32; ++b) {
             const uint32_t g = w0 * 32 + b;
-            if (g < G && !((listed >> b) & 1u)) add_share(g, e_g[g], rj * p0);
+            if (g < G && !((listed >> b) & 1u)) add_share(g, e_g[g] * (rj * p0));
           }
         }
       } else {

@@ -334,7 +334,7 @@ struct PassOut {
 
 // ECs whose Z comes out below this fraction of the background sum p0 * U are evaluated without the
 // background trick (the HIP sweeps use the same threshold, msweep_amd/csrc/sell.hpp)
-constexpr double kGuardRatio = 0x1p-20;
+constexpr double kGuardRatio = 0x1p-8;
 
 struct CsrL {
   const uint64_t *rowptr;
