@@ -277,7 +277,10 @@ def main():
                 "tol": 1e-6, "includes": "upload of log counts and prior, download of theta"}
     core.set_fixed_iters(True)
     core.prepare(logc, alpha0)               # inputs resident in HBM before the timed region
-    core.run(max_iters=max(a.warmup, 1))     # W untimed warm-up steps
+    # W untimed warm-up steps: the first W iterations of the solve (with its set-up: the evaluation of the
+    # initial state and the first iteration's rejected step); the K timed steps are the NEXT K iterations of
+    # the same solve (msw_core_continue) -- every kernel slot they need, rejected steps included
+    core.run(max_iters=max(a.warmup, 1))
 
     def sync():
         # barrier + device synchronisation on both sides of the timed region.  core.run() itself
@@ -291,7 +294,7 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    res = core.run(max_iters=a.steps)         # exactly K steps
+    res = core.continue_(a.steps)             # exactly K steps
     if dist is not None and not shard:
         gathered = comm.allgather(res["theta"])   # (world, G): the per-replicate abundances, RCCL all-gather
         assert gathered.shape == (world, G)
@@ -300,11 +303,11 @@ def main():
     tm0 = core.last_timing()
     log(f"timed {a.steps} steps in {dt:.3f}s")
     assert tm0["iters"] == a.steps, (tm0["iters"], a.steps)
-    # Same K steps again with HIP events around every sweep launch (on the solve stream) for the
+    # K more steps with HIP events around every sweep launch (on the solve stream) for the
     # per-kernel durations of the roofline object.  Kept out of the timed run: every event record
     # is a barrier packet that costs ~6 us of idle GPU between two kernels.
     core.set_profiling(True)
-    core.run(max_iters=a.steps)
+    core.continue_(a.steps)
     tm = core.last_timing()
     core.set_profiling(False)
     # the EM optimiser (--algorithm emgpu: one pass-B sweep + one O(G) kernel per iteration), same K

@@ -236,6 +236,10 @@ int msw_core_set_profiling(msw_handle h, int enabled);
 int msw_core_last_timing(msw_handle h, msw_timing *out);
 /* fixed-iteration mode for benchmarking: run exactly max_iters iterations (tol ignored) */
 int msw_core_set_fixed_iters(msw_handle h, int enabled);
+/* n_iters MORE iterations of the fixed-iteration RCG solve that last ran on the handle (msw_core_run in
+ * fixed-iteration mode): the optimiser state carries on where it stood.  bench.py's W warm-up steps are
+ * msw_core_run(W), its K timed steps msw_core_continue(K).  *iters_out = total iterations so far. */
+int msw_core_continue(msw_handle h, size_t n_iters, double *theta_out, size_t *iters_out, double *bound_out);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ EXPORTS = [
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
     "msw_core_set_fixed_iters", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
     "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
-    "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather",
+    "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_core_continue",
 ]
 
 
@@ -70,6 +70,7 @@ def load_library():
     L.msw_core_solve.argtypes = [vp, vp, vp, dp, sz, C.c_int, C.c_int, vp, C.POINTER(sz), C.POINTER(dp)]
     L.msw_core_prepare.argtypes = [vp, vp, vp]
     L.msw_core_run.argtypes = [vp, dp, sz, C.c_int, C.c_int, vp, C.POINTER(sz), C.POINTER(dp)]
+    L.msw_core_continue.argtypes = [vp, sz, vp, C.POINTER(sz), C.POINTER(dp)]
     L.msw_core_gamma.argtypes = [vp, vp, sz]
     L.msw_core_trace.argtypes = [vp, sz, vp, vp, vp, vp, vp, C.POINTER(sz)]
     L.msw_core_set_trace_theta.argtypes = [vp, sz]
@@ -252,6 +253,14 @@ class Core:
         it, b = C.c_size_t(), C.c_double()
         self._check(self._L.msw_core_run(self._h, float(tol), int(max_iters), int(algo), int(prec), _ptr(theta),
                                          C.byref(it), C.byref(b)))
+        return dict(theta=theta, iters=it.value, bound=b.value)
+
+    def continue_(self, n_iters):
+        """n_iters more iterations of the fixed-iteration RCG solve that last ran (msw_core_continue)."""
+        G, _, _ = self.shape()
+        theta = np.empty(G)
+        it, b = C.c_size_t(), C.c_double()
+        self._check(self._L.msw_core_continue(self._h, int(n_iters), _ptr(theta), C.byref(it), C.byref(b)))
         return dict(theta=theta, iters=it.value, bound=b.value)
 
     def gamma(self):

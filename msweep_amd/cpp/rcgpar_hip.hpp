@@ -1,15 +1,20 @@
 // rcgpar_hip.hpp -- C++ host shim over the C ABI (include/msweep_core.h) with the signatures
 // mSWEEP's rcg_optl() wrapper calls (reference: src/mSWEEP.cpp:176-205, 419-423, 512-516):
 //
-//   rcgpar::rcg_optl_torch(logl, log_times_observed, alpha0, tol, max_iters, log)
-//   rcgpar::em_torch      (logl, log_times_observed, alpha0, tol, max_iters, log, precision)
-//   rcgpar::mixture_components_torch(probs, log_times_observed)
+//   rcgpar::rcg_optl_torch(logl, log_times_observed, alpha0, tol, max_iters, log)          :194
+//   rcgpar::rcg_optl_omp  (logl, log_times_observed, alpha0, tol, max_iters, log)          :198
+//   rcgpar::em_torch      (logl, log_times_observed, alpha0, tol, max_iters, log, precision) :202
+//   rcgpar::mixture_components[_torch](probs, log_times_observed)                          :420,422,513,515
 //
 // `logl` is any matrix type with get_rows() / get_cols() / operator()(row, col) -- the part of
 // seamat::Matrix<double> the reference uses (include/Likelihood.hpp:176,182,258; Sample.hpp:84-85).
-// The return type is a template parameter so that mSWEEP instantiates it with
-// seamat::DenseMatrix<double> (constructible as (rows, cols, fill), writable through
-// operator()); `msw::DenseMatrix` below is a stand-alone equivalent for tests.
+// The optimisers return msw::Gamma, which converts to whatever dense matrix type the caller names
+// (constructible as (rows, cols, fill), writable through operator()(row, col)): the reference's
+//     const seamat::DenseMatrix<double> &ec_probs = rcgpar::rcg_optl_omp(ll_mat, ...);
+// compiles as written, with no template argument and no seamat header here (tests/cpp/
+// reference_calls_test.cpp holds the five call expressions against stand-in seamat types).
+// rcg_optl_omp -- the reference's DEFAULT --algorithm rcgcpu -- runs the same algorithm as
+// rcg_optl_torch and is served by the same HIP kernels: this core has no CPU path.
 // A non-zero C-ABI status becomes std::runtime_error, which mSWEEP's try/catch blocks
 // (src/mSWEEP.cpp:400-406, 506-511) already handle.
 //
@@ -23,6 +28,7 @@
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/msweep_core.h"
@@ -49,6 +55,29 @@ inline void check(msw_handle h, int rc) {
   if (rc != 0) throw std::runtime_error(msw_last_error(h));
 }
 
+// The G x E log-responsibility matrix an optimiser returns (rows = groups), convertible to the caller's
+// dense matrix type.
+class Gamma {
+ public:
+  Gamma(size_t rows, size_t cols) : r_(rows), c_(cols), v_(rows * cols) {}
+  size_t get_rows() const { return r_; }
+  size_t get_cols() const { return c_; }
+  const double &operator()(size_t r, size_t c) const { return v_[r * c_ + c]; }
+  double *data() { return v_.data(); }
+  template <class DenseT, class = decltype(DenseT(size_t(1), size_t(1), 0.0)),
+            class = decltype(std::declval<DenseT &>()(size_t(0), size_t(0)) = 0.0)>
+  operator DenseT() const {
+    DenseT out(r_, c_, 0.0);
+    for (size_t g = 0; g < r_; ++g)
+      for (size_t j = 0; j < c_; ++j) out(g, j) = v_[g * c_ + j];
+    return out;
+  }
+
+ private:
+  size_t r_, c_;
+  std::vector<double> v_;
+};
+
 // One grouping's likelihood, resident on one GPU.
 class DeviceLikelihood {
  public:
@@ -73,10 +102,47 @@ class DeviceLikelihood {
                size_t n_groups) {
     check(h_, msw_core_set_csr(h_, rowptr.data(), grp.data(), cnt.data(), lut.data(), lut_ld, logzi, n_groups,
                                rowptr.size() - 1));
+    mask_.assign(n_groups, true);
+    logc_.clear();
+    built_ = false;
+  }
+  // ConstructAdaptiveLikelihood (include/Likelihood.hpp:333-380) on the device: the pseudoalignment's
+  // equivalence classes (targets per EC, reads per EC), the group indicators and sizes, -q / -e,
+  // --min-hits and the zero inflation.  Afterwards log_counts() / groups_considered() hold what the
+  // reference's accessors of the same names return (:325-331) and solve() may pass no log counts at all.
+  void build(const std::vector<uint64_t> &ec_tptr, const std::vector<uint32_t> &ec_targets,
+             const std::vector<uint32_t> &target_group, const std::vector<uint64_t> &group_sizes,
+             const std::vector<uint64_t> &ec_counts, double q, double e, size_t min_hits, double zero_inflation) {
+    const size_t E = ec_counts.size(), G = group_sizes.size();
+    if (ec_tptr.size() != E + 1) throw std::runtime_error("DeviceLikelihood::build: ec_tptr must have n_ecs + 1 entries");
+    std::vector<uint8_t> mask(G, 0);
+    logc_.assign(E, 0.0);
+    size_t kept = 0;
+    check(h_, msw_core_build_likelihood(h_, ec_tptr.data(), ec_targets.data(), E, target_group.data(),
+                                        target_group.size(), group_sizes.data(), G, ec_counts.data(), q, e,
+                                        zero_inflation, min_hits, &kept, mask.data(), logc_.data()));
+    mask_.assign(mask.begin(), mask.end());
+    built_ = true;
+  }
+  const std::vector<double> &log_counts() const { return logc_; }          // Likelihood::log_counts()
+  const std::vector<bool> &groups_considered() const { return mask_; }     // Likelihood::groups_considered()
+  bool built_on_device() const { return built_; }
+  size_t n_groups() const {  // groups of the resident likelihood (after --min-hits masking)
+    size_t g = 0;
+    check(h_, msw_core_shape(h_, &g, nullptr, nullptr));
+    return g;
+  }
+  size_t n_ecs() const {
+    size_t e = 0;
+    check(h_, msw_core_shape(h_, nullptr, &e, nullptr));
+    return e;
   }
 
  private:
   msw_handle h_ = nullptr;
+  std::vector<double> logc_;
+  std::vector<bool> mask_;
+  bool built_ = false;
 };
 
 struct Estimate {
@@ -90,8 +156,10 @@ inline Estimate solve(DeviceLikelihood &lik, const std::vector<double> &log_time
                       std::ostream *log) {
   Estimate r;
   r.theta.resize(alpha0.size());
-  check(lik.handle(), msw_core_solve(lik.handle(), log_times_observed.data(), alpha0.data(), tol, max_iters, algo,
-                                     prec, r.theta.data(), &r.iters, &r.bound));
+  // no log counts given and the likelihood was built on the device: they are still there (no upload)
+  const double *logc = log_times_observed.empty() && lik.built_on_device() ? nullptr : log_times_observed.data();
+  check(lik.handle(), msw_core_solve(lik.handle(), logc, alpha0.data(), tol, max_iters, algo, prec, r.theta.data(),
+                                     &r.iters, &r.bound));
   if (log && log->good()) {  // rcgpar logs every 5th iteration
     const size_t n = r.iters < 4096 ? r.iters : 4096;
     std::vector<double> b(n), g(n);
@@ -102,13 +170,9 @@ inline Estimate solve(DeviceLikelihood &lik, const std::vector<double> &log_time
   return r;
 }
 
-template <class DenseT>
-DenseT gamma_of(DeviceLikelihood &lik, size_t n_groups, size_t n_ecs) {
-  std::vector<double> buf(n_groups * n_ecs);
-  check(lik.handle(), msw_core_gamma(lik.handle(), buf.data(), n_ecs));
-  DenseT out(n_groups, n_ecs, 0.0);
-  for (size_t g = 0; g < n_groups; ++g)
-    for (size_t j = 0; j < n_ecs; ++j) out(g, j) = buf[g * n_ecs + j];
+inline Gamma gamma_of(DeviceLikelihood &lik, size_t n_groups, size_t n_ecs) {
+  Gamma out(n_groups, n_ecs);
+  check(lik.handle(), msw_core_gamma(lik.handle(), out.data(), n_ecs));
   return out;
 }
 
@@ -117,32 +181,41 @@ DenseT gamma_of(DeviceLikelihood &lik, size_t n_groups, size_t n_ecs) {
 namespace rcgpar {
 
 // Drop-in for the call at src/mSWEEP.cpp:194 (a dense `ll_mat` is uploaded for the call).
-template <class DenseT = msw::DenseMatrix, class MatrixT>
-DenseT rcg_optl_torch(const MatrixT &logl, const std::vector<double> &log_times_observed,
-                      const std::vector<double> &alpha0, const double &tol, size_t max_iters, std::ostream &log,
-                      int device = 0) {
+template <class MatrixT>
+msw::Gamma rcg_optl_torch(const MatrixT &logl, const std::vector<double> &log_times_observed,
+                          const std::vector<double> &alpha0, const double &tol, size_t max_iters, std::ostream &log,
+                          int device = 0) {
   msw::DeviceLikelihood lik(device);
   lik.set_dense(logl);
   msw::solve(lik, log_times_observed, alpha0, tol, max_iters, MSW_ALGO_RCG, MSW_PREC_DOUBLE, &log);
-  return msw::gamma_of<DenseT>(lik, logl.get_rows(), logl.get_cols());
+  return msw::gamma_of(lik, logl.get_rows(), logl.get_cols());
+}
+
+// Drop-in for the call at src/mSWEEP.cpp:198 (--algorithm rcgcpu, the reference's default): the same
+// RCG algorithm, run by the HIP kernels.
+template <class MatrixT>
+msw::Gamma rcg_optl_omp(const MatrixT &logl, const std::vector<double> &log_times_observed,
+                        const std::vector<double> &alpha0, const double &tol, size_t max_iters, std::ostream &log,
+                        int device = 0) {
+  return rcg_optl_torch(logl, log_times_observed, alpha0, tol, max_iters, log, device);
 }
 
 // Drop-in for the call at src/mSWEEP.cpp:202.
-template <class DenseT = msw::DenseMatrix, class MatrixT>
-DenseT em_torch(const MatrixT &logl, const std::vector<double> &log_times_observed,
-                const std::vector<double> &alpha0, const double &tol, size_t max_iters, std::ostream &log,
-                std::string precision, int device = 0) {
+template <class MatrixT>
+msw::Gamma em_torch(const MatrixT &logl, const std::vector<double> &log_times_observed,
+                    const std::vector<double> &alpha0, const double &tol, size_t max_iters, std::ostream &log,
+                    std::string precision, int device = 0) {
   if (precision != "double" && precision != "float") throw std::runtime_error("em_torch: unknown precision " + precision);
   msw::DeviceLikelihood lik(device);
   lik.set_dense(logl);
   msw::solve(lik, log_times_observed, alpha0, tol, max_iters, MSW_ALGO_EM,
              precision == "float" ? MSW_PREC_FLOAT : MSW_PREC_DOUBLE, &log);
-  return msw::gamma_of<DenseT>(lik, logl.get_rows(), logl.get_cols());
+  return msw::gamma_of(lik, logl.get_rows(), logl.get_cols());
 }
 
-// rcgpar::mixture_components[_torch] (src/mSWEEP.cpp:420,422): theta_g = sum_j exp(gamma_gj + logc_j) / sum_j c_j.
-// Host loop over the returned matrix, as the reference does; with msw::solve() the same vector is
-// already available as Estimate::theta without materialising gamma.
+// rcgpar::mixture_components[_torch] (src/mSWEEP.cpp:420,422,513,515): theta_g = sum_j exp(gamma_gj + logc_j) /
+// sum_j c_j.  Host loop over the returned matrix, as the reference does; with msw::solve() the same vector
+// is already available as Estimate::theta without materialising gamma.
 template <class MatrixT>
 std::vector<double> mixture_components_torch(const MatrixT &probs, const std::vector<double> &log_times_observed) {
   const size_t G = probs.get_rows(), E = probs.get_cols();
@@ -155,6 +228,10 @@ std::vector<double> mixture_components_torch(const MatrixT &probs, const std::ve
     theta[g] = acc / total;
   }
   return theta;
+}
+template <class MatrixT>
+std::vector<double> mixture_components(const MatrixT &probs, const std::vector<double> &log_times_observed) {
+  return mixture_components_torch(probs, log_times_observed);
 }
 
 }  // namespace rcgpar

@@ -84,14 +84,18 @@ __device__ __forceinline__ double block_max(double v, double *sh) {
   return r;
 }
 
-// e = fx_mant(e) * fx_pow2(e) for a positive normal double: mantissa in [1, 2) and binary exponent as
-// doubles (fixed-point column sums, sweep_kernels.hpp; 0 -> pow2 0: such a group receives nothing, and
-// denormal weights are flushed to 0 where e_g is formed)
-__device__ __forceinline__ double fx_mant(double e) {
-  return __hiloint2double((__double2hiint(e) & 0x000FFFFF) | 0x3FF00000, __double2loint(e));
-}
-__device__ __forceinline__ double fx_pow2(double e) {
-  return __hiloint2double(__double2hiint(e) & 0x7FF00000, 0);
+// Fixed-point column sums (sweep_kernels.hpp): a cell of group g adds rint(2^K * r_j * (x - p0) * f_g),
+//   f_g = e_g                    for e_g >= 2^-9   (units of 2^-K reads)
+//   f_g = mantissa(e_g) * 2^-9   below             (units of 2^-K * e_g / f_g reads: finer by a power of two)
+// i.e. f_g = max(e_g, mantissa(e_g) * 2^-9), and k_redfin scales the group's total by 2^-K * e_g / f_g.
+// N_g <= sum c bounds the first kind, N_g <= e_g * 2^8 * sum c (the guard keeps Z_j above 2^-8 of the
+// background sum) the second: both totals stay below 2 * sum c * 2^K < 2^62.  A group that dies out keeps
+// its relative precision (with priors below one digamma(N_g) has slope 1 / N_g^2 and a fixed grid in
+// reads is felt), the large groups keep the absolute one.  e_g = 0: f_g = 2^-9, e_g / f_g = 0 -- whatever
+// the cells add is discarded (denormal weights are flushed to 0 where e_g is formed).
+__device__ __forceinline__ double fx_factor(double e) {
+  const double m9 = __hiloint2double((__double2hiint(e) & 0x000FFFFF) | ((1023 - 9) << 20), __double2loint(e));
+  return fmax(e, m9);
 }
 __device__ __forceinline__ double flush_denormal(double e) { return e < 0x1p-1000 ? 0.0 : e; }
 

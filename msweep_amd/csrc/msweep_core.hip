@@ -537,20 +537,23 @@ void begin_solve(msw_core *h, double tol, size_t max_iters) {
   MSW_HIP(hipGetLastError());
 }
 
-void run_rcg(msw_core *h, size_t max_iters) {
+// iters_start > 0: the solve on the handle is continued (msw_core_continue) -- no initial evaluation
+void run_rcg(msw_core *h, size_t max_iters, size_t iters_start = 0) {
   const int G = (int)h->G, n_lut = h->n_tab_inline();
-  // initial update_N_k on gamma = log(1/G)
-  hipLaunchKernelGGL(k_prepB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->u.p, h->lut_area.p,
-                     h->e.p, h->tabs());
-  launch_tables(h);
-  launch_passB(h);
-  h->timing.passB_launches--;  // the initial evaluation is not an iteration
-  if (h->profiling && h->evB_used) h->evB_used--;
-  launch_fin(h, 2);
+  if (iters_start == 0) {
+    // initial update_N_k on gamma = log(1/G)
+    hipLaunchKernelGGL(k_prepB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->u.p, h->lut_area.p,
+                       h->e.p, h->tabs());
+    launch_tables(h);
+    launch_passB(h);
+    h->timing.passB_launches--;  // the initial evaluation is not an iteration
+    if (h->profiling && h->evB_used) h->evB_used--;
+    launch_fin(h, 2);
+  }
   const int nbA = h->flavor == 0 ? h->nblk : h->nblk_dense;
   // Slots (state_kernels.hpp): one per iteration plus one per rejected step.  Enqueue as many as
   // iterations are still missing, poll, repeat; nothing is launched for branches not taken.
-  size_t iters_done = 0;
+  size_t iters_done = iters_start;
   for (;;) {
     // fixed-iteration runs know how many slots are missing; otherwise poll every kIterBatch
     const size_t batch = h->fixed_iters ? std::min<size_t>(256, max_iters - iters_done)
@@ -637,6 +640,25 @@ void collect_timing(msw_core *h) {
 }
 
 void run_em(msw_core *h, size_t max_iters, int prec);
+
+// n more iterations of the fixed-iteration RCG solve that last ran on the handle: the state carries on
+// where it stood (no re-initialisation, no initial evaluation) -- what a benchmark's "W warm-up steps,
+// then exactly K timed steps" means for an iterative solver.
+void continue_impl(msw_core *h, size_t n_iters, double *theta_out, size_t *iters_out, double *bound_out) {
+  if (!h->have_solution || !h->fixed_iters || h->last_algo != MSW_ALGO_RCG)
+    throw Fail("msw_core_continue: needs a fixed-iteration RCG solve on the handle (msw_core_set_fixed_iters, msw_core_run)");
+  const size_t start = (size_t)h->sc_host->iter;
+  if (n_iters == 0 || start + n_iters > (size_t)std::numeric_limits<int32_t>::max()) throw Fail("msw_core_continue: iteration count out of range");
+  h->timing = {};
+  h->evA_used = h->evB_used = 0;
+  hipLaunchKernelGGL(k_extend, dim3(1), dim3(1), 0, h->stream, h->sc.p, (int)n_iters);
+  MSW_HIP(hipEventRecord(h->ev0, h->stream));
+  run_rcg(h, start + n_iters, start);
+  MSW_HIP(hipEventRecord(h->ev1, h->stream));
+  finish_solve(h, theta_out, iters_out, bound_out);
+  collect_timing(h);
+  h->timing.iters = (uint64_t)h->sc_host->iter - start;
+}
 
 void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, double *theta_out,
               size_t *iters_out, double *bound_out) {
@@ -772,6 +794,10 @@ int msw_core_prepare(msw_handle h, const double *logc, const double *alpha0) {
 int msw_core_run(msw_handle h, double tol, size_t max_iters, int algo, int prec, double *theta_out,
                  size_t *iters_out, double *bound_out) {
   return guarded(h, [&] { run_impl(h, tol, max_iters, algo, prec, theta_out, iters_out, bound_out); });
+}
+
+int msw_core_continue(msw_handle h, size_t n_iters, double *theta_out, size_t *iters_out, double *bound_out) {
+  return guarded(h, [&] { continue_impl(h, n_iters, theta_out, iters_out, bound_out); });
 }
 
 int msw_core_set_trace_theta(msw_handle h, size_t n_iters) {

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
       long long ai = 0;
 #pragma unroll
       for (int i = 0; i < 64; ++i) ai += __double_as_longlong(accs[i][gl]);
-      A = (double)ai * s0.fx_inv * fx_pow2(eg0);  // sum_j e_g r_j (x_gj - p0), in reads
+      A = (double)ai * s0.fx_inv * (eg0 / fx_factor(eg0));  // sum_j e_g r_j (x_gj - p0), in reads (exact scaling)
     } else {
 #pragma unroll
       for (int i = 0; i < 64; ++i) A += accs[i][gl];
@@ -596,6 +596,12 @@ __global__ __launch_bounds__(256) void k_cvec_from_counts(const uint32_t *cnt, c
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
+// fixed-iteration runs: n more iterations of the solve that has just finished its quota
+__global__ void k_extend(Scalars *sc, int n) {
+  sc->max_iters += n;
+  sc->done = 0;
+}
+
 __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npart, const double *part,
                                                     const double *alpha0, double *u, double *os_u,
                                                     double *step_u, double tol, int max_iters,
@@ -633,7 +639,7 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
     z.flavor = flavor;
     int ex = 0;
     frexp(csum > 1.0 ? csum : 1.0, &ex);  // csum < 2^ex
-    const int k = 53 - ex < 40 ? 53 - ex : 40;   // 2 * 2^8 * csum * 2^K < 2^62 (sweep_kernels.hpp)
+    const int k = 61 - ex < 44 ? 61 - ex : 44;   // csum * 2^K < 2^61 (device_util.hpp fx_factor)
     const int t = 61 - ex < 40 ? 61 - ex : 40;   // csum * 2^t < 2^61 (guarded ECs' shares, in reads)
     z.fx_scale = ldexp(1.0, k);
     z.fx_inv = ldexp(1.0, -k);

@@ -38,16 +38,13 @@ constexpr int kLongStep = MSW_LONG_STEP;  // records per lane and step on the wa
 #ifndef MSW_PASSB_BATCH
 #define MSW_PASSB_BATCH 4
 #endif
-// Column sums in 64-bit FIXED POINT (default), each group in units of its own binary exponent: a cell
-// adds rint(2^K * m_g * r_j * (x - p0)), m_g in [1, 2) the mantissa of e_g (e_g = m_g * 2^ex_g), with an
-// INTEGER LDS atomic; k_redfin scales the total by 2^(ex_g - K).  Integer addition is associative: the
-// sums no longer depend on the order in which the wavefronts of a workgroup reach the atomics, so two
+// Column sums in 64-bit FIXED POINT (default): a cell adds rint(2^K * f_g * r_j * (x - p0)) with an INTEGER
+// LDS atomic (f_g: e_g, or a power-of-two multiple of it for the groups far below the largest --
+// device_util.hpp fx_factor); k_redfin turns the totals back into reads.  Integer addition is associative:
+// the sums no longer depend on the order in which the wavefronts of a workgroup reach the atomics, so two
 // runs of a solve are bit-identical (fp64 atomics: the stop test sits in their rounding noise and a
 // 10 M-read run stopped at 209 or 210 iterations), and the totals are the same whatever the number of
-// workgroups or ranks the ECs are spread over.  Taking the exponent from e_g keeps the RELATIVE
-// precision of every N_g near 2^-45 (a fixed grid in reads loses the groups that die out: with priors
-// below one digamma(N_g) has slope 1 / N_g^2 and an absolute 1e-10 reads is felt).  K = Scalars::fx_k:
-// m_g * sum_j r_j x_gj <= 2 * 2^8 * sum c (the guard keeps Z_j >= 2^-8 of the background sum) < 2^62.
+// workgroups or ranks the ECs are spread over.  2^K = Scalars::fx_scale, sum c * 2^K < 2^61.
 // MSW_FX=0 builds the fp64-atomic sweeps (A/B timing only); kFx lives in common.hpp.
 // double -> integer by the magic-number trick: for |q| < 2^51 the low 52 bits of (q + 1.5 * 2^52) hold
 // rint(q) in two's complement; subtracting the magic's bit pattern leaves it as a 64-bit integer.  The
@@ -534,11 +531,11 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     else
       atomicAdd(reinterpret_cast<V *>(acc_b + off), v);
   };
-  // kFx: a cell adds rint(rs * pk), rs = 2^K * r_j, pk = m_g * (x - p0).  |rs * pk| < 2^51 is what the
-  // magic-number conversion needs; |pk| < 2 * max(x, p0) <= 2 * xb (Scalars::xb bounds every table
-  // value of the pass), so ONE test per EC (rs * xb < 2^50) covers all its cells.  ECs that fail it
-  // -- a large multiplicity over a small Z -- split each addend into two parts of 32 and 51 bits (two
-  // atomics; sums are modulo 2^64, so the parts need not be added together).
+  // kFx: a cell adds rint(rs * pk), rs = 2^K * r_j, pk = f_g * (x - p0).  |rs * pk| < 2^51 is what the
+  // magic-number conversion needs; |pk| <= max(e_g |x - p0|, 2^-8 max(x, p0)) <= max(Z + zbase, 2^-8 xb)
+  // (Scalars::xb bounds every table value of the pass), so ONE test per EC covers all its cells.  ECs
+  // that fail it -- a large multiplicity over a small Z -- split each addend into two parts of 32 and 51
+  // bits (two atomics; sums are modulo 2^64, so the parts need not be added together).
   auto addFX = [&](RT r, double rs, double pk) { addACC(r, fx_bits(rs, pk)); };
   auto addFXwide = [&](RT r, double rs, double pk) {
     const double q = rs * pk;
@@ -550,7 +547,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   };
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, hbase = p0 * uniform_d(sc->logzi) * U;
-  const double fxs = uniform_d(sc->fx_scale), fxlim = 0x1p50 / uniform_d(sc->xb);
+  const double fxs = uniform_d(sc->fx_scale), fxb = 0x1p-8 * uniform_d(sc->xb);
   const double gthr = zbase * kGuardRatio;  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
   const uint32_t gcnt_off = (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 128u;
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
@@ -607,9 +604,9 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
           if (k0 + k < L) {
             zs = fma(ev[k], xt[k].x, zs);
             hs = fma(ev[k], xt[k].y, hs);
-            // the scatter adds r_j * (x - p0) -- times the mantissa of e_g in the fixed-point build
+            // the scatter adds r_j * (x - p0) -- times f_g in the fixed-point build
             if constexpr (KP && KEEPN > 0)
-              if (k0 + k < KEEPN) xv[k0 + k] = kFx ? fx_mant(ev[k]) * xt[k].x : xt[k].x;
+              if (k0 + k < KEEPN) xv[k0 + k] = kFx ? fx_factor(ev[k]) * xt[k].x : xt[k].x;
           }
         }
       }
@@ -629,7 +626,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     };
     // scatter of up to kRegCells cells held in b; padding records point at the lane's own sentinel
     // group: no test, no shared address
-    // (kFx: rj is 2^K * r_j, the kept values are m_g * (x - p0); WIDE_ADD: the two-part adds)
+    // (kFx: rj is 2^K * r_j, the kept values are f_g * (x - p0); WIDE_ADD: the two-part adds)
     auto scatter = [&](RT(&b)[kRegCells], uint32_t n, double rj, auto KEPT, auto WIDE_ADD) {
       constexpr bool KP = decltype(KEPT)::value;
       constexpr bool WA = decltype(WIDE_ADD)::value;
@@ -638,8 +635,8 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         if ((uint32_t)k < n) {
           double x0, x1;
           if constexpr (kFx) {
-            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : fx_mant(E_(b[k])) * XM_(b[k]);
-            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : fx_mant(E_(b[k + 1])) * XM_(b[k + 1]);
+            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : fx_factor(E_(b[k])) * XM_(b[k]);
+            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : fx_factor(E_(b[k + 1])) * XM_(b[k + 1]);
             if constexpr (WA) {
               addFXwide(b[k], rj, x0);
               addFXwide(b[k + 1], rj, x1);
@@ -667,7 +664,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         s_W += rj;
         if constexpr (kFx) {
           const double rs = rj * fxs;
-          if (rs < fxlim) scatter(sb.r, len, rs, std::true_type{}, std::false_type{});
+          if (rs * fmax(Z + zbase, fxb) < 0x1p51) scatter(sb.r, len, rs, std::true_type{}, std::false_type{});
           else scatter(sb.r, len, rs, std::true_type{}, std::true_type{});
         } else {
           scatter(sb.r, len, rj, std::true_type{}, std::false_type{});
@@ -725,7 +722,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         s_rH += rj * H;
         s_W += rj;
         const double rs = kFx ? rj * fxs : rj;
-        const bool narrow = !kFx || rs < fxlim;
+        const bool narrow = !kFx || rs * fmax(Z + zbase, fxb) < 0x1p51;
         for (k0 = 0; k0 < len; k0 += kRegCells) {
           const uint32_t n = len - k0 < (uint32_t)kRegCells ? len - k0 : (uint32_t)kRegCells;
           load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, n, t);
@@ -800,14 +797,14 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
 #pragma unroll
         for (int u = 0; u < kLongStep; ++u) rc[u] = first[u];
         const double rs = kFx ? rj * fxs : rj;
-        const bool narrow = !kFx || rs < fxlim;  // wave-uniform
+        const bool narrow = !kFx || rs * fmax(Z + zbase, fxb) < 0x1p51;  // wave-uniform
         for (uint32_t kb = c0;;) {
 #pragma unroll
           for (int q = 0; q < kLongStep; q += 4) {
             if (kb + 64u * q < c1) {
               double xm[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) xm[u] = kFx ? fx_mant(E_(rc[q + u])) * XM_(rc[q + u]) : XM_(rc[q + u]);
+              for (int u = 0; u < 4; ++u) xm[u] = kFx ? fx_factor(E_(rc[q + u])) * XM_(rc[q + u]) : XM_(rc[q + u]);
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 if constexpr (kFx) {

@@ -126,6 +126,13 @@ void orc_discrete_cp(const uint32_t *weights, size_t n_ecs, double *cp_out);
 /* raw MT19937-64 words from a seed (for testing the device generator) */
 void orc_mt19937_64_words(uint64_t seed, size_t skip, size_t n, uint64_t *out);
 
+/* ---- --run-rate statistics (src/Sample.cpp:99-152) -------------------------------------- */
+/* Sample::dirichlet_kld + Sample::get_rates on the G x E log-responsibility matrix: alphas_i = sum_j
+ * round(c_j) additions of exp(gamma_ij), KLD_i clamped at 1e-16, RATE_i = KLD_i / sum KLD through the
+ * source's log-sum-exp (shift max(0, max log KLD)).  Outputs [G], any may be NULL. */
+void orc_dirichlet_kld_rate(const double *gamma, size_t G, size_t E, const double *logc,
+                            double *alphas_out, double *kld_out, double *rate_out);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

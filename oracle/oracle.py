@@ -75,6 +75,7 @@ class Oracle:
         L.orc_bootstrap_counts_restated.argtypes = [_u32p, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, _u32p]
         L.orc_discrete_cp.argtypes = [_u32p, C.c_size_t, _dp]
         L.orc_mt19937_64_words.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, _u64p]
+        L.orc_dirichlet_kld_rate.argtypes = [_dp, C.c_size_t, C.c_size_t, _dp, _dp, _dp, _dp]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
 
@@ -214,6 +215,14 @@ class Oracle:
         out = np.empty(n, np.uint64)
         self.lib.orc_mt19937_64_words(int(seed) & 0xFFFFFFFFFFFFFFFF, int(skip), int(n), out)
         return out
+
+    def dirichlet_kld_rate(self, gamma, logc):
+        """Sample::dirichlet_kld + get_rates (src/Sample.cpp:99-152): (alphas, KLD, RATE)."""
+        gamma = np.ascontiguousarray(gamma, np.float64)
+        G, E = gamma.shape
+        al, kld, rate = np.empty(G), np.empty(G), np.empty(G)
+        self.lib.orc_dirichlet_kld_rate(gamma, G, E, np.ascontiguousarray(logc, np.float64), al, kld, rate)
+        return al, kld, rate
 
     def num_threads(self):
         return self.lib.orc_num_threads()

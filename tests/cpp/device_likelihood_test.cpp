@@ -1,0 +1,37 @@
+// msw::DeviceLikelihood::build() / log_counts() / groups_considered() + msw::solve() with the log counts left
+// on the device: the C++ face of ConstructAdaptiveLikelihood + rcg_optl (include/Likelihood.hpp:321-380,
+// src/mSWEEP.cpp:346,402).  stdin: E H T G min_hits; ec_tptr[E+1]; ec_targets[H]; target_group[T];
+// group_sizes[G]; ec_counts[E].
+#include <cstdio>
+#include <iostream>
+
+#include "../../msweep_amd/cpp/rcgpar_hip.hpp"
+
+int main() {
+  size_t E, H, T, G, min_hits;
+  if (!(std::cin >> E >> H >> T >> G >> min_hits)) return 2;
+  std::vector<uint64_t> tptr(E + 1), sizes(G), counts(E);
+  std::vector<uint32_t> targets(H), tg(T);
+  for (auto &x : tptr) std::cin >> x;
+  for (auto &x : targets) std::cin >> x;
+  for (auto &x : tg) std::cin >> x;
+  for (auto &x : sizes) std::cin >> x;
+  for (auto &x : counts) std::cin >> x;
+  try {
+    msw::DeviceLikelihood lik(0);
+    lik.build(tptr, targets, tg, sizes, counts, 0.65, 0.01, min_hits, 0.01);
+    std::printf("n_groups %zu\nn_ecs %zu\nmask", lik.n_groups(), lik.n_ecs());
+    for (bool b : lik.groups_considered()) std::printf(" %d", b ? 1 : 0);
+    std::printf("\nlogc");
+    for (double x : lik.log_counts()) std::printf(" %.17g", x);
+    std::vector<double> alpha(lik.n_groups(), 1.0);
+    msw::Estimate est = msw::solve(lik, {}, alpha, 1e-6, 5000, MSW_ALGO_RCG, MSW_PREC_DOUBLE, nullptr);
+    std::printf("\niters %zu\ntheta", est.iters);
+    for (double t : est.theta) std::printf(" %.17g", t);
+    std::printf("\n");
+  } catch (const std::exception &ex) {
+    std::printf("exception %s\n", ex.what());
+    return 1;
+  }
+  return 0;
+}

@@ -53,3 +53,12 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".inc", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not bad.search(txt), (f, bad.search(txt).group(0))
+
+
+def test_reference_call_expressions_compile(tmp_path):
+    """The rcgpar call expressions of src/mSWEEP.cpp:194,198,202,420,422, verbatim, compile against the C++
+    shim (stand-in seamat types in the test TU); running them needs a GPU (tests/test_gpu_cpp_shim.py)."""
+    import subprocess
+    for tu in ("reference_calls_test", "shim_test", "device_likelihood_test"):
+        subprocess.check_call(["g++", "-std=c++17", "-O0", "-Wall", "-c", "-o", str(tmp_path / (tu + ".o")),
+                               os.path.join(ROOT, "tests", "cpp", tu + ".cpp")])

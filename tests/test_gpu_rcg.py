@@ -527,3 +527,25 @@ def test_solves_are_bit_reproducible(gpu_core):
     for th, it in runs[1:]:
         np.testing.assert_array_equal(th, runs[0][0])
         np.testing.assert_array_equal(it, runs[0][1])
+
+
+def test_continue_is_the_same_solve(gpu_core):
+    """msw_core_continue (bench.py: W warm-up steps, then K timed steps of the SAME solve): 5 + 20 iterations
+    give the bits of 25 in one go."""
+    p = synth.make_csr_problem(100_000, 300, seed=52, max_other=8)
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    alpha0 = np.ones(300)
+    gpu_core.set_fixed_iters(True)
+    try:
+        gpu_core.prepare(lik.log_counts(), alpha0)
+        whole = gpu_core.run(max_iters=25)
+        gpu_core.run(max_iters=5)
+        part = gpu_core.continue_(20)
+        tm = gpu_core.last_timing()
+    finally:
+        gpu_core.set_fixed_iters(False)
+    assert whole["iters"] == 25 and part["iters"] == 25 and tm["iters"] == 20
+    assert part["bound"] == whole["bound"]
+    np.testing.assert_array_equal(part["theta"], whole["theta"])
+    with pytest.raises(MswError, match="fixed-iteration"):
+        gpu_core.continue_(3)

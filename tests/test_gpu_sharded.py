@@ -75,7 +75,10 @@ def test_sharded_em(gpu_core):
     lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
     single = gpu_core.solve(lik.log_counts(), np.ones(80), tol=1e-8, algo=ALGO_EM, max_iters=20000)
     assert abs(out[0]["iters"] - single["iters"]) <= 2
-    np.testing.assert_allclose(out[0]["theta"], single["theta"], rtol=1e-6, atol=1e-10)
+    # compared after the same number of iterations (the stop sits in the last bits of the log-likelihood;
+    # one slow EM iteration moves the small weights by 1e-5)
+    same = gpu_core.solve(lik.log_counts(), np.ones(80), tol=-1.0, algo=ALGO_EM, max_iters=out[0]["iters"])
+    np.testing.assert_allclose(out[0]["theta"], same["theta"], rtol=1e-6, atol=1e-10)
     np.testing.assert_array_equal(out[0]["theta"], out[1]["theta"])
 
 
