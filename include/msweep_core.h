@@ -72,7 +72,10 @@ int msw_core_set_csr(msw_handle h, const uint64_t *rowptr, const uint32_t *grp,
  *   q, e               : -q / -e flags (bb_constants, include/Likelihood.hpp:212-214)
  *   min_hits           : --min-hits mask (include/Likelihood.hpp:141-171)
  * Outputs: *n_groups_out = groups kept, mask_out[G] = groups_considered() (:331),
- * logc_out[E] = log_counts() (:328); either may be NULL. */
+ * logc_out[E] = log_counts() (:328); either may be NULL.
+ * EC-sharded (msw_core_set_comm called first; every rank passes its own block of ECs and the same targets /
+ * groups): the --min-hits counts are all-reduced (G unsigned 64-bit integers, once), so every rank keeps
+ * the same groups in the same order. */
 int msw_core_build_likelihood(msw_handle h, const uint64_t *ec_tptr,
                               const uint32_t *ec_targets, size_t n_ecs,
                               const uint32_t *target_group, size_t n_targets,

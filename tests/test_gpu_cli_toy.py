@@ -184,3 +184,40 @@ def test_native_driver_errors(tmp_path, mini_binary):
     p = subprocess.run([mini_binary, "--themisto-1", str(tmp_path / "toy_1.txt"), "-i", str(tmp_path / "clustering.txt"),
                         "--alphas", "1,2"], capture_output=True, text=True, timeout=60)
     assert p.returncode == 1 and "--alphas must have the same number of values" in p.stderr
+
+
+def test_rate_kld_against_the_restated_reference(gpu_core, oracle):
+    """--run-rate (experimental in the reference): the product's host routine (msweep_amd/__main__.py
+    dirichlet_kld_rate, fed with the column sums the solve already has) against the oracle's restatement of
+    Sample::dirichlet_kld + get_rates on the G x E matrix (src/Sample.cpp:99-152: repeated additions per read,
+    the 1e-16 clamp, the log-sum-exp with its shift of max(0, max log KLD))."""
+    from msweep_amd.__main__ import dirichlet_kld_rate
+    from msweep_amd import synth
+    from msweep_amd.likelihood import from_grouped_counts
+    p = synth.make_csr_problem(4000, 25, seed=71, max_other=5, dirichlet=0.3)
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    res = gpu_core.solve(lik.log_counts(), np.ones(25))
+    gamma = gpu_core.gamma()
+    total = float(p["ec_counts"].sum())
+    kld, rate = dirichlet_kld_rate(res["theta"] * total)
+    al_o, kld_o, rate_o = oracle.dirichlet_kld_rate(gamma, lik.log_counts())
+    np.testing.assert_allclose(res["theta"] * total, al_o, rtol=1e-9)
+    np.testing.assert_allclose(kld, kld_o, rtol=1e-6)       # lgamma differences of ~1e4-sized arguments
+    np.testing.assert_allclose(rate, rate_o, rtol=1e-6)
+    assert rate.sum() == pytest.approx(1.0, rel=1e-12)
+    # a group nobody supports: KLD clamps at 1e-16 (src/Sample.cpp:126)
+    kld2, rate2 = dirichlet_kld_rate(np.array([5000.0, 1e-300, 3000.0]))
+    assert kld2[1] == pytest.approx(1e-16) and rate2.sum() == pytest.approx(1.0)
+
+
+def test_cli_probs_with_bootstrap_are_the_original_estimate(tmp_path, capsys):
+    """--iters N --write-probs: the probabilities written are those of the un-resampled estimate (the
+    reference writes them before its replicate loop, src/mSWEEP.cpp:437-493 vs :496)."""
+    _toy(tmp_path, n_reads=500)
+    base = ["--themisto-1", str(tmp_path / "toy_1.txt"), "--themisto-2", str(tmp_path / "toy_2.txt"),
+            "-i", str(tmp_path / "clustering.txt")]
+    assert main(base + ["-o", str(tmp_path / "plain"), "--write-probs"]) == 0
+    assert main(base + ["-o", str(tmp_path / "boot"), "--write-probs", "--iters", "3", "--seed", "7"]) == 0
+    assert open(str(tmp_path / "plain_probs.tsv")).read() == open(str(tmp_path / "boot_probs.tsv")).read()
+    head, _ = _parse(str(tmp_path / "boot_abundances.txt"))
+    assert head["#bootstrap_iters:"] == "3"

@@ -159,3 +159,55 @@ def test_rccl_allgather_single_rank():
         np.testing.assert_array_equal(comm.allgather(x), x[None, :])
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_sharded_build_with_min_hits_equals_single_handle(gpu_core, n_ranks):
+    """every rank builds the likelihood of its EC block on the device; the --min-hits
+    counts (include/Likelihood.hpp:146-163: hits of a group over ALL ECs) are all-reduced, so every rank
+    prunes the same groups; the EC-sharded solve on top gives the single-handle answer."""
+    from msweep_amd.likelihood import from_alignment
+    p = synth.make_csr_problem(40000, 400, seed=46, max_other=5, theta_support=60)
+    aln = synth.csr_to_targets(p)
+    G = 400
+    min_hits = 30                                   # prunes groups that a single shard would have kept
+    lik = from_alignment(gpu_core, aln["ec_tptr"], aln["ec_targets"], aln["target_group"], p["group_sizes"],
+                         p["ec_counts"], min_hits=min_hits)
+    single = gpu_core.solve(None, np.ones(lik.n_groups))
+    assert 1 < lik.n_groups < 60
+    bounds = shard_ecs(p["rowptr"], n_ranks)
+    tptr = aln["ec_tptr"].astype(np.int64)
+    comms = Comm.local(n_ranks)
+    out, err = [None] * n_ranks, []
+
+    def work(r):
+        try:
+            core = Core(0)
+            e0, e1 = bounds[r], bounds[r + 1]
+            core.set_comm(comms[r])
+            lk = from_alignment(core, (tptr[e0:e1 + 1] - tptr[e0]).astype(np.uint64), aln["ec_targets"][tptr[e0]:tptr[e1]],
+                                aln["target_group"], p["group_sizes"], p["ec_counts"][e0:e1], min_hits=min_hits)
+            res = core.solve(None, np.ones(lk.n_groups))
+            out[r] = (lk.groups_considered().copy(), lk.n_groups, res)
+            core.set_comm(None)
+            core.close()
+        except Exception as ex:
+            err.append(ex)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not err, err
+    # a shard on its own would see fewer hits: the test means something only if the global counts matter
+    local_hits = np.bincount(p["grp"][int(p["rowptr"][bounds[0]]):int(p["rowptr"][bounds[1]])],
+                             weights=np.repeat(p["ec_counts"][bounds[0]:bounds[1]],
+                                               np.diff(p["rowptr"][bounds[0]:bounds[1] + 1].astype(np.int64))), minlength=G)
+    assert np.any((local_hits >= min_hits) != lik.groups_considered())
+    for mask, ng, res in out:
+        np.testing.assert_array_equal(mask, lik.groups_considered())
+        assert ng == lik.n_groups
+        assert res["iters"] == single["iters"]
+        assert_theta(res["theta"], single["theta"])
+        np.testing.assert_array_equal(res["theta"], out[0][2]["theta"])

@@ -32,6 +32,19 @@ def burst(k, prof=False):
     return s
 
 
+def cont(k):
+    core.set_profiling(False)
+    t0 = time.perf_counter()
+    core.continue_(k)
+    dt = time.perf_counter() - t0
+    tm = core.last_timing()
+    return f"continue K={k:4d}: wall {dt * 1e3 / k:.4f} ms/step, device {tm['solve_ms'] / k:.4f} ms/step, slots {tm['passB_launches']}"
+
+
+print("one solve, continued:")
+print("  ", burst(5), flush=True)
+for k in (20, 20, 20, 20, 100, 20, 20):
+    print("  ", cont(k), flush=True)
 print("cold start:")
 for k in (5, 20, 20, 20, 200, 20, 20, 1000, 20, 20):
     print("  ", burst(k), flush=True)
