@@ -25,7 +25,8 @@ typedef struct msw_core *msw_handle;
 
 /* --algorithm (src/mSWEEP.cpp:127,192-204): rcggpu -> MSW_ALGO_RCG, emgpu -> MSW_ALGO_EM. */
 enum { MSW_ALGO_RCG = 0, MSW_ALGO_EM = 1 };
-/* --emprecision (src/mSWEEP.cpp:129,202) */
+/* --emprecision (src/mSWEEP.cpp:129,202).  Accepted and equivalent: both run the fp64 kernels and return
+ * the same bits (the reference's float mode exists to halve its G x E matrices, which do not exist here). */
 enum { MSW_PREC_DOUBLE = 0, MSW_PREC_FLOAT = 1 };
 
 /* ---- lifetime ---------------------------------------------------------------------- */

@@ -25,7 +25,7 @@ def parse(argv):
     ap.add_argument("-t", type=int, default=1, help="accepted for compatibility (the GPU core ignores it)")
     ap.add_argument("--max-iters", type=int, default=5000)
     ap.add_argument("--tol", type=float, default=0.000001)
-    ap.add_argument("--algorithm", default="rcggpu")
+    ap.add_argument("--algorithm", default="rcgcpu")   # the reference's default (src/mSWEEP.cpp:127); served by the GPU RCG kernels
     ap.add_argument("--emprecision", default="double")
     ap.add_argument("--iters", type=int, default=0)
     ap.add_argument("--seed", type=int, default=26012023)
@@ -111,10 +111,15 @@ def main(argv=None):
         sys.stderr.write(f"Reading the pseudoalignments failed:\n  {ex}\nexiting\n")
         return 1
     if a.algorithm == "rcgcpu":
-        sys.stderr.write("rcgcpu is the reference's CPU path; use rcggpu or emgpu with this core\n")
-        return 1
-    algo = ALGO_RCG if a.algorithm == "rcggpu" else ALGO_EM      # anything else -> em (src/mSWEEP.cpp:200)
+        # the reference's default: the same RCG algorithm on the host (rcgpar::rcg_optl_omp); this core runs it
+        # on the GPU -- there is no CPU path here
+        if a.verbose:
+            sys.stderr.write("note: --algorithm rcgcpu is served by the GPU RCG kernels (same algorithm as rcggpu)\n")
+    algo = ALGO_RCG if a.algorithm in ("rcggpu", "rcgcpu") else ALGO_EM   # anything else -> em (src/mSWEEP.cpp:200)
     prec = PREC_FLOAT if a.emprecision == "float" else PREC_DOUBLE
+    if algo == ALGO_EM and prec == PREC_FLOAT:
+        sys.stderr.write("note: --emprecision float is computed in double here (no G x E matrix exists whose "
+                         "footprint float would halve); results are those of --emprecision double\n")
     try:
         core = Core(a.device)
         if a.read_likelihood:

@@ -44,6 +44,33 @@ class Timing(C.Structure):
 _lib = None
 
 
+def source_hash():
+    """sha256 prefix over the library's sources (the same function as __graft_entry__.source_hash)."""
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".inc", ".h")))
+    for f in files + [os.path.join(os.path.dirname(_HERE), "include", "msweep_core.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _check_fresh(L):
+    """A library that was not compiled from the sources in this tree is refused (MSWEEP_CORE_LIB, the
+    developer override for A/B builds, is exempt): a stale prebuilt .so cannot pass silently."""
+    if os.environ.get("MSWEEP_CORE_LIB"):
+        return
+    ver = L.msw_core_version().decode()
+    try:
+        want = source_hash()
+    except OSError:
+        return          # installed without its sources: nothing to compare with
+    if not ver.endswith("src " + want):
+        raise MswError(f"{LIB_PATH} is stale: built from other sources ({ver}; the tree hashes to {want}). "
+                       "Rebuild: python -c 'import __graft_entry__ as g; g.build()'")
+
+
 def load_library():
     """dlopen the in-tree extension; raises if it has not been built."""
     global _lib
@@ -54,6 +81,8 @@ def load_library():
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, sz, dp = C.c_void_p, C.c_size_t, C.c_double
+    L.msw_core_version.restype = C.c_char_p
+    _check_fresh(L)
     L.msw_core_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.msw_core_destroy.argtypes = [vp]
     L.msw_core_destroy.restype = None

@@ -30,7 +30,7 @@ const char *kVersion = "msweep-amd-0.1.0";
 
 struct Args {
   std::vector<std::string> themisto;
-  std::string mode = "intersection", indicators, prefix, algorithm = "rcggpu", emprecision = "double", alphas;
+  std::string mode = "intersection", indicators, prefix, algorithm = "rcgcpu", emprecision = "double", alphas;
   size_t iters = 0, seed = 26012023, bootstrap_count = 0, min_hits = 0, max_iters = 5000;
   double q = 0.65, e = 0.01, zero_inflation = 0.01, tol = 1e-6;
   int gpu = 0;
@@ -153,12 +153,13 @@ int main(int argc, char **argv) {
     std::cerr << "Reading the pseudoalignments failed:\n  " << ex.what() << "\nexiting\n";
     return 1;
   }
-  if (a.algorithm == "rcgcpu") {
-    std::cerr << "rcgcpu is the reference's CPU path; use rcggpu or emgpu with this core\n";
-    return 1;
-  }
-  const int algo = a.algorithm == "rcggpu" ? MSW_ALGO_RCG : MSW_ALGO_EM;  // anything else -> em (src/mSWEEP.cpp:200)
+  if (a.algorithm == "rcgcpu" && a.verbose)  // the reference's default: the same RCG algorithm on the host; no CPU path here
+    std::cerr << "note: --algorithm rcgcpu is served by the GPU RCG kernels (same algorithm as rcggpu)\n";
+  const int algo = (a.algorithm == "rcggpu" || a.algorithm == "rcgcpu") ? MSW_ALGO_RCG : MSW_ALGO_EM;  // else em (src/mSWEEP.cpp:200)
   const int prec = a.emprecision == "float" ? MSW_PREC_FLOAT : MSW_PREC_DOUBLE;
+  if (algo == MSW_ALGO_EM && prec == MSW_PREC_FLOAT)
+    std::cerr << "note: --emprecision float is computed in double here (no G x E matrix exists whose footprint "
+                 "float would halve); results are those of --emprecision double\n";
   const size_t G = grouping.names.size();
   msw_handle h = nullptr;
   size_t n_kept = 0;

@@ -692,7 +692,11 @@ void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, dou
 // =========================================================================================
 extern "C" {
 
-const char *msw_core_version(void) { return "msweep_core 0.1 gfx950 (HIP, wave64)"; }
+#ifndef MSW_SRC_HASH
+#define MSW_SRC_HASH "unhashed"
+#endif
+// "... src <hash>": sha256 prefix of the sources this library was compiled from (__graft_entry__.source_hash)
+const char *msw_core_version(void) { return "msweep_core 0.2 gfx950 (HIP, wave64) src " MSW_SRC_HASH; }
 
 const char *msw_last_error(msw_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 

@@ -62,3 +62,14 @@ def test_reference_call_expressions_compile(tmp_path):
     for tu in ("reference_calls_test", "shim_test", "device_likelihood_test"):
         subprocess.check_call(["g++", "-std=c++17", "-O0", "-Wall", "-c", "-o", str(tmp_path / (tu + ".o")),
                                os.path.join(ROOT, "tests", "cpp", tu + ".cpp")])
+
+
+def test_library_carries_the_hash_of_its_sources():
+    """msw_core_version() ends with the sha256 prefix of the sources the .so was compiled from; build()
+    rebuilds and load_library() refuses a library that does not match the tree."""
+    import __graft_entry__ as g
+    lib = core.load_library()
+    want = g.source_hash()
+    assert core.source_hash() == want
+    assert lib.msw_core_version().decode().endswith("src " + want)
+    assert g.built_hash(g.LIB) == want

@@ -93,6 +93,24 @@ def test_native_reader_errors(tmp_path):
     assert r["n_reads"] == 3 and len(r["ec_counts"]) == 0 and r["ec_tptr"].tolist() == [0]
 
 
+def test_native_reader_huge_read_id_does_not_size_the_tables(tmp_path):
+    """A malformed line with read id 4e9 must not allocate (max id + 1) table entries: ids at or beyond the
+    line count never take part in the equivalence classes (include/mSWEEP_alignment.hpp:148) and are dropped."""
+    import resource
+    f = tmp_path / "huge.txt"
+    f.write_text("0 1 2\n1 3\n4000000000 5\n2 1 2\n")
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    r = read_alignment([str(f)], 10)
+    after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert after - before < 1_000_000                     # KiB: nowhere near 3 x 32 GB
+    g = tmp_path / "ok.txt"
+    g.write_text("0 1 2\n1 3\n3\n2 1 2\n")
+    ok = read_alignment([str(g)], 10)
+    for k in ("ec_tptr", "ec_targets", "ec_counts"):
+        np.testing.assert_array_equal(r[k], ok[k])
+    assert r["n_reads"] == ok["n_reads"] == 4
+
+
 def test_native_reader_multithreaded_chunks(tmp_path):
     """Files above 1 MB are parsed in per-thread chunks cut at line boundaries: same result as the
     mirror, and the line number of a late format error is that of the whole file."""

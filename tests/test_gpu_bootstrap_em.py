@@ -191,3 +191,15 @@ def test_replicates_in_flight_across_likelihood_changes(gpu_core, monkeypatch):
     w = np.random.default_rng(2).integers(1, 9, 3000).astype(np.uint32)
     both(w, int(w.sum()), 70)
 
+
+
+def test_emprecision_float_is_served_in_double(gpu_core):
+    """--emprecision float (src/mSWEEP.cpp:129,202): accepted, computed in fp64 -- the same bits as double
+    (msweep_amd/csrc/host_em.inc says why no fp32 variant exists)."""
+    from msweep_amd.core import PREC_DOUBLE, PREC_FLOAT
+    p = synth.make_csr_problem(20000, 60, seed=33, max_other=5)
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    d = gpu_core.solve(lik.log_counts(), np.ones(60), algo=ALGO_EM, prec=PREC_DOUBLE, max_iters=300)
+    f = gpu_core.solve(lik.log_counts(), np.ones(60), algo=ALGO_EM, prec=PREC_FLOAT, max_iters=300)
+    assert d["iters"] == f["iters"] and d["bound"] == f["bound"]
+    np.testing.assert_array_equal(d["theta"], f["theta"])
