@@ -124,6 +124,12 @@ int msw_core_run(msw_handle h, double tol, size_t max_iters, int algo, int prec,
  * dimension ld >= E.  Materialised on demand from the structured state. */
 int msw_core_gamma(msw_handle h, double *gamma_out, size_t ld);
 
+/* The columns [ec_begin, ec_end) of the same matrix: gamma_out[g * ld + (j - ec_begin)], ld >= ec_end -
+ * ec_begin.  What Sample::write_probs (src/Sample.cpp:63-85: one output line per EC) and the mGEMS binning
+ * input (src/mSWEEP.cpp:437-469) consume EC by EC: at the size of BASELINE's configurations the whole matrix
+ * is hundreds of GB (G x E x 8 B = 375 GB at 10 M reads x 5 k groups), a block of it is not. */
+int msw_core_gamma_block(msw_handle h, size_t ec_begin, size_t ec_end, double *gamma_out, size_t ld);
+
 /* Per-iteration diagnostics of the last solve (what rcgpar logs every 5th iteration to
  * the verbose stream, src/mSWEEP.cpp:198): arrays of length n (<= max recorded, 4096);
  * theta_trace is n x G or NULL.  Returns the number of iterations recorded via *n_out. */

@@ -63,10 +63,15 @@ def write_likelihood_file(f, ec_counts, L):
         f.write(str(int(ec_counts[j])) + "\t" + "\t".join("%g" % x for x in L[:, j]) + "\n")
 
 
-def write_probs(of, names, zero_names, probs):
+def write_probs(of, names, zero_names, core, block=8192):
+    """Sample::write_probs[2] (src/Sample.cpp:63-85,154-186), one line per EC, streamed from the device in
+    blocks of ECs (msw_core_gamma_block): the G x E matrix is never held, here or there."""
     of.write("ec_id\t" + "\t".join(list(names) + list(zero_names)) + "\n")
-    for j in range(probs.shape[1]):
-        of.write(str(j) + "\t" + "\t".join(["%g" % x for x in probs[:, j]] + ["0"] * len(zero_names)) + "\n")
+    E = core.shape()[1]
+    for e0 in range(0, E, block):
+        probs = np.exp(core.gamma_block(e0, min(E, e0 + block)))
+        for jj in range(probs.shape[1]):
+            of.write(str(e0 + jj) + "\t" + "\t".join(["%g" % x for x in probs[:, jj]] + ["0"] * len(zero_names)) + "\n")
     of.write("\n")
     of.flush()
 
@@ -180,10 +185,9 @@ def main(argv=None):
     zero = [n for n, m in zip(names, mask) if not m]
     if a.write_probs or a.print_probs:
         # Sample::write_probs (src/Sample.cpp:63-85): header ec_id + group names, one row per EC of exp(gamma)
-        probs = np.exp(core.gamma())
         for dst in ([open(f"{a.prefix}_probs.tsv", "w")] if a.write_probs and a.prefix else []) + \
                    ([sys.stdout] if a.print_probs or (a.write_probs and not a.prefix) else []):
-            write_probs(dst, est, zero if a.min_hits > 0 else [], probs)
+            write_probs(dst, est, zero if a.min_hits > 0 else [], core)
             if dst is not sys.stdout:
                 dst.close()
     out = open(f"{a.prefix}_abundances.txt", "w") if a.prefix else sys.stdout

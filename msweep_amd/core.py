@@ -27,7 +27,7 @@ EXPORTS = [
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
     "msw_core_set_fixed_iters", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
     "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
-    "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_core_continue",
+    "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_core_continue", "msw_core_gamma_block",
 ]
 
 
@@ -101,6 +101,7 @@ def load_library():
     L.msw_core_run.argtypes = [vp, dp, sz, C.c_int, C.c_int, vp, C.POINTER(sz), C.POINTER(dp)]
     L.msw_core_continue.argtypes = [vp, sz, vp, C.POINTER(sz), C.POINTER(dp)]
     L.msw_core_gamma.argtypes = [vp, vp, sz]
+    L.msw_core_gamma_block.argtypes = [vp, sz, sz, vp, sz]
     L.msw_core_trace.argtypes = [vp, sz, vp, vp, vp, vp, vp, C.POINTER(sz)]
     L.msw_core_set_trace_theta.argtypes = [vp, sz]
     L.msw_core_bootstrap.argtypes = [vp, vp, C.c_int32, sz, sz, sz, vp, dp, sz, C.c_int, C.c_int, vp, vp]
@@ -296,6 +297,14 @@ class Core:
         G, E, _ = self.shape()
         out = np.empty((G, E))
         self._check(self._L.msw_core_gamma(self._h, _ptr(out), E))
+        return out
+
+    def gamma_block(self, ec_begin, ec_end):
+        """G x (ec_end - ec_begin) block of the log-responsibilities (msw_core_gamma_block)."""
+        G, E, _ = self.shape()
+        w = int(ec_end) - int(ec_begin)
+        out = np.empty((G, max(w, 0)))
+        self._check(self._L.msw_core_gamma_block(self._h, int(ec_begin), int(ec_end), _ptr(out), max(w, 1)))
         return out
 
     def set_trace_theta(self, n):

@@ -7,70 +7,66 @@ namespace msw {
 
 // ---------------------------------------------------------------------------------------
 // gamma materialisation (K6): gamma(g, j) = a*L(g, j) + u_g - lse_j, rows = groups, columns in
-// the ORIGINAL EC order.  With (a, u, lse) = (1, 0, none) the same kernels expand the resident
-// likelihood.  Utility kernels, not on the timed path.
+// the ORIGINAL EC order, any block of ECs.  With (a, u, lse) = (1, 0, none) the same kernels expand the
+// resident likelihood.  Utility kernels, not on the timed path.
 // ---------------------------------------------------------------------------------------
+// iperm[original EC index] = permuted position (built once per likelihood, on first use)
+__global__ __launch_bounds__(256) void k_invert_perm(const uint32_t *perm, uint32_t E, uint32_t *iperm) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < E) iperm[perm[p]] = p;
+}
+
+// gamma (or, with (a, u, lse) = (1, 0, none), the likelihood itself) of the ECs [e0, e1) in the ORIGINAL EC
+// order: out[g * ld + (j - e0)], all groups.  A thread per EC: its normaliser lse_j, the background value
+// of every group, then its listed cells.  What msw_core_gamma_block serves --write-probs / the binning input
+// from, block by block (src/Sample.cpp:63-85, src/mSWEEP.cpp:437-469), without a G x E buffer anywhere.
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_lse_sell(SellDev S, double a, double logzi, const double *u,
-                                                 const double *lut, double *lse /*original order*/) {
+__global__ __launch_bounds__(256) void k_gamma_block(SellDev S, const uint32_t *iperm, uint32_t e0, uint32_t e1,
+                                                    double a, double logzi, const double *u, const double *lut,
+                                                    int normalise, double *out, size_t ld) {
   __shared__ double sh[32];
   const int tid = threadIdx.x;
-  double m = -INFINITY;
-  for (uint32_t g = tid; g < S.n_groups; g += blockDim.x) m = fmax(m, u[g]);
-  const double M = block_max(m, sh);
-  double su = 0.0;
-  for (uint32_t g = tid; g < S.n_groups; g += blockDim.x) su += exp(u[g] - M);
-  const double U = block_sum(su, sh);
+  double M = 0.0, U = 0.0;
+  if (normalise) {
+    double m = -INFINITY;
+    for (uint32_t g = tid; g < S.n_groups; g += blockDim.x) m = fmax(m, u[g]);
+    M = block_max(m, sh);
+    double su = 0.0;
+    for (uint32_t g = tid; g < S.n_groups; g += blockDim.x) su += exp(u[g] - M);
+    U = block_sum(su, sh);
+  }
   const double p0 = exp(a * logzi);
-  for (uint32_t p = blockIdx.x * blockDim.x + tid; p < S.n_ecs; p += gridDim.x * blockDim.x) {
-    double zs = 0.0;
-    for_each_cell<WIDE>(S, p, [&](uint32_t g, uint32_t i) { zs += exp(u[g] - M) * (exp(a * lut[i]) - p0); });
-    double Z = p0 * U + zs;
-    if (!(Z >= p0 * U * kGuardRatio)) {
-      // guarded EC (sell.hpp): background and listed cells cancel -- every group visited instead
-      // (a thread per EC scanning its own cells for each group: utility kernel, rare path)
-      Z = 0.0;
-      for (uint32_t g = 0; g < S.n_groups; ++g) {
-        double xg = p0;
-        for_each_cell<WIDE>(S, p, [&](uint32_t gg, uint32_t i) { if (gg == g) xg = exp(a * lut[i]); });
-        Z += exp(u[g] - M) * xg;
+  for (uint32_t j = e0 + blockIdx.x * blockDim.x + tid; j < e1; j += gridDim.x * blockDim.x) {
+    const uint32_t p = iperm[j];
+    double lse = 0.0;
+    if (normalise) {
+      double zs = 0.0;
+      for_each_cell<WIDE>(S, p, [&](uint32_t g, uint32_t i) { zs += exp(u[g] - M) * (exp(a * lut[i]) - p0); });
+      double Z = p0 * U + zs;
+      if (!(Z >= p0 * U * kGuardRatio)) {  // guarded EC (sell.hpp): every group visited instead
+        Z = 0.0;
+        for (uint32_t g = 0; g < S.n_groups; ++g) {
+          double xg = p0;
+          for_each_cell<WIDE>(S, p, [&](uint32_t gg, uint32_t i) { if (gg == g) xg = exp(a * lut[i]); });
+          Z += exp(u[g] - M) * xg;
+        }
       }
+      lse = M + log(Z);
     }
-    lse[S.perm[p]] = M + log(Z);
+    double *col = out + (j - e0);
+    for (uint32_t g = 0; g < S.n_groups; ++g) col[(size_t)g * ld] = a * logzi + u[g] - lse;
+    for_each_cell<WIDE>(S, p, [&](uint32_t g, uint32_t i) { col[(size_t)g * ld] = a * lut[i] + u[g] - lse; });
   }
 }
 
-__global__ __launch_bounds__(256) void k_gamma_fill(double *out, size_t ld, int g_begin, int g_end,
-                                                   uint32_t E, double a, double logzi,
-                                                   const double *u, const double *lse) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= E) return;
-  const double l = lse ? lse[j] : 0.0;
-  for (int g = g_begin; g < g_end; ++g)
-    out[(size_t)(g - g_begin) * ld + j] = a * logzi + u[g] - l;
-}
-
-template <bool WIDE>
-__global__ __launch_bounds__(256) void k_gamma_scatter(SellDev S, double *out, size_t ld, int g_begin,
-                                                      int g_end, double a, const double *u,
-                                                      const double *lut, const double *lse) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= S.n_ecs) return;
-  const uint32_t j = S.perm[p];
-  const double l = lse ? lse[j] : 0.0;
-  for_each_cell<WIDE>(S, p, [&](uint32_t gu, uint32_t i) {
-    const int g = (int)gu;
-    if (g >= g_begin && g < g_end) out[(size_t)(g - g_begin) * ld + j] = a * lut[i] + u[g] - l;
-  });
-}
-
 // dense flavour: gamma from Lt (EC-major) -> rows = groups slab [g_begin, g_end)
+// (ECs [e0, e0 + E) of the matrix, written to columns 0 .. E - 1 of out)
 __global__ __launch_bounds__(256) void k_gamma_dense(const double *Lt, int G, uint32_t E, double a,
                                                     const double *u, int sub_lse, double *out,
-                                                    size_t ld, int g_begin, int g_end) {
+                                                    size_t ld, int g_begin, int g_end, uint32_t e0) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= E) return;
-  const double *row = Lt + (size_t)j * G;
+  const double *row = Lt + ((size_t)e0 + j) * G;
   double lse = 0.0;
   if (sub_lse) {
     double m = -INFINITY;

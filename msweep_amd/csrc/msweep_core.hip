@@ -57,6 +57,7 @@ struct msw_core {
   int n_tab_inline() const { return flavor == 0 && n_area <= (uint32_t)kTabInline ? (int)n_area : 0; }
   double logzi = 0.0;
   DevBuf<uint32_t> rec, slice_off, long_ptr, rec_long, perm;
+  DevBuf<uint32_t> iperm;  // original EC index -> permuted position (gamma blocks; built on first use)
   DevBuf<double> lut, Lt;
   int nblk = 0;      // persistent workgroups of the CSR sweeps
   int nblk_dense = 0;
@@ -769,13 +770,20 @@ int msw_core_layout_hash(msw_handle h, uint64_t *hash_out) {
 }
 
 int msw_core_get_dense_logl(msw_handle h, double *L_out, size_t ld) {
-  return guarded(h, [&] { materialise_impl(h, L_out, ld, /*gamma=*/false); });
+  return guarded(h, [&] { materialise_impl(h, L_out, ld, /*gamma=*/false, 0, h->E); });
 }
 
 int msw_core_gamma(msw_handle h, double *gamma_out, size_t ld) {
   return guarded(h, [&] {
     if (!h->have_solution) throw Fail("msw_core_gamma: no solve has run on this handle");
-    materialise_impl(h, gamma_out, ld, /*gamma=*/true);
+    materialise_impl(h, gamma_out, ld, /*gamma=*/true, 0, h->E);
+  });
+}
+
+int msw_core_gamma_block(msw_handle h, size_t ec_begin, size_t ec_end, double *gamma_out, size_t ld) {
+  return guarded(h, [&] {
+    if (!h->have_solution) throw Fail("msw_core_gamma_block: no solve has run on this handle");
+    materialise_impl(h, gamma_out, ld, /*gamma=*/true, ec_begin, ec_end);
   });
 }
 

@@ -549,3 +549,31 @@ def test_continue_is_the_same_solve(gpu_core):
     np.testing.assert_array_equal(part["theta"], whole["theta"])
     with pytest.raises(MswError, match="fixed-iteration"):
         gpu_core.continue_(3)
+
+
+def test_gamma_block_equals_the_columns_of_gamma(gpu_core, oracle):
+    """msw_core_gamma_block: any block of ECs of the log-responsibility matrix (what --write-probs and the
+    binning input read EC by EC, src/Sample.cpp:63-85), CSR and dense flavours; blocks tile the matrix."""
+    p = synth.make_csr_problem(30000, 90, seed=53, max_other=7)
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    gpu_core.solve(lik.log_counts(), np.ones(90))
+    full = gpu_core.gamma()
+    E = full.shape[1]
+    for e0, e1 in ((0, 1), (17, 4000), (E - 5, E), (0, E), (123, 123)):
+        np.testing.assert_array_equal(gpu_core.gamma_block(e0, e1), full[:, e0:e1])
+    lut = precalc_lls(p["group_sizes"])
+    ref = oracle.rcg_optl_csr(p["rowptr"], p["grp"], lutidx_of(p, lut), lut, np.log(0.01), 90, lik.log_counts(),
+                              np.ones(90), want_gamma=True)
+    np.testing.assert_allclose(np.exp(full), np.exp(ref["gamma"]), atol=1e-9)
+    with pytest.raises(MswError, match="EC range"):
+        gpu_core.gamma_block(5, E + 1)
+    d = synth.make_dense_problem(3000, 40, seed=9)
+    import os
+    os.environ["MSWEEP_DENSE_COMPRESS"] = "0"
+    try:
+        from_dense(gpu_core, d["logl"], d["logc"])
+    finally:
+        del os.environ["MSWEEP_DENSE_COMPRESS"]
+    gpu_core.solve(d["logc"], np.ones(40))
+    full = gpu_core.gamma()
+    np.testing.assert_array_equal(gpu_core.gamma_block(100, 2100), full[:, 100:2100])
