@@ -298,6 +298,8 @@ def main():
     # initial state and the first iteration's rejected step); the K timed steps are the NEXT K iterations of
     # the same solve (msw_core_continue) -- every kernel slot they need, rejected steps included
     core.run(max_iters=max(a.warmup, 1))
+    if dist is not None and not shard:
+        comm.allgather(np.zeros(G))           # RCCL sets its connections up on the first collective: not timed
 
     def sync():
         # barrier + device synchronisation on both sides of the timed region.  core.run() itself

@@ -47,6 +47,7 @@ struct RcclComm final : msw_comm {
     if (rc != ncclSuccess) throw HipError(std::string("ncclCommInitRank: ") + ncclGetErrorString(rc));
   }
   ~RcclComm() override {
+    if (ag_stream) (void)hipStreamDestroy(ag_stream);
     if (comm) (void)ncclCommDestroy(comm);
   }
   int rank() const override { return r; }
@@ -67,23 +68,18 @@ struct RcclComm final : msw_comm {
     if (rc == ncclSuccess) rc = rc2;
     if (rc != ncclSuccess) throw HipError(std::string("ncclAllReduce (grouped): ") + ncclGetErrorString(rc));
   }
+  // staging buffers and stream are kept: a second call costs two small copies and the collective
+  DevBuf<double> ag_send, ag_recv;
+  hipStream_t ag_stream = nullptr;
   void allgather_host(const double *send, size_t cnt, double *recv) override {
-    DevBuf<double> s, d;
-    s.alloc(cnt);
-    d.alloc(cnt * (size_t)n);
-    hipStream_t st;
-    MSW_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    try {
-      MSW_HIP(hipMemcpyAsync(s.p, send, cnt * sizeof(double), hipMemcpyHostToDevice, st));
-      const ncclResult_t rc = ncclAllGather(s.p, d.p, cnt, ncclDouble, comm, st);
-      if (rc != ncclSuccess) throw HipError(std::string("ncclAllGather: ") + ncclGetErrorString(rc));
-      MSW_HIP(hipMemcpyAsync(recv, d.p, cnt * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-      MSW_HIP(hipStreamSynchronize(st));
-    } catch (...) {
-      (void)hipStreamDestroy(st);
-      throw;
-    }
-    (void)hipStreamDestroy(st);
+    if (!ag_stream) MSW_HIP(hipStreamCreateWithFlags(&ag_stream, hipStreamNonBlocking));
+    ag_send.alloc(cnt);
+    ag_recv.alloc(cnt * (size_t)n);
+    MSW_HIP(hipMemcpyAsync(ag_send.p, send, cnt * sizeof(double), hipMemcpyHostToDevice, ag_stream));
+    const ncclResult_t rc = ncclAllGather(ag_send.p, ag_recv.p, cnt, ncclDouble, comm, ag_stream);
+    if (rc != ncclSuccess) throw HipError(std::string("ncclAllGather: ") + ncclGetErrorString(rc));
+    MSW_HIP(hipMemcpyAsync(recv, ag_recv.p, cnt * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ag_stream));
+    MSW_HIP(hipStreamSynchronize(ag_stream));
   }
   int count() const {  // what RCCL itself says the communicator spans
     int c = 0;

@@ -7,8 +7,9 @@ tag=${1:-prof}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python3 bench.py > $out/bench_line.json 2> $out/bench.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $out/stats.log 2>&1 || exit 1
+python3 bench.py --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench.err || exit 1
+# kernel stats of the SAME command the driver runs (the CPU baseline leg, which launches no kernel, left out)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc/fetch --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extras > $out/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc/write --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extras > $out/pmc_write.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum -d $out/pmc/tcc --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extras > $out/pmc_tcc.log 2>&1 || exit 1
