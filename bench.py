@@ -28,6 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+OUT = sys.stdout
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 TRAFFIC_JSON = "r01_traffic_pmc_v7.json"  # HBM bytes per launch of the sweeps (rocprofv3 PMC, committed)
 
@@ -204,6 +205,12 @@ def main():
                  f"(plain `python bench.py --gpus {a.gpus}` starts them itself)")
     if a.launch_selftest:
         return launch_selftest(a, rank, world)
+    # ONE JSON line on stdout: libraries that print banners there (RCCL's version block at its first
+    # initialisation) are sent to stderr; the line itself goes to the saved descriptor
+    global OUT
+    sys.stdout.flush()
+    OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     dist = None
     if world > 1 or a.force_dist:
         import torch
@@ -395,7 +402,7 @@ def main():
             except Exception as ex:
                 line["cpu_baseline_structured"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port",
                                                    "sample": f"failed: {ex}"}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=OUT, flush=True)
     core.set_comm(None) if shard else None
     core.close()
     if dist is not None:
