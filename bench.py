@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 OUT = sys.stdout
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_JSON = "r01_traffic_pmc_v7.json"  # HBM bytes per launch of the sweeps (rocprofv3 PMC, committed)
+TRAFFIC_JSON = "r02_traffic_pmc.json"  # HBM bytes per launch of the sweeps (rocprofv3 PMC, committed)
 
 
 def parse():
