@@ -236,6 +236,25 @@ __global__ __launch_bounds__(256) void k_cell_lutidx(const uint32_t *grp, const 
   }
 }
 
+// msw_core_set_csr: LUT slot of every cell from the caller's (group, count) pairs, idx = lut_off[group] +
+// count, with the range checks of the upload (bad: 1 = group id out of range, 2 = count beyond the table)
+__global__ __launch_bounds__(256) void k_csr_lutidx(const uint32_t *grp, const uint32_t *cnt, uint64_t nnz,
+                                                   uint32_t n_groups, uint32_t lut_ld, const uint32_t *lut_off,
+                                                   uint32_t *idx, int *bad) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t g = grp[k], c = cnt[k];
+    if (g >= n_groups) {
+      atomicOr(bad, 1);
+      idx[k] = 0;
+    } else if (c >= lut_ld) {
+      atomicOr(bad, 2);
+      idx[k] = 0;
+    } else {
+      idx[k] = lut_off[g] + c;
+    }
+  }
+}
+
 // fill_ec_counts (include/Likelihood.hpp:188-195)
 __global__ __launch_bounds__(256) void k_log_counts(const uint64_t *ec_counts, uint32_t E, double *logc) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x)
