@@ -106,7 +106,7 @@ struct Scalars {
   double fx_scale, fx_inv, fx_tscale, fx_tinv, xb, tmax, tmin;
   int32_t didreset, reset_pending, done, iter;
   int32_t max_iters, fixed_iters, trace_theta, flavor;  // flavor: 0 csr, 1 dense
-  int32_t tab_ver, pad_;  // bumped whenever (a) changes the per-slot tables: k_tables (large slot areas) follows
+  int32_t tab_ver, fx_shift;  // fx_shift: device_util.hpp fx_factor, set with p0 / xb  // bumped whenever (a) changes the per-slot tables: k_tables (large slot areas) follows
 };
 
 }  // namespace msw

@@ -85,17 +85,28 @@ __device__ __forceinline__ double block_max(double v, double *sh) {
 }
 
 // Fixed-point column sums (sweep_kernels.hpp): a cell of group g adds rint(2^K * r_j * (x - p0) * f_g),
-//   f_g = e_g                    for e_g >= 2^-9   (units of 2^-K reads)
-//   f_g = mantissa(e_g) * 2^-9   below             (units of 2^-K * e_g / f_g reads: finer by a power of two)
-// i.e. f_g = max(e_g, mantissa(e_g) * 2^-9), and k_redfin scales the group's total by 2^-K * e_g / f_g.
-// N_g <= sum c bounds the first kind, N_g <= e_g * 2^8 * sum c (the guard keeps Z_j above 2^-8 of the
-// background sum) the second: both totals stay below 2 * sum c * 2^K < 2^62.  A group that dies out keeps
+//   f_g = e_g                    for e_g >= 2^-s   (units of 2^-K reads)
+//   f_g = mantissa(e_g) * 2^-s   below             (units of 2^-K * e_g / f_g reads: finer by a power of two)
+// i.e. f_g = max(e_g, mantissa(e_g) * 2^-s), and k_redfin scales the group's total by 2^-K * e_g / f_g.
+// Overflow: N_g <= sum c bounds the first kind.  For the second, N_g / e_g = sum_j r_j (x_gj or p0) with
+// r_j <= 2^8 c_j / (p0 U) (the guard keeps Z_j above 2^-8 of the background sum p0 U) and x <= xb, hence
+// N_g / e_g <= 2^8 (xb / p0) sum c, and with s = 9 + ceil(log2(xb / p0)) (Scalars::fx_shift, per pass)
+// f_g N_g / e_g < 2 sum c: both totals stay below 2 * sum c * 2^K < 2^62.  A group that dies out keeps
 // its relative precision (with priors below one digamma(N_g) has slope 1 / N_g^2 and a fixed grid in
-// reads is felt), the large groups keep the absolute one.  e_g = 0: f_g = 2^-9, e_g / f_g = 0 -- whatever
+// reads is felt), the large groups keep the absolute one.  e_g = 0: f_g = 2^-s, e_g / f_g = 0 -- whatever
 // the cells add is discarded (denormal weights are flushed to 0 where e_g is formed).
-__device__ __forceinline__ double fx_factor(double e) {
-  const double m9 = __hiloint2double((__double2hiint(e) & 0x000FFFFF) | ((1023 - 9) << 20), __double2loint(e));
-  return fmax(e, m9);
+// fx_expbits(s): the exponent field of 2^-s, the form fx_factor takes s in.
+__device__ __forceinline__ int fx_expbits(int s) { return (1023 - s) << 20; }
+__device__ __forceinline__ double fx_factor(double e, int expbits) {
+  const double ms = __hiloint2double((__double2hiint(e) & 0x000FFFFF) | expbits, __double2loint(e));
+  return fmax(e, ms);
+}
+// s for a pass: 9 + ceil(log2(xb / p0)), at least 9
+__device__ __forceinline__ int fx_shift_of(double xb, double p0) {
+  int ex = 0;
+  frexp(xb / p0, &ex);  // xb / p0 < 2^ex
+  ex = ex < 0 ? 0 : ex;
+  return ex > 900 ? 909 : 9 + ex;
 }
 __device__ __forceinline__ double flush_denormal(double e) { return e < 0x1p-1000 ? 0.0 : e; }
 

@@ -46,6 +46,7 @@ __device__ inline void prepB_block(Scalars *sc, double a, int G, int n_lut, cons
     sc->U = U;
     sc->p0 = p0;
     sc->xb = fmax(xtop, p0);
+    sc->fx_shift = fx_shift_of(fmax(xtop, p0), p0);
     sc->tab_ver = sc->tab_ver + 1;
   }
 }
@@ -232,7 +233,9 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
       sc->M = M;
       sc->U = U;
       sc->p0 = p0;
-      sc->xb = fmax(exp(a_new * (a_new >= 0.0 ? s0.tmax : s0.tmin)), p0);
+      const double xb = fmax(exp(a_new * (a_new >= 0.0 ? s0.tmax : s0.tmin)), p0);
+      sc->xb = xb;
+      sc->fx_shift = fx_shift_of(xb, p0);
     }
   }
 }
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
       long long ai = 0;
 #pragma unroll
       for (int i = 0; i < 64; ++i) ai += __double_as_longlong(accs[i][gl]);
-      A = (double)ai * s0.fx_inv * (eg0 / fx_factor(eg0));  // sum_j e_g r_j (x_gj - p0), in reads (exact scaling)
+      A = (double)ai * s0.fx_inv * (eg0 / fx_factor(eg0, fx_expbits(s0.fx_shift)));  // sum_j e_g r_j (x_gj - p0), in reads (exact scaling)
     } else {
 #pragma unroll
       for (int i = 0; i < 64; ++i) A += accs[i][gl];
@@ -648,6 +651,7 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
     z.tmax = fmax(trange[0], logzi);
     z.tmin = fmin(trange[1], logzi);
     z.xb = 1.0;
+    z.fx_shift = 9;
     *sc = z;
     tab_built[0] = -1;  // no tables yet
     tab_built[1] = 0;

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
       atomicAdd(reinterpret_cast<V *>(acc_b + off), v);
   };
   // kFx: a cell adds rint(rs * pk), rs = 2^K * r_j, pk = f_g * (x - p0).  |rs * pk| < 2^51 is what the
-  // magic-number conversion needs; |pk| <= max(e_g |x - p0|, 2^-8 max(x, p0)) <= max(Z + zbase, 2^-8 xb)
+  // magic-number conversion needs; |pk| <= max(e_g |x - p0|, 2^(1-s) max(x, p0)) <= max(Z + zbase, 2^(1-s) xb)
   // (Scalars::xb bounds every table value of the pass), so ONE test per EC covers all its cells.  ECs
   // that fail it -- a large multiplicity over a small Z -- split each addend into two parts of 32 and 51
   // bits (two atomics; sums are modulo 2^64, so the parts need not be added together).
@@ -547,7 +547,8 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   };
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, hbase = p0 * uniform_d(sc->logzi) * U;
-  const double fxs = uniform_d(sc->fx_scale), fxb = 0x1p-8 * uniform_d(sc->xb);
+  const int fxe = (int)uniform((uint32_t)fx_expbits(sc->fx_shift));
+  const double fxs = uniform_d(sc->fx_scale), fxb = ldexp(uniform_d(sc->xb), 1 - (int)uniform((uint32_t)sc->fx_shift));
   const double gthr = zbase * kGuardRatio;  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
   const uint32_t gcnt_off = (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 128u;
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
             hs = fma(ev[k], xt[k].y, hs);
             // the scatter adds r_j * (x - p0) -- times f_g in the fixed-point build
             if constexpr (KP && KEEPN > 0)
-              if (k0 + k < KEEPN) xv[k0 + k] = kFx ? fx_factor(ev[k]) * xt[k].x : xt[k].x;
+              if (k0 + k < KEEPN) xv[k0 + k] = kFx ? fx_factor(ev[k], fxe) * xt[k].x : xt[k].x;
           }
         }
       }
@@ -635,8 +636,8 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         if ((uint32_t)k < n) {
           double x0, x1;
           if constexpr (kFx) {
-            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : fx_factor(E_(b[k])) * XM_(b[k]);
-            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : fx_factor(E_(b[k + 1])) * XM_(b[k + 1]);
+            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : fx_factor(E_(b[k]), fxe) * XM_(b[k]);
+            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : fx_factor(E_(b[k + 1]), fxe) * XM_(b[k + 1]);
             if constexpr (WA) {
               addFXwide(b[k], rj, x0);
               addFXwide(b[k + 1], rj, x1);
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
             if (kb + 64u * q < c1) {
               double xm[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) xm[u] = kFx ? fx_factor(E_(rc[q + u])) * XM_(rc[q + u]) : XM_(rc[q + u]);
+              for (int u = 0; u < 4; ++u) xm[u] = kFx ? fx_factor(E_(rc[q + u]), fxe) * XM_(rc[q + u]) : XM_(rc[q + u]);
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 if constexpr (kFx) {
