@@ -166,13 +166,35 @@ def launch_ranks(a):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # wait for all; a rank that fails takes the others down with it (they would wait in the rendezvous or in a
+    # collective until a timeout): only the processes started here are signalled, by their own handles
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        print(f"bench.py: ranks failed (rank, exit code): {bad}" + (f"; first to fail: rank {failed[0]}" if failed else ""),
+              file=sys.stderr)
         sys.exit(1)
     sys.exit(0)
 
@@ -181,6 +203,8 @@ def launch_selftest(a, rank, world):
     """CPU-only rehearsal of the launcher + rendezvous (tests/test_parallel_cpu.py): gloo, no GPU."""
     import torch
     import torch.distributed as dist
+    if os.environ.get("MSWEEP_SELFTEST_FAIL_RANK") == str(rank):   # (tests) a rank that dies before the rendezvous
+        sys.exit(3)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)])
     out = [torch.empty_like(t) for _ in range(world)]

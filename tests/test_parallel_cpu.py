@@ -136,3 +136,13 @@ def test_bench_gpus_n_launches_n_ranks_itself():
 def test_bench_gpus_mismatch_is_an_error():
     r = _bench(["--gpus", "2", "--launch-selftest"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    """A rank that exits non-zero takes the job down: the parent stops the ranks it started (they would wait
+    in the rendezvous until its timeout) and exits non-zero itself."""
+    import time
+    t0 = time.time()
+    r = _bench(["--gpus", "2", "--launch-selftest"], {"MSWEEP_SELFTEST_FAIL_RANK": "1"})
+    assert r.returncode != 0 and "ranks failed" in r.stderr and "rank 1" in r.stderr
+    assert time.time() - t0 < 120
