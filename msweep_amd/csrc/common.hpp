@@ -104,6 +104,9 @@ struct Scalars {
   // fixed-point column sums (sweep_kernels.hpp kFx): 2^K and 2^-K; 2^t / 2^-t of the guarded ECs' shares
   // (sell.hpp); xb >= every table value x_i = exp(a T_i) and p0 of the current pass; extreme table values
   double fx_scale, fx_inv, fx_tscale, fx_tinv, xb, tmax, tmin;
+  // every exp(a T) of a pass is formed as exp(a (T - tref)), tref = the table value with the largest a T
+  // (incl. log zi): x_i <= 1, p0 <= 1 whatever a does; the ELBO gets a * tref * sum c back (k_fin)
+  double tref;
   int32_t didreset, reset_pending, done, iter;
   int32_t max_iters, fixed_iters, trace_theta, flavor;  // flavor: 0 csr, 1 dense
   int32_t tab_ver, fx_shift;  // fx_shift: device_util.hpp fx_factor, set with p0 / xb  // bumped whenever (a) changes the per-slot tables: k_tables (large slot areas) follows

@@ -88,10 +88,13 @@ __device__ __forceinline__ double block_max(double v, double *sh) {
 //   f_g = e_g                    for e_g >= 2^-s   (units of 2^-K reads)
 //   f_g = mantissa(e_g) * 2^-s   below             (units of 2^-K * e_g / f_g reads: finer by a power of two)
 // i.e. f_g = max(e_g, mantissa(e_g) * 2^-s), and k_redfin scales the group's total by 2^-K * e_g / f_g.
-// Overflow: N_g <= sum c bounds the first kind.  For the second, N_g / e_g = sum_j r_j (x_gj or p0) with
-// r_j <= 2^8 c_j / (p0 U) (the guard keeps Z_j above 2^-8 of the background sum p0 U) and x <= xb, hence
-// N_g / e_g <= 2^8 (xb / p0) sum c, and with s = 9 + ceil(log2(xb / p0)) (Scalars::fx_shift, per pass)
-// f_g N_g / e_g < 2 sum c: both totals stay below 2 * sum c * 2^K < 2^62.  A group that dies out keeps
+// Range: the accumulators hold only the listed cells' part of N_g = e_g p0 W + e_g sum_j r_j (x_gj - p0),
+// which near the guard threshold is up to 2^8 times -sum c and does NOT fit: they are sums MODULO 2^64, and
+// k_redfin adds the background part in the same units and the same modular arithmetic -- what has to fit is
+// N_g itself.  N_g <= sum c for the first kind of group; for the second, N_g / e_g = sum_j r_j (x_gj or p0)
+// with r_j <= 2^8 c_j / (p0 U) (the guard keeps Z_j above 2^-8 of the background sum p0 U) and x <= xb,
+// hence N_g / e_g <= 2^8 (xb / p0) sum c, and with s = 9 + ceil(log2(xb / p0)) (Scalars::fx_shift, per
+// pass) f_g N_g / e_g < 2 sum c: both stay below 2 * sum c * 2^K < 2^62.  A group that dies out keeps
 // its relative precision (with priors below one digamma(N_g) has slope 1 / N_g^2 and a fixed grid in
 // reads is felt), the large groups keep the absolute one.  e_g = 0: f_g = 2^-s, e_g / f_g = 0 -- whatever
 // the cells add is discarded (denormal weights are flushed to 0 where e_g is formed).
@@ -101,6 +104,8 @@ __device__ __forceinline__ double fx_factor(double e, int expbits) {
   const double ms = __hiloint2double((__double2hiint(e) & 0x000FFFFF) | expbits, __double2loint(e));
   return fmax(e, ms);
 }
+// reference value of a pass's tables: exp(a (T - tref)) <= 1 for every table value T and for log zi
+__device__ __forceinline__ double tref_of(double a, double tmax, double tmin) { return a >= 0.0 ? tmax : tmin; }
 // s for a pass: 9 + ceil(log2(xb / p0)), at least 9
 __device__ __forceinline__ int fx_shift_of(double xb, double p0) {
   int ex = 0;

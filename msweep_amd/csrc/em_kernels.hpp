@@ -50,7 +50,7 @@ __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, 
   }
   sa = block_sum(sa, sh);
   su = block_sum(su, sh);
-  const double ll = (flavor == 0) ? s_clogZ + M * csum : s_clogZ + s_rH + su;
+  const double ll = (flavor == 0) ? s_clogZ + (M + sc->tref) * csum : s_clogZ + s_rH + su;  // a = 1: Z carries exp(-tref)
   const double denom = csum + sa;
   for (int g = tid; g < G; g += nt) {
     double t = (Nc[g] + alpha0[g] - 1.0) / denom;

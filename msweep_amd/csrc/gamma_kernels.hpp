@@ -22,8 +22,8 @@ __global__ __launch_bounds__(256) void k_invert_perm(const uint32_t *perm, uint3
 // from, block by block (src/Sample.cpp:63-85, src/mSWEEP.cpp:437-469), without a G x E buffer anywhere.
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_gamma_block(SellDev S, const uint32_t *iperm, uint32_t e0, uint32_t e1,
-                                                    double a, double logzi, const double *u, const double *lut,
-                                                    int normalise, double *out, size_t ld) {
+                                                    double a, double logzi, double tref, const double *u,
+                                                    const double *lut, int normalise, double *out, size_t ld) {
   __shared__ double sh[32];
   const int tid = threadIdx.x;
   double M = 0.0, U = 0.0;
@@ -35,23 +35,24 @@ __global__ __launch_bounds__(256) void k_gamma_block(SellDev S, const uint32_t *
     for (uint32_t g = tid; g < S.n_groups; g += blockDim.x) su += exp(u[g] - M);
     U = block_sum(su, sh);
   }
-  const double p0 = exp(a * logzi);
+  // every exp(a T) relative to tref (the table value with the largest a T, log zi included): <= 1
+  const double p0 = exp(a * (logzi - tref));
   for (uint32_t j = e0 + blockIdx.x * blockDim.x + tid; j < e1; j += gridDim.x * blockDim.x) {
     const uint32_t p = iperm[j];
     double lse = 0.0;
     if (normalise) {
       double zs = 0.0;
-      for_each_cell<WIDE>(S, p, [&](uint32_t g, uint32_t i) { zs += exp(u[g] - M) * (exp(a * lut[i]) - p0); });
+      for_each_cell<WIDE>(S, p, [&](uint32_t g, uint32_t i) { zs += exp(u[g] - M) * (exp(a * (lut[i] - tref)) - p0); });
       double Z = p0 * U + zs;
       if (!(Z >= p0 * U * kGuardRatio)) {  // guarded EC (sell.hpp): every group visited instead
         Z = 0.0;
         for (uint32_t g = 0; g < S.n_groups; ++g) {
           double xg = p0;
-          for_each_cell<WIDE>(S, p, [&](uint32_t gg, uint32_t i) { if (gg == g) xg = exp(a * lut[i]); });
+          for_each_cell<WIDE>(S, p, [&](uint32_t gg, uint32_t i) { if (gg == g) xg = exp(a * (lut[i] - tref)); });
           Z += exp(u[g] - M) * xg;
         }
       }
-      lse = M + log(Z);
+      lse = M + log(Z) + a * tref;
     }
     double *col = out + (j - e0);
     for (uint32_t g = 0; g < S.n_groups; ++g) col[(size_t)g * ld] = a * logzi + u[g] - lse;

@@ -34,10 +34,11 @@ __device__ inline void prepB_block(Scalars *sc, double a, int G, int n_lut, cons
   }
   const double U = block_sum(su, sh);
   const double logzi = sc->logzi, oma = 1.0 - a;
-  const double p0 = exp(a * logzi);
-  const double xtop = exp(a * (a >= 0.0 ? sc->tmax : sc->tmin));
+  const double tref = tref_of(a, sc->tmax, sc->tmin);  // tmax / tmin include log zi
+  const double p0 = exp(a * (logzi - tref));
+  const double xtop = 1.0;  // exp(a (tref - tref)): the largest table value of the pass
   for (int i = tid; i < n_lut; i += nt) {
-    const double T = lut[i], x = exp(a * T);
+    const double T = lut[i], x = exp(a * (T - tref));
     X.A[i] = make_double2(x, oma * (T - logzi));
     X.B[i] = make_double2(x - p0, x * T - p0 * logzi);
   }
@@ -45,6 +46,7 @@ __device__ inline void prepB_block(Scalars *sc, double a, int G, int n_lut, cons
     sc->M = M;
     sc->U = U;
     sc->p0 = p0;
+    sc->tref = tref;
     sc->xb = fmax(xtop, p0);
     sc->fx_shift = fx_shift_of(fmax(xtop, p0), p0);
     sc->tab_ver = sc->tab_ver + 1;
@@ -61,9 +63,10 @@ __global__ __launch_bounds__(256) void k_tables(const Scalars *sc, int n_tab, co
   const int ver = sc->tab_ver;
   if (built[0] != ver) {
     const double a = sc->a, logzi = sc->logzi, oma = 1.0 - a;
-    const double p0 = exp(a * logzi);
+    const double tref = tref_of(a, sc->tmax, sc->tmin);
+    const double p0 = exp(a * (logzi - tref));
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_tab; i += gridDim.x * blockDim.x) {
-      const double T = lut[i], x = exp(a * T);
+      const double T = lut[i], x = exp(a * (T - tref));
       X.A[i] = make_double2(x, oma * (T - logzi));
       X.B[i] = make_double2(x - p0, x * T - p0 * logzi);
     }
@@ -194,12 +197,13 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
     }
   }
   const int flavor = s0.flavor;
-  double p0 = 0.0;
+  double p0 = 0.0, tref = 0.0;
   if (flavor == 0) {  // per-slot tables of both sweeps (prepB_block's arithmetic)
     const double oma = 1.0 - a_new;
-    p0 = exp(a_new * logzi);
+    tref = tref_of(a_new, s0.tmax, s0.tmin);
+    p0 = exp(a_new * (logzi - tref));
     for (int i = tid; i < n_lut; i += nt) {
-      const double T = i == tid ? lt : lut[i], x = exp(a_new * T);
+      const double T = i == tid ? lt : lut[i], x = exp(a_new * (T - tref));
       X.A[i] = make_double2(x, oma * (T - logzi));
       X.B[i] = make_double2(x - p0, x * T - p0 * logzi);
     }
@@ -233,9 +237,9 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
       sc->M = M;
       sc->U = U;
       sc->p0 = p0;
-      const double xb = fmax(exp(a_new * (a_new >= 0.0 ? s0.tmax : s0.tmin)), p0);
-      sc->xb = xb;
-      sc->fx_shift = fx_shift_of(xb, p0);
+      sc->tref = tref;
+      sc->xb = 1.0;
+      sc->fx_shift = fx_shift_of(1.0, p0);
     }
   }
 }
@@ -319,11 +323,10 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
   double lgv = 0.0, muv = 0.0, s0v = 0.0, s1v = 0.0, s2v = 0.0;
   if (tid < kRedfinGroups && g < G) {
     double A = 0.0;
+    long long ai = 0;
     if (fx) {
-      long long ai = 0;
 #pragma unroll
       for (int i = 0; i < 64; ++i) ai += __double_as_longlong(accs[i][gl]);
-      A = (double)ai * s0.fx_inv * (eg0 / fx_factor(eg0, fx_expbits(s0.fx_shift)));  // sum_j e_g r_j (x_gj - p0), in reads (exact scaling)
     } else {
 #pragma unroll
       for (int i = 0; i < 64; ++i) A += accs[i][gl];
@@ -331,8 +334,24 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
     double nc;
     const double ug = ug0;
     const int flavor = s0.flavor;
-    if (flavor == 0) {
-      nc = fx ? fma(eg0, s0.p0 * W, A) : eg0 * (s0.p0 * W + A);
+    if (flavor == 0 && fx) {
+      // N_g = e_g p0 W + e_g sum_j r_j (x_gj - p0).  The second part arrives as an integer in units of
+      // 2^-K e_g / f_g reads -- MODULO 2^64: near the guard threshold it is up to 2^8 times -sum c (the
+      // background share it cancels against) and does not fit 64 bits.  The first part is therefore added in
+      // the same units and the same modular arithmetic: the sum, N_g itself, is below 2^62 units and comes
+      // out right whatever its two parts wrapped to.  (2^K f_g p0 W < 2^83: split at 2^32 like the cells'
+      // two-part adds; its fp64 rounding, 2^-53 of the background share, is what the guard bounds.)
+      const double fg = fx_factor(eg0, fx_expbits(s0.fx_shift));
+      const double t1 = fg * (s0.p0 * W) * s0.fx_scale;
+      const double th1 = floor(t1 * 0x1p-32), tl1 = fma(-th1, 0x1p32, t1);
+      const unsigned long long b =
+          ((unsigned long long)(uint32_t)__double2loint(th1 + 6755399441055744.0) << 32) + (unsigned long long)__double2ll_rn(tl1);
+      const long long tot = (long long)((unsigned long long)ai + b);
+      nc = fmax((double)tot * s0.fx_inv * (eg0 / fg), 0.0);
+      nc += (double)th * s0.fx_tinv + (double)tl * (s0.fx_tinv * 0x1p-36);
+      muv = (s0.M - ug) * nc;
+    } else if (flavor == 0) {
+      nc = eg0 * (s0.p0 * W + A);
       nc += (double)th * s0.fx_tinv + (double)tl * (s0.fx_tinv * 0x1p-36);
       muv = (s0.M - ug) * nc;
     } else {
@@ -411,7 +430,8 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
     return;
   }
   const double coef = (flavor == 0) ? (1.0 - a) : 1.0;
-  const double bound = s0.bound_const + s_clogZ + coef * s_rH + mu + lg;
+  // (the sweeps' Z carries exp(-a tref): sum c log Z gets a * tref * sum c back; 0 for the dense flavour)
+  const double bound = s0.bound_const + s_clogZ + coef * s_rH + mu + lg + (flavor == 0 ? a * s0.tref * csum : 0.0);
   const int didreset = s0.didreset;
   __syncthreads();
   if (!reeval && bound < oldbound) {
@@ -642,8 +662,13 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
     z.flavor = flavor;
     int ex = 0;
     frexp(csum > 1.0 ? csum : 1.0, &ex);  // csum < 2^ex
-    const int k = 61 - ex < 44 ? 61 - ex : 44;   // csum * 2^K < 2^61 (device_util.hpp fx_factor)
-    const int t = 61 - ex < 40 ? 61 - ex : 40;   // csum * 2^t < 2^61 (guarded ECs' shares, in reads)
+    // csum * 2^K < 2^61 (device_util.hpp fx_factor).  No other cap: with few reads most ECs then take the
+    // two-part adds (their addends exceed the 2^51 of the one-fma conversion), which only costs time where
+    // there is none to lose, and a toy problem keeps 18 digits below its single read
+    const int k = 61 - ex < 120 ? 61 - ex : 120;
+    // guarded ECs' shares, in reads: a share is at most its EC's count <= csum < 2^ex, and share * 2^t has
+    // to stay below the 2^51 of the one-fma conversion (the second limb carries the next 36 bits)
+    const int t = 50 - ex;
     z.fx_scale = ldexp(1.0, k);
     z.fx_inv = ldexp(1.0, -k);
     z.fx_tscale = ldexp(1.0, t);
@@ -651,6 +676,7 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
     z.tmax = fmax(trange[0], logzi);
     z.tmin = fmin(trange[1], logzi);
     z.xb = 1.0;
+    z.tref = 0.0;
     z.fx_shift = 9;
     *sc = z;
     tab_built[0] = -1;  // no tables yet

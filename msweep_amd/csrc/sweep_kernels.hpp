@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, b1 = p0 * uniform_d(sc->V1c), b2 = p0 * uniform_d(sc->V2c);
-  const double gthr = zbase * kGuardRatio;  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
+  const double gthr = fmax(zbase * kGuardRatio, 2.2250738585072014e-308);  // (Z = 0 is set aside too: reported, not divided by)  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
   const uint32_t gcnt_off = (uint32_t)pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true) + 128u;
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
   auto defer = [&](uint32_t p) {
@@ -418,12 +418,12 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   if (n_guard) {
     const uint32_t wv = uniform(tid >> 6), nwv = kPassThreads / 64;
     uint32_t *bits = GD.bits + (size_t)(blockIdx.x * 16 + wv) * GD.words;
-    const double a = uniform_d(sc->a), oma = 1.0 - a, logzi = uniform_d(sc->logzi);
+    const double a = uniform_d(sc->a), oma = 1.0 - a, logzi = uniform_d(sc->logzi), tref = uniform_d(sc->tref);
     for (uint32_t i = wv; i < n_guard; i += nwv) {
       const uint32_t p = GD.list[(size_t)blockIdx.x * GD.cap + i];
       double z = 0.0, t1 = 0.0, t2 = 0.0;
       wave_cells<WIDE>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
-        const double T = GD.lut_area[ent], x = exp(a * T), sv = oma * (T - logzi) + ew_g[g].y;
+        const double T = GD.lut_area[ent], x = exp(a * (T - tref)), sv = oma * (T - logzi) + ew_g[g].y;
         const double q = ew_g[g].x * x;
         atomicOr(&bits[g >> 5], 1u << (g & 31));
         z += q;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   const double zbase = p0 * U, hbase = p0 * uniform_d(sc->logzi) * U;
   const int fxe = (int)uniform((uint32_t)fx_expbits(sc->fx_shift));
   const double fxs = uniform_d(sc->fx_scale), fxb = ldexp(uniform_d(sc->xb), 1 - (int)uniform((uint32_t)sc->fx_shift));
-  const double gthr = zbase * kGuardRatio;  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
+  const double gthr = fmax(zbase * kGuardRatio, 2.2250738585072014e-308);  // (Z = 0 is set aside too: reported, not divided by)  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
   const uint32_t gcnt_off = (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 128u;
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
   auto defer = [&](uint32_t p) {
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   if (n_guard) {
     const uint32_t wv = uniform(tid >> 6), nwv = kPassThreadsB / 64;
     uint32_t *bits = GD.bits + (size_t)(blockIdx.x * 16 + wv) * GD.words;
-    const double a = uniform_d(sc->a), logzi = uniform_d(sc->logzi);
+    const double a = uniform_d(sc->a), logzi = uniform_d(sc->logzi), tref = uniform_d(sc->tref);
     // A group's share of a guarded EC, in reads, goes to two global 64-bit fixed-point accumulators
     // of the group (units 2^-t and 2^-(t+36) reads, 2^t = Scalars::fx_tscale): such a share can exceed any
     // bound the group's own exponent allows for (c e_g p0 / Z with Z far below the background sum),
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
       const double c = S.cvec[p];
       double z = 0.0, h = 0.0;
       wave_cells<WIDE>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
-        const double T = GD.lut_area[ent], q = e_g[g] * exp(a * T);
+        const double T = GD.lut_area[ent], q = e_g[g] * exp(a * (T - tref));
         atomicOr(&bits[g >> 5], 1u << (g & 31));
         z += q;
         h = fma(q, T, h);
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
           s_rH += rj * H;
         }
         wave_cells<WIDE>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
-          add_share(g, e_g[g] * rj * exp(a * GD.lut_area[ent]));
+          add_share(g, e_g[g] * rj * exp(a * (GD.lut_area[ent] - tref)));
         });
         for (uint32_t w0 = lane; w0 < GD.words; w0 += 64) {
           const uint32_t listed = atomicAnd(&bits[w0], 0u);  // read and clear

@@ -356,6 +356,15 @@ inline void chunk_range(size_t E, size_t nch, size_t c, size_t *j0, size_t *j1) 
   *j1 = E * (c + 1) / nch;
 }
 
+// Every exp(a T) of a pass is formed relative to tref = the table value with the largest a T (log zi
+// included), so that x <= 1 and p0 <= 1 whatever a does (the dense-state algorithm works in the log domain
+// and has no such issue); sum c log Z gets a * tref * sum c back.  The HIP kernels do the same.
+inline double tref_of(const CsrL &S, double a) {
+  double tmax = S.logzi, tmin = S.logzi;
+  for (size_t i = 0; i < S.n_lut; ++i) { tmax = std::max(tmax, S.lut[i]); tmin = std::min(tmin, S.lut[i]); }
+  return a >= 0.0 ? tmax : tmin;
+}
+
 // B pass on CSR: returns Nc_g (without alpha) and the bound's data terms.
 void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double *Nc,
                 long double *bound_data, double *lse_out /*E or null*/) {
@@ -366,10 +375,11 @@ void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double
   double U = 0.0;
   for (size_t g = 0; g < G; ++g) { e[g] = std::exp(st.u[g] - M); U += e[g]; }
   const double a = st.a;
-  const double p0 = std::exp(a * S.logzi);
+  const double tref = tref_of(S, a);
+  const double p0 = std::exp(a * (S.logzi - tref));
   std::vector<double> xm(S.n_lut), xTm(S.n_lut);
   for (size_t i = 0; i < S.n_lut; ++i) {
-    const double x = std::exp(a * S.lut[i]);
+    const double x = std::exp(a * (S.lut[i] - tref));
     xm[i] = x - p0;
     xTm[i] = x * S.lut[i] - p0 * S.logzi;
   }
@@ -400,21 +410,21 @@ void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double
         if (mark.empty()) mark.assign(G, 0);
         double z = 0.0, h = 0.0, r0 = 0.0;
         for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
-          const double T = S.lut[S.lutidx[k]], q = e[S.grp[k]] * std::exp(a * T);
+          const double T = S.lut[S.lutidx[k]], q = e[S.grp[k]] * std::exp(a * (T - tref));
           mark[S.grp[k]] = j + 1;
           z += q;
           h += q * T;
         }
         for (size_t g = 0; g < G; ++g) if (mark[g] != j + 1) r0 += e[g];
         const double Zg = z + p0 * r0, Hg = h + p0 * S.logzi * r0;
-        if (lse_out) lse_out[j] = M + std::log(Zg);
+        if (lse_out) lse_out[j] = M + std::log(Zg) + a * tref;
         if (c != 0.0) {
           const double rg = c / Zg;
           sum_clogZ += (long double)c * std::log(Zg);
           sum_rH += (long double)rg * Hg;
           // A holds sum_j r_j (x - p0) per group, N_g = e_g (p0 W + A_g): a share s_g enters as s_g / e_g
           for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k)
-            A[S.grp[k]] += rg * std::exp(a * S.lut[S.lutidx[k]]);
+            A[S.grp[k]] += rg * std::exp(a * (S.lut[S.lutidx[k]] - tref));
           for (size_t g = 0; g < G; ++g) if (mark[g] != j + 1) A[g] += rg * p0;
         }
         continue;
@@ -422,7 +432,7 @@ void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double
       const double Z = zbase + zs;
       const double H = hbase + hs;
       const double r = c / Z;
-      if (lse_out) lse_out[j] = M + std::log(Z);
+      if (lse_out) lse_out[j] = M + std::log(Z) + a * tref;
       if (c != 0.0) {
         sum_clogZ += (long double)c * std::log(Z);
         sum_rH += (long double)r * H;
@@ -444,7 +454,9 @@ void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double
     Nc[g] = e[g] * (p0 * W + A);
     mu += (long double)(M - st.u[g]) * Nc[g];
   }
-  *bound_data = sum_clogZ + (long double)(1.0 - a) * sum_rH + mu;
+  long double csum = 0.0L;
+  for (size_t j = 0; j < E; ++j) csum += cvec[j];
+  *bound_data = sum_clogZ + (long double)(1.0 - a) * sum_rH + mu + (long double)(a * tref) * csum;
 }
 
 double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
@@ -452,7 +464,8 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
   double M = -std::numeric_limits<double>::infinity();
   for (size_t g = 0; g < G; ++g) M = std::max(M, st.u[g]);
   const double a = st.a, oma = 1.0 - a;
-  const double p0 = std::exp(a * S.logzi);
+  const double tref = tref_of(S, a);
+  const double p0 = std::exp(a * (S.logzi - tref));
   std::vector<double> e(G);
   double U = 0.0;
   for (size_t g = 0; g < G; ++g) {
@@ -475,7 +488,7 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
   std::vector<double> x(S.n_lut), D(S.n_lut);
   for (size_t i = 0; i < S.n_lut; ++i) {
     const double T = S.lut[i];
-    x[i] = std::exp(a * T);
+    x[i] = std::exp(a * (T - tref));
     D[i] = oma * (T - S.logzi);
   }
   const double zbase = p0 * U, b1 = p0 * V1c, b2 = p0 * V2c;
