@@ -140,8 +140,14 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
   const double a = s0.a, oldnorm = s0.oldnorm, bound = s0.bound, logzi = s0.logzi;
   double os_a = s0.os_a;
   const int didreset = s0.didreset;
-  const double newnorm = block_sum(pn, sh);
-  const double beta = newnorm / oldnorm;
+  // (one group: q_j is the constant 1 and the variance exactly 0 -- the sweep's background form would
+  // leave rounding noise, and a ratio of two noises as beta)
+  const double pnsum = block_sum(pn, sh);
+  const double newnorm = G == 1 ? 0.0 : pnsum;
+  // (an exactly stationary start -- identical groups under a symmetric prior -- makes the ratio x/0: the
+  // reference carries the inf / NaN into its state and returns NaN weights; here such a step has no momentum)
+  const double ratio = newnorm / oldnorm;
+  const double beta = ratio < INFINITY ? ratio : 0.0;
   double step_a = 1.0 - a;
   if (didreset) {
     os_a *= 0.0;

@@ -46,6 +46,12 @@ def rcg_optl_torch(logl, log_times_observed, alpha0, tol, max_iters, log=None, d
     return _solve(logl, log_times_observed, alpha0, tol, max_iters, log, ALGO_RCG, PREC_DOUBLE, device)
 
 
+def rcg_optl_omp(logl, log_times_observed, alpha0, tol, max_iters, log=None, device=0):
+    """--algorithm rcgcpu, the reference's default (src/mSWEEP.cpp:196-199): the same RCG algorithm, served
+    by the GPU kernels (this library has no CPU path)."""
+    return rcg_optl_torch(logl, log_times_observed, alpha0, tol, max_iters, log, device)
+
+
 def em_torch(logl, log_times_observed, alpha0, tol, max_iters, log=None, precision="double", device=0):
     """--algorithm emgpu / anything else (src/mSWEEP.cpp:200-203); --emprecision float|double."""
     if precision not in ("double", "float"):
@@ -62,12 +68,17 @@ def mixture_components_torch(probs, log_times_observed=None):
     raise MswError("mixture_components_torch: expected the EcProbs returned by rcg_optl_torch / em_torch")
 
 
+def mixture_components(probs, log_times_observed=None):
+    """rcgpar::mixture_components (src/mSWEEP.cpp:420,513)."""
+    return mixture_components_torch(probs, log_times_observed)
+
+
 def rcg_optl(algorithm, ll_mat, log_ec_counts, prior_counts, tol=1e-6, max_iters=5000, emprecision="double",
              log=None, device=0):
-    """The dispatch wrapper itself (src/mSWEEP.cpp:176-205).  `rcgcpu` is the reference's OpenMP
-    path and is not provided by this library."""
+    """The dispatch wrapper itself (src/mSWEEP.cpp:176-205): rcggpu, rcgcpu (the default; the same
+    algorithm, run by the GPU kernels), anything else -> EM."""
     if algorithm == "rcggpu":
         return rcg_optl_torch(ll_mat, log_ec_counts, prior_counts, tol, max_iters, log, device)
     if algorithm == "rcgcpu":
-        raise MswError("rcgcpu is the reference's CPU path; this library implements rcggpu and emgpu")
+        return rcg_optl_omp(ll_mat, log_ec_counts, prior_counts, tol, max_iters, log, device)
     return em_torch(ll_mat, log_ec_counts, prior_counts, tol, max_iters, log, emprecision, device)

@@ -651,8 +651,12 @@ size_t structured_loop(size_t G, size_t E, const double *logc, const double *alp
   for (; k < max_iters; ++k) {
     for (size_t g = 0; g < G; ++g) w[g] = (orc_digamma(N[g]) - 1.0) - st.u[g];
     double step_a = 1.0 - st.a;
-    const double newnorm = passA(st, w.data());
-    const double beta_FR = newnorm / oldnorm;
+    // one group: the softmax is the constant 1 and the reference's gradient exactly zero (the background
+    // form of pass A would leave rounding noise)
+    const double newnorm = G == 1 ? (passA(st, w.data()), 0.0) : passA(st, w.data());
+    // x/0 (an exactly stationary start): no momentum, where the reference's dense state turns NaN
+    const double ratio = newnorm / oldnorm;
+    const double beta_FR = ratio < INFINITY ? ratio : 0.0;
     oldnorm = newnorm;
     for (size_t g = 0; g < G; ++g) step_u[g] = w[g];
     if (didreset) {

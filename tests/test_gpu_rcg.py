@@ -221,6 +221,29 @@ def test_edge_cases_csr(gpu_core, oracle):
                      lut[:1], lz, 1)
     r1 = gpu_core.solve(np.log([3.0, 5.0]), np.ones(1))
     assert r1["theta"][0] == pytest.approx(1.0, rel=1e-14)
+    # (b') one group, ECs with and without the hit: the gradient is exactly zero, as the reference's is (a norm
+    # of rounding noise once made beta a ratio of two noises and the state ran away)
+    for E, miss in ((3, {0}), (64, {5}), (200, {7, 8})):
+        rp = np.concatenate([[0], np.cumsum([0 if j in miss else 1 for j in range(E)])]).astype(np.uint64)
+        n = int(rp[-1])
+        gpu_core.set_csr(rp, np.zeros(n, np.uint32), np.ones(n, np.uint32), lut[:1], lz, 1)
+        lc = np.log(np.arange(1.0, E + 1))
+        r1 = gpu_core.solve(lc, np.ones(1))
+        o1 = oracle.rcg_optl_csr(rp, np.zeros(n, np.uint32), np.full(n, 1, np.uint32), lut[:1], lz, 1, lc, np.ones(1))
+        assert r1["theta"][0] == 1.0 and r1["iters"] == o1["iters"] == 2
+        assert r1["bound"] == pytest.approx(o1["bound"], rel=1e-12)
+    # (b'') identical groups, symmetric prior: an exactly stationary start (beta = x / 0; the reference-shaped dense
+    # oracle returns NaN here).  No momentum for such a step: the weights stay at the symmetric point.
+    lut2 = precalc_lls(np.array([2, 2], np.uint64))
+    for rp2, c2 in (([0, 2], [57.0]), ([0, 2, 4, 4], [57.0, 3.0, 11.0])):
+        rp2 = np.array(rp2, np.uint64)
+        n = int(rp2[-1])
+        g2, k2 = np.tile([0, 1], n // 2).astype(np.uint32), np.ones(n, np.uint32)
+        gpu_core.set_csr(rp2, g2, k2, lut2, lz, 2)
+        rs = gpu_core.solve(np.log(c2), np.ones(2))
+        os_ = oracle.rcg_optl_csr(rp2, g2, (g2 * lut2.shape[1] + k2).astype(np.uint32), lut2, lz, 2, np.log(c2), np.ones(2))
+        np.testing.assert_allclose(rs["theta"], [0.5, 0.5], rtol=1e-12)
+        np.testing.assert_allclose(os_["theta"], [0.5, 0.5], rtol=1e-12)
     # (c) a single EC
     gpu_core.set_csr(np.array([0, 2], np.uint64), np.array([1, 3], np.uint32), np.array([1, 1], np.uint32), lut, lz, 4)
     r2 = gpu_core.solve(np.log([10.0]), np.ones(4))
