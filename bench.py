@@ -413,7 +413,7 @@ def main():
             line["time_to_convergence"] = conv
         if em is not None:
             line["em_algorithm"] = em
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and n_gpus == 1:   # rank 0 at N = 1 only: the host cores are shared by the ranks
             log("cpu baseline ...")
             try:
                 line["cpu_baseline"] = cpu_baseline(prob, precalc_lls(prob["group_sizes"]), a.cpu_sample_ecs,
