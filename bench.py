@@ -367,6 +367,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # the practical ceiling beside the specification: the rates this very device reaches with a
+    # read-only 16-byte-load sweep and with the triad -- on a buffer the size of the sweeps' record stream (what
+    # a kernel that does nothing but read that stream once would get, launch ramp and tail included) and on 4 GiB
+    stream_read = stream_triad = stream_read_4g = stream_triad_4g = None
+    if rank == 0:
+        stream_read, stream_triad = core.hbm_stream_rates(max(int(tm["bytes_passB"]), 1 << 20), 5)
+        stream_read_4g, stream_triad_4g = core.hbm_stream_rates(1 << 32, 3)
     if rank == 0:
         cells = float(E) * G * a.steps * (1 if shard else n_gpus)
         msA = tm["passA_ms"] / max(tm["passA_launches"], 1)
@@ -406,7 +413,16 @@ def main():
                         "passB_launches": tm["passB_launches"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": b_dom, "avg_launch_ms": ms_dom},
+                         "algorithmic_bytes_per_launch": b_dom, "avg_launch_ms": ms_dom,
+                         "measured_stream_GBs": {"read_only_same_size": stream_read, "triad_same_size": stream_triad,
+                                                 "read_only_4GiB": stream_read_4g, "triad_4GiB": stream_triad_4g,
+                                                 "what": "msw_core_hbm_stream_rates on this device, best of 5 shapes x "
+                                                         "5 launches; same_size = a buffer of algorithmic_bytes_per_launch"},
+                         "frac_of_measured_read": achieved / stream_read if stream_read else None,
+                         "kernels": {"k_passA": {"achieved": tm["bytes_passA"] / (msA * 1e-3) / 1e9 if msA > 0 else 0.0,
+                                                 "frac": tm["bytes_passA"] / (msA * 1e-3) / 1e9 / HBM_PEAK_GBS if msA > 0 else 0.0},
+                                     "k_passB": {"achieved": tm["bytes_passB"] / (msB * 1e-3) / 1e9 if msB > 0 else 0.0,
+                                                 "frac": tm["bytes_passB"] / (msB * 1e-3) / 1e9 / HBM_PEAK_GBS if msB > 0 else 0.0}}},
             "setup_s": {"generate": t_gen},
         }
         if conv is not None:

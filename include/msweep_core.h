@@ -244,6 +244,11 @@ typedef struct msw_timing {
 } msw_timing;
 int msw_core_set_profiling(msw_handle h, int enabled);
 int msw_core_last_timing(msw_handle h, msw_timing *out);
+/* Measurement only (bench.py's roofline object): the streaming rates this device reaches on n_bytes of HBM --
+ * a read-only 16-byte-load sweep (the shape of the sweeps' record stream) and the triad a = b + 3 c -- best of
+ * `reps` launches after two warm-up launches, in GB/s (1e9).  SURVEY.md 8(d): the practical ceiling beside the
+ * 8 TB/s specification.  No reference counterpart. */
+int msw_core_hbm_stream_rates(msw_handle h, size_t n_bytes, int reps, double *read_gbs, double *triad_gbs);
 /* fixed-iteration mode for benchmarking: run exactly max_iters iterations (tol ignored) */
 int msw_core_set_fixed_iters(msw_handle h, int enabled);
 /* n_iters MORE iterations of the fixed-iteration RCG solve that last ran on the handle (msw_core_run in

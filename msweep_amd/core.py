@@ -25,7 +25,7 @@ EXPORTS = [
     "msw_core_gamma",
     "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
-    "msw_core_set_fixed_iters", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
+    "msw_core_set_fixed_iters", "msw_core_hbm_stream_rates", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
     "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
     "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_core_continue", "msw_core_gamma_block",
 ]
@@ -112,6 +112,7 @@ def load_library():
     L.msw_comm_allgather.argtypes = [vp, vp, sz, vp]
     L.msw_core_set_profiling.argtypes = [vp, C.c_int]
     L.msw_core_set_fixed_iters.argtypes = [vp, C.c_int]
+    L.msw_core_hbm_stream_rates.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.msw_core_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.msw_comm_unique_id.argtypes = [vp]
     L.msw_comm_create_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
@@ -376,6 +377,12 @@ class Core:
 
     def set_fixed_iters(self, on):
         self._check(self._L.msw_core_set_fixed_iters(self._h, int(bool(on))))
+
+    def hbm_stream_rates(self, n_bytes=1 << 30, reps=5):
+        """(read-only GB/s, triad GB/s) of this device on n_bytes of HBM: the practical ceiling (measurement only)."""
+        r, t = C.c_double(), C.c_double()
+        self._check(self._L.msw_core_hbm_stream_rates(self._h, int(n_bytes), int(reps), C.byref(r), C.byref(t)))
+        return r.value, t.value
 
     def last_timing(self):
         t = Timing()

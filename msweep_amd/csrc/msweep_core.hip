@@ -26,6 +26,7 @@
 #include "likelihood_kernels.hpp"
 #include "bootstrap_kernels.hpp"
 #include "em_kernels.hpp"
+#include "stream_kernels.hpp"
 
 using namespace msw;
 
@@ -958,6 +959,51 @@ int msw_core_last_timing(msw_handle h, msw_timing *out) {
   return guarded(h, [&] {
     if (!out) throw Fail("null out");
     *out = h->timing;
+  });
+}
+
+int msw_core_hbm_stream_rates(msw_handle h, size_t n_bytes, int reps, double *read_gbs, double *triad_gbs) {
+  return guarded(h, [&] {
+    if (!read_gbs || !triad_gbs) throw Fail("null out");
+    if (n_bytes < (1u << 20) || reps < 1) throw Fail("msw_core_hbm_stream_rates: at least 1 MiB and one repetition");
+    const size_t n = n_bytes / sizeof(double2);
+    DevBuf<double2> a, b, c;
+    DevBuf<double> sink;
+    a.alloc(n);
+    b.alloc(n);
+    c.alloc(n);
+    sink.alloc(1);
+    MSW_HIP(hipMemsetAsync(a.p, 0, n * sizeof(double2), h->stream));
+    MSW_HIP(hipMemsetAsync(b.p, 0, n * sizeof(double2), h->stream));
+    MSW_HIP(hipMemsetAsync(c.p, 0, n * sizeof(double2), h->stream));
+    hipEvent_t e0, e1;
+    MSW_HIP(hipEventCreate(&e0));
+    MSW_HIP(hipEventCreate(&e1));
+    // the rate depends on the launch shape by +-10 %: the best of a few shapes is the ceiling
+    const int shapes[5][2] = {{256, 512}, {512, 256}, {1024, 512}, {2048, 1024}, {8192, 1024}};
+    double best_r = 0.0, best_t = 0.0;
+    for (int r = 0; r < reps + 2; ++r) {  // the first two rounds warm the clocks and the TLB
+      for (const auto &sh : shapes) {
+        float ms = 0.f;
+        MSW_HIP(hipEventRecord(e0, h->stream));
+        k_stream_read<<<sh[0], sh[1], 0, h->stream>>>(a.p, n, sink.p);
+        MSW_HIP(hipEventRecord(e1, h->stream));
+        MSW_HIP(hipEventSynchronize(e1));
+        MSW_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2) best_r = std::max(best_r, (double)(n * sizeof(double2)) / (ms * 1e-3) / 1e9);
+        MSW_HIP(hipEventRecord(e0, h->stream));
+        k_stream_triad<<<sh[0], sh[1], 0, h->stream>>>(a.p, b.p, c.p, n);
+        MSW_HIP(hipEventRecord(e1, h->stream));
+        MSW_HIP(hipEventSynchronize(e1));
+        MSW_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2) best_t = std::max(best_t, (double)(3 * n * sizeof(double2)) / (ms * 1e-3) / 1e9);
+      }
+    }
+    MSW_HIP(hipGetLastError());
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *read_gbs = best_r;
+    *triad_gbs = best_t;
   });
 }
 
