@@ -50,7 +50,8 @@ const char *msw_core_version(void);
  * log(zi), in at least 3/4 of the cells and at most 65536 distinct values elsewhere) is re-expressed
  * on the device as the CSR-of-ECs form below -- the same numbers, bit for bit
  * (msw_core_get_dense_logl returns the input), any group count, solved by the sparse sweeps.
- * Any other matrix is kept dense (n_groups <= 8192).  msw_core_shape's nnz tells which. */
+ * Any other matrix is kept dense up to n_groups = 8192; beyond, it is re-expressed whatever its shape (every
+ * cell that differs from the most frequent value listed, up to 2^28 of them).  msw_core_shape's nnz tells which. */
 int msw_core_set_dense_logl(msw_handle h, const double *L, size_t n_groups, size_t n_ecs,
                             size_t ld);
 

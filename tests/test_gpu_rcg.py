@@ -494,8 +494,26 @@ def test_dense_path_many_groups(gpu_core, oracle, E, G, seed, dense_mode):
     assert abs(res["iters"] - s["iters"]) <= 3
     assert_theta(res["theta"], s["theta"])
     np.testing.assert_allclose(np.exp(gpu_core.gamma()), np.exp(s["gamma"]), atol=1e-6)
-    with pytest.raises(MswError, match="n_groups <= 8192"):
-        gpu_core.set_dense_logl(np.random.default_rng(0).normal(size=(8193, 2)))   # no background structure
+
+
+def test_unstructured_dense_matrix_beyond_the_dense_sweeps(gpu_core, oracle):
+    """More than 8192 groups and no background structure at all (every cell its own value): the matrix is
+    re-expressed as CSR-of-ECs with every cell listed -- any dense matrix the reference's boundary accepts solves."""
+    rng = np.random.default_rng(0)
+    G, E = 8300, 120
+    L = rng.normal(-3.0, 1.0, size=(G, E))
+    logc = np.log(rng.integers(1, 30, E).astype(float))
+    alpha0 = np.ones(G)
+    gpu_core.set_dense_logl(L)
+    assert gpu_core.shape()[:2] == (G, E) and gpu_core.shape()[2] >= G * E - E
+    gpu_core.set_trace_theta(10)
+    res = gpu_core.solve(logc, alpha0)
+    tr = gpu_core.trace(10, with_theta=True)
+    s = oracle.rcg_optl_dense_structured(L, logc, alpha0, trace=10)
+    lockstep(tr, s["trace"], 10, rel=1e-8)
+    assert abs(res["iters"] - s["iters"]) <= 3
+    assert_theta(res["theta"], s["theta"])
+    np.testing.assert_array_equal(gpu_core.get_dense_logl(), L)
 
 
 def test_mid_length_ecs_streaming_path(gpu_core, oracle):
