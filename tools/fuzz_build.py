@@ -57,6 +57,14 @@ for case in range(n_cases):
         assert core.shape() == (int(mask.sum()), E, int((counts[mask] > 0).sum()))
         r = core.solve(None, np.ones(lik.n_groups), max_iters=30)
         assert np.all(np.isfinite(r["theta"])) and abs(r["theta"].sum() - 1.0) < 1e-9
+        if lik.n_groups * E <= 2_000_000:                 # gamma, whole and in blocks (Sample.cpp:63-85's input)
+            g = core.gamma()
+            np.testing.assert_allclose(np.exp(g).sum(0), 1.0, rtol=1e-10)
+            e0 = int(rng.integers(0, E))
+            e1 = int(rng.integers(e0, E + 1))
+            np.testing.assert_array_equal(core.gamma_block(e0, e1), g[:, e0:e1])
+            # theta is the count-weighted mean of the responsibilities (rcgpar::mixture_components)
+            np.testing.assert_allclose(np.exp(g) @ ecc.astype(np.float64) / ecc.sum(), r["theta"], rtol=1e-9, atol=1e-15)
     except Exception as ex:  # noqa: BLE001
         print("FAILED", tag, "::", str(ex)[:600], flush=True)
         sys.exit(1)
