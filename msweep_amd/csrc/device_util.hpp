@@ -101,8 +101,15 @@ __device__ __forceinline__ double block_max(double v, double *sh) {
 // fx_expbits(s): the exponent field of 2^-s, the form fx_factor takes s in.
 __device__ __forceinline__ int fx_expbits(int s) { return (1023 - s) << 20; }
 __device__ __forceinline__ double fx_factor(double e, int expbits) {
-  const double ms = __hiloint2double((__double2hiint(e) & 0x000FFFFF) | expbits, __double2loint(e));
-  return fmax(e, ms);
+  // max(e, mantissa(e) * 2^-s): the two differ in the exponent field only and e >= 0, so the larger double is
+  // the one with the larger high word -- an integer max (fmax costs two canonicalising v_max_f64 more per cell)
+#ifdef MSW_FXF_FMAX  // A/B build macro (tools/ab_build.py): the floating-point max
+  return fmax(e, __hiloint2double((__double2hiint(e) & 0x000FFFFF) | expbits, __double2loint(e)));
+#else
+  const int hi = __double2hiint(e);
+  const int ms = (hi & 0x000FFFFF) | expbits;
+  return __hiloint2double(hi > ms ? hi : ms, __double2loint(e));
+#endif
 }
 // reference value of a pass's tables: exp(a (T - tref)) <= 1 for every table value T and for log zi
 __device__ __forceinline__ double tref_of(double a, double tmax, double tmin) { return a >= 0.0 ? tmax : tmin; }
