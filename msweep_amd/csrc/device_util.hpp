@@ -107,7 +107,8 @@ __device__ __forceinline__ double fx_factor(double e, int expbits) {
   return fmax(e, __hiloint2double((__double2hiint(e) & 0x000FFFFF) | expbits, __double2loint(e)));
 #else
   const int hi = __double2hiint(e);
-  const int ms = (hi & 0x000FFFFF) | expbits;
+  int ms;  // (hi & 0xFFFFF) | expbits as one bit-field insert (the compiler emits v_and + v_or)
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(ms) : "v"(0x000FFFFF), "v"(hi), "v"(expbits));
   return __hiloint2double(hi > ms ? hi : ms, __double2loint(e));
 #endif
 }
