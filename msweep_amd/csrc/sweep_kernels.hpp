@@ -577,7 +577,14 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   auto process = [&](SliceBuf<WIDE> &sb) {
     const uint32_t o = sb.o, len = sb.len;
     double c = (double)sb.c8;
-    if (sb.c8 == kC8Escape) c = S.cvec[S.n_long + sb.sl * 64 + lane];  // not a small integer: rare
+    // not a small integer: rare.  A wave-uniform branch with the wait for its load INSIDE: loads return in
+    // order, so a load issued here sits behind the next slice's prefetch -- left pending, the compiler's
+    // wait for it at the first use of c (the EC epilogue of EVERY slice, escape or not) is vmcnt(0) and
+    // drains the prefetch half-way through the slice
+    if (__builtin_amdgcn_ballot_w64(sb.c8 == kC8Escape)) {
+      if (sb.c8 == kC8Escape) c = S.cvec[S.n_long + sb.sl * 64 + lane];
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    }
     double zs = 0.0, hs = 0.0;
     // row sums: straight-line code per cell count (wave-uniform, even).  x - p0 of the first KEEPN
     // cells stays in registers for the scatter, any others are gathered a second time (with 16
