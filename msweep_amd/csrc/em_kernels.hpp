@@ -26,45 +26,85 @@ __global__ __launch_bounds__(1024) void k_em_init(Scalars *sc, int G, int n_lut,
 
 // M-step: theta_g = max(0, (Nc_g + alpha_g - 1) / (sum c + sum(alpha - 1))), u = log theta;
 // stop when the weighted log-likelihood gain drops below tol (after the first iteration).
+// One workgroup between two sweeps, organised like k_step: every load issued up front, the scalar state read
+// once, one pair of barriers for the four sums, u from the logarithm to e_g = exp(u - M) in registers; a = 1
+// throughout, so the per-slot tables k_em_init built stay (only M, U and e change).
 __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, int npartS,
                                                 const double *partS, const double *Nc,
                                                 const double *alpha0, double *u, double *theta,
                                                 const double *lut, double *e, TabDev X, TraceDev tr) {
-  __shared__ double sh[32];
-  if (sc->done) return;
+  __shared__ double sh[16 * 4];
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int flavor = sc->flavor;
-  const double csum = sc->csum, oldll = sc->bound, tol = sc->tol, M = sc->M;
-  double p1 = 0.0, p2 = 0.0;
+  double q[4] = {0.0, 0.0, 0.0, 0.0};  // sum c log Z, sum r H, sum (alpha - 1), sum u Nc
   for (int b = tid; b < npartS; b += nt) {
-    p1 += partS[4 * b];
-    p2 += partS[4 * b + 1];
+    q[0] += partS[4 * b];
+    q[1] += partS[4 * b + 1];
   }
-  const double s_clogZ = block_sum(p1, sh);
-  const double s_rH = block_sum(p2, sh);
-  double sa = 0.0, su = 0.0;
-  for (int g = tid; g < G; g += nt) {
-    sa += alpha0[g] - 1.0;
-    const double nc = Nc[g];
-    if (flavor != 0 && nc != 0.0) su += u[g] * nc;
+  const bool inreg = G <= kStepRegs * nt;
+  double ncv[kStepRegs], alv[kStepRegs], uv[kStepRegs];
+  if (inreg) {
+#pragma unroll
+    for (int k = 0; k < kStepRegs; ++k) {
+      const int g = tid + k * nt;
+      if (g < G) {
+        ncv[k] = Nc[g];
+        alv[k] = alpha0[g];
+        uv[k] = u[g];
+      }
+    }
   }
-  sa = block_sum(sa, sh);
-  su = block_sum(su, sh);
-  const double ll = (flavor == 0) ? s_clogZ + (M + sc->tref) * csum : s_clogZ + s_rH + su;  // a = 1: Z carries exp(-tref)
+  const Scalars s0 = *sc;
+  if (s0.done) return;
+  const int flavor = s0.flavor;
+  const double csum = s0.csum, oldll = s0.bound, tol = s0.tol;
+  if (inreg) {
+#pragma unroll
+    for (int k = 0; k < kStepRegs; ++k) {
+      if (tid + k * nt < G) {
+        q[2] += alv[k] - 1.0;
+        if (flavor != 0 && ncv[k] != 0.0) q[3] += uv[k] * ncv[k];
+      }
+    }
+  } else {
+    for (int g = tid; g < G; g += nt) {
+      q[2] += alpha0[g] - 1.0;
+      const double nc = Nc[g];
+      if (flavor != 0 && nc != 0.0) q[3] += u[g] * nc;
+    }
+  }
+  block_sum_n<4>(q, sh);
+  const double s_clogZ = q[0], s_rH = q[1], sa = q[2], su = q[3];
+  const double ll = (flavor == 0) ? s_clogZ + (s0.M + s0.tref) * csum : s_clogZ + s_rH + su;  // a = 1: Z carries exp(-tref)
   const double denom = csum + sa;
-  for (int g = tid; g < G; g += nt) {
-    double t = (Nc[g] + alpha0[g] - 1.0) / denom;
-    t = t > 0.0 ? t : 0.0;
-    theta[g] = t;
-    u[g] = log(t);
-  }
-  const int it = sc->iter;
+  const int it = s0.iter;
   int done = 0;
-  if (!sc->fixed_iters && it > 0 && (ll - oldll < tol)) done = 1;
-  if (it + 1 >= sc->max_iters) done = 1;
-  if (it < sc->trace_theta && tr.theta)
-    for (int g = tid; g < G; g += nt) tr.theta[(size_t)it * G + g] = theta[g];
-  __syncthreads();
+  if (!s0.fixed_iters && it > 0 && (ll - oldll < tol)) done = 1;
+  if (it + 1 >= s0.max_iters) done = 1;
+  const bool trace = it < s0.trace_theta && tr.theta;
+  double m = -INFINITY;
+  if (inreg) {
+#pragma unroll
+    for (int k = 0; k < kStepRegs; ++k) {
+      const int g = tid + k * nt;
+      if (g < G) {
+        double t = (ncv[k] + alv[k] - 1.0) / denom;
+        t = t > 0.0 ? t : 0.0;
+        theta[g] = t;
+        if (trace) tr.theta[(size_t)it * G + g] = t;
+        uv[k] = log(t);
+        u[g] = uv[k];
+        m = fmax(m, uv[k]);
+      }
+    }
+  } else {
+    for (int g = tid; g < G; g += nt) {
+      double t = (Nc[g] + alpha0[g] - 1.0) / denom;
+      t = t > 0.0 ? t : 0.0;
+      theta[g] = t;
+      if (trace) tr.theta[(size_t)it * G + g] = t;
+      u[g] = log(t);
+    }
+  }
   if (tid == 0) {
     sc->oldbound = oldll;
     sc->bound = ll;
@@ -77,7 +117,28 @@ __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, 
     sc->iter = it + 1;
     sc->done = done;
   }
-  if (!done && flavor == 0) prepB_block(sc, 1.0, G, n_lut, u, lut, e, X, sh);
+  if (done || flavor != 0) return;
+  if (!inreg) {  // many groups: the looping form (it rebuilds the tables too, to the same values)
+    __syncthreads();
+    prepB_block(sc, 1.0, G, n_lut, u, lut, e, X, sh);
+    return;
+  }
+  const double M = block_max(m, sh);
+  double se = 0.0;
+#pragma unroll
+  for (int k = 0; k < kStepRegs; ++k) {
+    const int g = tid + k * nt;
+    if (g < G) {
+      const double eg = flush_denormal(exp(uv[k] - M));
+      e[g] = eg;
+      se += eg;
+    }
+  }
+  const double U = block_sum(se, sh);
+  if (tid == 0) {
+    sc->M = M;
+    sc->U = U;
+  }
 }
 
 }  // namespace msw
