@@ -15,9 +15,11 @@ shutil.copy(os.path.join(R, "include", "msweep_core.h"), os.path.join(X, "includ
 p = os.path.join(X, "msweep_amd", "csrc", "sweep_kernels.hpp"); s = open(p).read()
 NOPATCH = "--nopatch" in sys.argv
 if NOPATCH: sys.argv.remove("--nopatch")
-def rep(a, b):
+def rep(a, b, optional=False):
     global s
     if NOPATCH: return
+    if optional and a not in s:
+        print("ab_build: stale hook skipped:", a.strip()[:50]); return
     assert a in s, a[:60]
     s = s.replace(a, b)
 rep('''  auto EW_ = [&](RT r) -> double2 { return tab16<GLDS>(ew_b, R::hi2(r, shift)); };
@@ -87,11 +89,11 @@ rep("""        const double rj = c / Z;
 #endif
         s_rH += rj * H;
         s_W += rj;
-        // padding records""")
+        // padding records""", optional=True)
 rep("""        if (sb.c8 <= 3u) {""","""#if MSW_EXP == 5 || MSW_EXP == 6
         if (true) { s_clogZ += c * Z; } else
 #endif
-        if (sb.c8 <= 3u) {""")
+        if (sb.c8 <= 3u) {""", optional=True)
 rep("""  s_clogZ = block_sum(s_clogZ, sh);""","""  s_clogZ = block_sum(s_clogZ + exp_sink * 1e-300, sh);""")
 open(p, "w").write(s)
 args = sys.argv[1:]

@@ -5,6 +5,7 @@
 #include <random>
 #include <vector>
 #include <algorithm>
+#include <cstdlib>
 static const uint8_t kRGroup[64] = {0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0,1,1,1,1,0,0,0,0,0,0,0,0,1,1,1,1,
                                     2,2,2,2,3,3,3,3,3,3,3,3,2,2,2,2,3,3,3,3,2,2,2,2,2,2,2,2,3,3,3,3};
 // 8-lane blocks = intersections of the contiguous 16-lane groups and the b128 groups
@@ -48,6 +49,15 @@ int main(int argc, char **argv) {
     const int NEC = 64 * 200;
     std::vector<std::vector<uint32_t>> ecs(NEC);
     for (auto &v : ecs) { v.push_back(src(rng)); while ((int)v.size() < len0) { uint32_t g = rng() % G; if (std::find(v.begin(), v.end(), g) == v.end()) v.push_back(g); } }
+    if (getenv("SIM_RENUMBER")) {  // groups renumbered by descending frequency: the hottest 16 sit in 16 different banks
+      static std::vector<uint32_t> rank;
+      if (rank.empty()) {
+        std::vector<uint32_t> ord(G); for (uint32_t g = 0; g < G; ++g) ord[g] = g;
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return th[a] > th[b]; });
+        rank.resize(G); for (uint32_t r = 0; r < G; ++r) rank[ord[r]] = r;
+      }
+      for (auto &v : ecs) for (auto &g : v) g = rank[g];
+    }
     std::vector<int> order(NEC);
     for (int i = 0; i < NEC; ++i) order[i] = i;
     if (mode == 1 || mode == 7) {
