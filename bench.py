@@ -416,7 +416,7 @@ def main():
                          "algorithmic_bytes_per_launch": b_dom, "avg_launch_ms": ms_dom,
                          "measured_stream_GBs": {"read_only_same_size": stream_read, "triad_same_size": stream_triad,
                                                  "read_only_4GiB": stream_read_4g, "triad_4GiB": stream_triad_4g,
-                                                 "what": "msw_core_hbm_stream_rates on this device, best of 5 shapes x "
+                                                 "what": "msw_core_hbm_stream_rates on this device, best of 7 shapes x "
                                                          "5 launches; same_size = a buffer of algorithmic_bytes_per_launch"},
                          "frac_of_measured_read": achieved / stream_read if stream_read else None,
                          "kernels": {"k_passA": {"achieved": tm["bytes_passA"] / (msA * 1e-3) / 1e9 if msA > 0 else 0.0,

@@ -980,7 +980,7 @@ int msw_core_hbm_stream_rates(msw_handle h, size_t n_bytes, int reps, double *re
     MSW_HIP(hipEventCreate(&e0));
     MSW_HIP(hipEventCreate(&e1));
     // the rate depends on the launch shape by +-10 %: the best of a few shapes is the ceiling
-    const int shapes[5][2] = {{256, 512}, {512, 256}, {1024, 512}, {2048, 1024}, {8192, 1024}};
+    const int shapes[7][2] = {{256, 512}, {256, 1024}, {512, 256}, {512, 1024}, {1024, 512}, {2048, 1024}, {8192, 1024}};
     double best_r = 0.0, best_t = 0.0;
     for (int r = 0; r < reps + 2; ++r) {  // the first two rounds warm the clocks and the TLB
       for (const auto &sh : shapes) {

@@ -11,10 +11,15 @@ __global__ __launch_bounds__(1024) void k_stream_read(const double2 *a, size_t n
   double s0 = 0.0, s1 = 0.0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {  // four independent loads in flight per lane
-    const double2 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
-    s0 += v0.x + v1.x + v2.x + v3.x;
-    s1 += v0.y + v1.y + v2.y + v3.y;
+  for (; i + 7 * stride < n; i += 8 * stride) {  // eight independent 16-byte loads in flight per lane
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = a[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s0 += v[u].x;
+      s1 += v[u].y;
+    }
   }
   for (; i < n; i += stride) {
     const double2 v = a[i];
