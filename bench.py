@@ -401,7 +401,10 @@ def main():
                        "algorithm": "rcg", "reads": a.reads, "groups": G, "ecs": E, "nnz": nnz, "seed": a.seed,
                        "sharding": "single solve" if n_gpus == 1 else (
                            f"one solve, ECs sharded over {n_gpus} GPUs, RCCL all-reduce of (G+4) fp64 per iteration"
-                           if shard else f"bootstrap replicates, 1 per GPU x {n_gpus}")},
+                           if shard else f"bootstrap replicates, 1 per GPU x {n_gpus}: every rank solves on its "
+                                         "replicate's RESAMPLED counts (a third of the ECs at zero, one in fifty at four or "
+                                         "more), a different trajectory from the original counts the single-GPU line "
+                                         "solves on")},
             "iters_per_sec": a.steps * (1 if shard else n_gpus) / dt,
             "listed_cells_per_sec": float(nnz) * a.steps * (1 if shard else n_gpus) / dt,
             "value_counts": "logical EC x group cells of the matrix the reference holds (E * G per iteration); "

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     GD.list[(size_t)blockIdx.x * GD.cap + i] = p;
   };
   double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;
-  double lp_mant = 1.0;  // deferred logarithms: product of mantissas in [2^-192, 1] ...
+  double lp_mant = 1.0;  // deferred logarithms: product of mantissas in [2^-960, 1] ...
   int lp_exp = 0;        // ... and sum of exponents, per lane
   auto flush_logs = [&] {
     s_clogZ += log(lp_mant) + (double)lp_exp * 0.693147180559945309417232121458;
@@ -678,17 +678,30 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
           scatter(sb.r, len, rj, std::true_type{}, std::false_type{});
         }
         // sum c log Z after the scatter (its registers are free by now).  For the multiplicities
-        // 1..3 -- nearly all ECs -- the logarithm is deferred: the mantissas are multiplied up per
-        // lane and one log per 64 slices is taken of the product (flush_logs): ~8 operations per
-        // EC instead of ~40, and if anything a smaller rounding error than the sum of logs.
+        // 1..15 the logarithm is deferred: the mantissas are multiplied up per lane and one log per 64
+        // slices is taken of the product (flush_logs): ~8 operations per EC instead of ~40, and if anything
+        // a smaller rounding error than the sum of logs.  1..3 -- nearly all ECs of an alignment -- take two
+        // conditional multiplications; a bootstrap replicate's counts (Poisson-like: one EC in fifty at 4 or
+        // more, so most wavefronts hold one) take m^c by binary powering, still a third of a logarithm, which
+        // the whole wavefront would otherwise pay for its one lane (pass B 99 -> 88 us on resampled counts).
+        // Both give the same bits for 1..3.
         __builtin_amdgcn_sched_barrier(0);
-        if (sb.c8 <= 3u) {
+        if (sb.c8 <= 15u) {
           int ez;
           const double m = frexp(Z, &ez);
-          double r = m;
-          r *= sb.c8 >= 2u ? m : 1.0;
-          r *= sb.c8 >= 3u ? m : 1.0;
-          lp_mant *= r;
+          double r;
+          if (__builtin_amdgcn_ballot_w64(sb.c8 > 3u) == 0) {  // wave-uniform
+            r = m;
+            r *= sb.c8 >= 2u ? m : 1.0;
+            r *= sb.c8 >= 3u ? m : 1.0;
+          } else {
+            const double m2 = m * m, m4 = m2 * m2, m8 = m4 * m4;
+            r = (sb.c8 & 1u) ? m : 1.0;
+            r *= (sb.c8 & 2u) ? m2 : 1.0;
+            r *= (sb.c8 & 4u) ? m4 : 1.0;
+            r *= (sb.c8 & 8u) ? m8 : 1.0;
+          }
+          lp_mant *= r;  // >= 2^-15 per slice: 2^-960 between two flushes
           lp_exp += ez * (int)sb.c8;
         } else {
           s_clogZ += c * log(Z);
