@@ -8,7 +8,7 @@ from msweep_amd import synth
 from msweep_amd.core import Core
 from msweep_amd.likelihood import from_grouped_counts
 
-CASES = [(100_000, 200, 48), (1_000_000, 1000, 32), (10_000_000, 5000, 16)]
+CASES = [(100_000, 200, 48), (1_000_000, 1000, 32), (3_000_000, 5000, 24), (10_000_000, 5000, 16)]
 if len(sys.argv) > 1:
     CASES = [CASES[int(a)] for a in sys.argv[1:]]
 core = Core(0)
