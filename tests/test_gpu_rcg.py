@@ -618,3 +618,12 @@ def test_gamma_block_equals_the_columns_of_gamma(gpu_core, oracle):
     gpu_core.solve(d["logc"], np.ones(40))
     full = gpu_core.gamma()
     np.testing.assert_array_equal(gpu_core.gamma_block(100, 2100), full[:, 100:2100])
+
+
+def test_hbm_stream_rates_are_plausible(gpu_core):
+    """msw_core_hbm_stream_rates (bench.py's measured ceiling): between a tenth of the specification and the
+    specification itself, and refused below 1 MiB."""
+    r, t = gpu_core.hbm_stream_rates(1 << 28, 2)
+    assert 800.0 < r < 8000.0 and 800.0 < t < 8000.0
+    with pytest.raises(MswError, match="at least 1 MiB"):
+        gpu_core.hbm_stream_rates(1000, 1)
