@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the abundance-estimation hot path (BASELINE.json).
 
-Workload (config.workload "cfg3"): synthetic 10M reads x 5k groups collapsed to a CSR-of-ECs
-likelihood (seeded generator msweep_amd/synth.py, seed 2), resident in HBM before the timed
-region.  A "step" = ONE RCG iteration of the hot path over the whole likelihood: pass A
-(natural-gradient norm sweep) + pass B (per-EC softmax, column sums N_g, ELBO sweep) + the O(G)
-digamma / Fletcher-Reeves / bound kernels.  `value` = cells of the EC x group likelihood matrix
-the reference would hold (E * G) processed per second, summed over all ranks.
+Default workload (config.workload "cfg3", the configuration BASELINE.json's metric is quoted on): synthetic
+10M reads x 5k groups collapsed to a CSR-of-ECs likelihood (seeded generator msweep_amd/synth.py, seed 2),
+resident in HBM before the timed region.  A "step" = ONE RCG iteration of the hot path over the whole
+likelihood: pass A (natural-gradient norm sweep) + pass B (per-EC softmax, column sums N_g, ELBO sweep) + the
+O(G) digamma / Fletcher-Reeves / bound kernels.  `value` = cells of the EC x group likelihood matrix the
+reference would hold (E * G) processed per second, summed over all ranks.
 
-N > 1 (one process per GPU): the path shards over bootstrap replicates (src/mSWEEP.cpp:496-518,
-independent solves on the same likelihood): rank r runs K iterations on replicate r's resampled EC
-counts -- no data-path collective; the per-replicate abundances are exchanged with one RCCL
-all-gather at the end (msw_comm_allgather, inside the timed region).  Scaling is "weak" (per-GPU
-work fixed).  Launched either by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
-the environment) or plainly as `python bench.py --gpus N`: the parent then starts the N rank
-processes itself BEFORE anything touches the GPU (it never initialises HIP), relays rank 0's line
-and exits non-zero if any rank fails.
+--config selects the other single-GPU configurations of BASELINE.json, same JSON object:
+  cfg2  synthetic 1M ECs x 500 groups DENSE likelihood through rcg_optl's own dense boundary
+        (msw_core_set_dense_logl; the library re-expresses it as CSR-of-ECs on the device);
+  cfg5  sparse 50M reads x 20k groups through msw_core_build_likelihood with --min-hits 1 (build timed
+        separately), one GPU;
+  cfg4  cfg3 + bootstrap: a "step" is ONE bootstrap replicate (src/mSWEEP.cpp:496-518) through
+        msw_core_bootstrap_dist -- K replicates per rank: stream seek / GF(2) jump-ahead, resampling, solve to
+        --tol 1e-6, and the all-gather of the abundances inside the timed region.
+
+N > 1 (one process per GPU): the path shards over bootstrap replicates (independent solves on the same
+likelihood): with cfg3 rank r runs K iterations on replicate r's resampled EC counts -- no data-path collective;
+the per-replicate abundances are exchanged with one RCCL all-gather at the end (msw_comm_allgather, inside the
+timed region).  Every cfg3 line (any N) also carries `bootstrap_cfg4`: a short run of the REAL replicate loop
+(msw_core_bootstrap_dist, fixed replicates per rank).  Scaling is "weak" (per-GPU work fixed).  Launched either by
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or plainly as
+`python bench.py --gpus N`: the parent then starts the N rank processes itself BEFORE anything touches the GPU
+(it never initialises HIP), relays rank 0's line and exits non-zero if any rank fails.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,22 +39,30 @@ sys.path.insert(0, ROOT)
 
 OUT = sys.stdout
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_JSON = "r02_traffic_pmc.json"  # HBM bytes per launch of the sweeps (rocprofv3 PMC, committed)
+METRIC = "EM iters/sec + reads×groups cells/sec, 10M reads × 5k groups"
+# HBM bytes per launch of the sweeps (rocprofv3 PMC passes, committed): newest file that covers the workload
+TRAFFIC_JSON = {"cfg3": ["r03_traffic_pmc.json", "r02_traffic_pmc.json"], "cfg2": ["r03_cfg2_traffic_pmc.json"],
+                "cfg5": ["r03_cfg5_traffic_pmc.json"], "cfg4": ["r03_traffic_pmc.json", "r02_traffic_pmc.json"]}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--reads", type=int, default=10_000_000)
-    ap.add_argument("--groups", type=int, default=5000)
-    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100; cfg4: 4 replicates per rank)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20; cfg4: 1)")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg3",
+                    help="BASELINE.json configuration (default cfg3, the one the metric is quoted on)")
+    ap.add_argument("--reads", type=int, default=None, help="cfg3/4/5: reads (default 10M; cfg5 50M); cfg2: ECs (1M)")
+    ap.add_argument("--groups", type=int, default=None, help="default 5000 (cfg2: 500, cfg5: 20000)")
+    ap.add_argument("--seed", type=int, default=None, help="generator seed (default: 2; cfg2: 1; cfg5: 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true",
-                    help="skip the EM and time-to-convergence runs after the timed region (profiling runs)")
+    ap.add_argument("--no-extras", "--no-prewarm", dest="no_extras", action="store_true",
+                    help="skip the convergence solves and the EM leg that run BEFORE the timed region (and warm "
+                         "the clocks: `prewarm` in the line) and the bootstrap leg after it")
     ap.add_argument("--cpu-sample-ecs", type=int, default=500_000)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--bootstrap-per-rank", type=int, default=4,
+                    help="cfg3: replicates per rank of the bootstrap_cfg4 leg (0 = skip)")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="(tests) exercise the rank launcher and the rendezvous on CPU/gloo only: no GPU, no workload")
     ap.add_argument("--mode", choices=["replicates", "shard"], default="replicates",
@@ -54,7 +71,18 @@ def parse():
                          "column sums every iteration (strong scaling)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed / RCCL even with one rank (exercises the N > 1 code path)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    dflt = {"cfg2": (1_000_000, 500, 1), "cfg3": (10_000_000, 5000, 2), "cfg4": (10_000_000, 5000, 2),
+            "cfg5": (50_000_000, 20_000, 3)}[a.config]
+    a.default_shape = (a.reads, a.groups, a.seed) == (None, None, None)
+    a.reads = dflt[0] if a.reads is None else a.reads
+    a.groups = dflt[1] if a.groups is None else a.groups
+    a.seed = dflt[2] if a.seed is None else a.seed
+    if a.steps is None:
+        a.steps = 4 if a.config == "cfg4" else 100
+    if a.warmup is None:
+        a.warmup = 1 if a.config == "cfg4" else 20
+    return a
 
 
 def cpu_share():
@@ -84,66 +112,66 @@ def cpu_info():
     return info
 
 
-def cpu_baseline(prob, lut, n_ecs, iters):
-    """Oracle leg (test infrastructure, the ONLY place bench.py touches oracle/): the dense-state
-    RCG exactly as the reference structures it (rcgpar::rcg_optl_omp restated), timed on the host
-    cores over the first `n_ecs` ECs of the same workload expanded to a dense G x E matrix."""
+# ---- CPU baselines (oracle legs: test infrastructure, the ONLY place bench.py touches oracle/) ------------------
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
     from oracle import Oracle
     O = Oracle()
-    G = len(prob["group_sizes"])
-    rp = prob["rowptr"].astype(np.int64)
+    cores = cpu_share()
+    O.set_num_threads(cores)
+    return O, cores
+
+
+def _timed_iters(fn, iters):
+    """per-iteration time = (run of `iters` + 1 iterations) - (run of 1 iteration): the one-off cost of
+    allocating and first-touching the state is not an iteration"""
+    t0 = time.perf_counter()
+    fn(1)
+    t1 = time.perf_counter()
+    fn(iters + 1)
+    t2 = time.perf_counter()
+    return max((t2 - t1) - (t1 - t0), 1e-9), t1 - t0
+
+
+def cpu_dense_state(L, logc, iters, what):
+    """The dense-state RCG exactly as the reference structures it (rcgpar::rcg_optl_omp restated: L, gamma, step,
+    oldstep as G x E fp64), timed on the host cores on the dense matrix L."""
+    import numpy as np
+    O, cores = _oracle()
+    G, E = L.shape
+    dt, t_first = _timed_iters(lambda n: O.rcg_optl_dense(L, logc, np.ones(G), tol=-1.0, max_iters=n), iters)
+    return {"value": E * G * iters / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": f"{what} as a dense fp64 matrix ({E} ECs x {G} groups, {E * G * 8 / 1e9:.1f} GB; the reference's "
+                      f"four G x E matrices), {iters} RCG iterations of the dense-state restatement of "
+                      f"rcgpar::rcg_optl_omp on {cores} OpenMP threads, {dt:.1f} s (+ {t_first:.1f} s for set-up and one "
+                      f"iteration); iters/s on the sample = {iters / dt:.3f}",
+            "cpu": cpu_info()}
+
+
+def cpu_structured_csr(rowptr, grp, lutidx, lut, G, logc, iters, what):
+    """Second CPU line (apples to apples): the oracle's structured CSR restatement -- the same O(nnz) algorithm
+    the GPU runs -- on the FULL workload."""
+    import numpy as np
+    O, cores = _oracle()
+    E = len(rowptr) - 1
+    dt, _ = _timed_iters(lambda n: O.rcg_optl_csr(rowptr, grp, lutidx, lut, np.log(0.01), G, logc, np.ones(G),
+                                                  tol=-1.0, max_iters=n), iters)
+    return {"value": float(E) * G * iters / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+            "listed_cells_per_sec": float(len(grp)) * iters / dt,
+            "sample": f"{what}, {iters} iterations of the structured CSR restatement (oracle/rcg_oracle.cpp "
+                      f"orc_rcg_optl_csr: the O(nnz) algorithm the GPU runs) on {cores} OpenMP threads, {dt:.1f} s; "
+                      f"iters/s = {iters / dt:.3f}"}
+
+
+def dense_sample(rowptr, grp, cnt, lut, G, n_ecs):
+    import numpy as np
+    rp = rowptr.astype(np.int64)
     E = min(n_ecs, len(rp) - 1)
     nz = rp[E]
     L = np.full((G, E), np.log(0.01))
     rows = np.repeat(np.arange(E), np.diff(rp[:E + 1]))
-    L[prob["grp"][:nz], rows] = lut[prob["grp"][:nz], prob["cnt"][:nz]]
-    logc = np.log(prob["ec_counts"][:E].astype(float))
-    cores = cpu_share()
-    O.set_num_threads(cores)
-    # per-iteration time = (run of `iters` + 1 iterations) - (run of 1 iteration): the one-off cost of
-    # allocating and first-touching the three G x E state matrices is not an iteration
-    t0 = time.perf_counter()
-    O.rcg_optl_dense(L, logc, np.ones(G), tol=-1.0, max_iters=1)
-    t1 = time.perf_counter()
-    r = O.rcg_optl_dense(L, logc, np.ones(G), tol=-1.0, max_iters=iters + 1)
-    t2 = time.perf_counter()
-    dt = max((t2 - t1) - (t1 - t0), 1e-9)
-    out = {"value": E * G * iters / dt, "unit": "cells/s", "cores": cores, "kind": "port",
-           "sample": f"first {E} ECs of the cfg3 workload x {G} groups as a dense fp64 matrix "
-                     f"({E * G * 8 / 1e9:.1f} GB; the reference's four G x E matrices), {iters} RCG iterations of "
-                     f"the dense-state restatement of rcgpar::rcg_optl_omp on {cores} OpenMP threads, {dt:.1f} s "
-                     f"(+ {t1 - t0:.1f} s for set-up and one iteration); iters/s on the sample = {iters / dt:.3f}",
-           "cpu": cpu_info()}
-    return out
-
-
-def cpu_baseline_structured(prob, lut, iters):
-    """Second CPU line (apples to apples): the oracle's structured CSR restatement -- the same
-    O(nnz) algorithm the GPU runs -- single-threaded on the FULL workload."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
-    from oracle import Oracle
-    O = Oracle()
-    G = len(prob["group_sizes"])
-    E = len(prob["rowptr"]) - 1
-    lutidx = (prob["grp"].astype(np.uint32) * lut.shape[1] + prob["cnt"]).astype(np.uint32)
-    logc = np.log(prob["ec_counts"].astype(float))
-    cores = cpu_share()
-    O.set_num_threads(cores)
-    t0 = time.perf_counter()
-    O.rcg_optl_csr(prob["rowptr"], prob["grp"], lutidx, lut, np.log(0.01), G, logc, np.ones(G), tol=-1.0, max_iters=1)
-    t1 = time.perf_counter()
-    r = O.rcg_optl_csr(prob["rowptr"], prob["grp"], lutidx, lut, np.log(0.01), G, logc, np.ones(G), tol=-1.0,
-                       max_iters=iters + 1)
-    t2 = time.perf_counter()
-    dt = max((t2 - t1) - (t1 - t0), 1e-9)
-    return {"value": float(E) * G * iters / dt, "unit": "cells/s", "cores": cores, "kind": "port",
-            "listed_cells_per_sec": float(len(prob["grp"])) * iters / dt,
-            "sample": f"full cfg3 workload, {iters} iterations of the structured CSR restatement "
-                      f"(oracle/rcg_oracle.cpp orc_rcg_optl_csr: the O(nnz) algorithm the GPU runs) on {cores} "
-                      f"OpenMP threads, {dt:.1f} s; iters/s = {iters / dt:.3f}"}
+    L[grp[:nz], rows] = lut[grp[:nz], cnt[:nz]]
+    return L
 
 
 def log(msg):
@@ -215,6 +243,129 @@ def launch_selftest(a, rank, world):
     dist.destroy_process_group()
 
 
+# ---- workloads --------------------------------------------------------------------------------------------------
+def load_workload(a, core, shard, rank, world):
+    """Generate the configuration's synthetic input and make its likelihood resident on `core`.
+    Returns dict(E, G, nnz, logc (host vector or None = resident), w (uint32 EC counts or None), desc,
+    setup_s, cpu (callable -> dict of CPU baselines), ...)."""
+    import numpy as np
+    from msweep_amd import synth
+    from msweep_amd.likelihood import from_alignment, from_dense, from_grouped_counts, precalc_lls
+    t0 = time.time()
+    if a.config == "cfg2":
+        E, G = a.reads, a.groups
+        p = synth.make_dense_problem(E, G, seed=a.seed)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        from_dense(core, p["logl"], p["logc"])
+        t_up = time.time() - t0
+        nnz = core.shape()[2]
+        log(f"cfg2: dense {G} x {E} generated in {t_gen:.1f}s, resident in {t_up:.2f}s (listed cells {nnz})")
+
+        def cpu():
+            out = {"cpu_baseline": cpu_dense_state(p["logl"], p["logc"], a.cpu_iters, "the full cfg2 workload")}
+            O, cores = _oracle()
+            dt, _ = _timed_iters(lambda n: O.rcg_optl_dense_structured(p["logl"], p["logc"], np.ones(G), tol=-1.0,
+                                                                       max_iters=n), 5)
+            out["cpu_baseline_structured"] = {
+                "value": float(E) * G * 5 / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+                "sample": f"full cfg2 workload, 5 iterations of the structured restatement on the dense matrix "
+                          f"(oracle/rcg_oracle.cpp: two read-only passes over L per iteration, no G x E state) on "
+                          f"{cores} OpenMP threads, {dt:.1f} s; iters/s = {5 / dt:.3f}"}
+            return out
+        return dict(E=E, G=G, nnz=nnz, logc=p["logc"], w=None, cpu=cpu, reads=E,
+                    setup_s={"generate": t_gen, "set_dense_logl": t_up},
+                    desc=f"cfg2: synthetic {E} ECs x {G} groups dense fp64 likelihood (4.0 GB) through the dense boundary "
+                         "(msw_core_set_dense_logl: re-expressed on the device as CSR-of-ECs, one table slot per listed "
+                         "cell), RCG-VB, fixed iteration count")
+    if a.config == "cfg5":
+        G = a.groups
+        p = synth.make_csr_problem(a.reads, G, seed=a.seed, max_other=7, theta_support=max(G // 10, 1), chunk=2_000_000)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        aln = synth.csr_to_targets(p, shuffle=False)
+        t_aln = time.time() - t0
+        E, nnz = len(p["rowptr"]) - 1, len(p["grp"])
+        t0 = time.time()
+        lik = from_alignment(core, aln["ec_tptr"], aln["ec_targets"], aln["target_group"], p["group_sizes"],
+                             p["ec_counts"], min_hits=1)
+        t_build = time.time() - t0
+        hits = int(len(aln["ec_targets"]))
+        del aln
+        G2 = lik.n_groups
+        log(f"cfg5: E={E} nnz={nnz} generated in {t_gen:.0f}+{t_aln:.0f}s; build (upload of {hits} target hits, "
+            f"K0-K2, --min-hits 1 mask, SELL packing) {t_build:.2f}s; {G2} of {G} groups kept")
+
+        def cpu():
+            kept = np.nonzero(lik.groups_considered())[0]
+            newid = np.cumsum(lik.groups_considered()) - 1
+            grp2 = newid[p["grp"]].astype(np.uint32)
+            lut = precalc_lls(p["group_sizes"][kept])
+            lutidx = (grp2 * lut.shape[1] + p["cnt"]).astype(np.uint32)
+            out = {}
+            n = min(200_000, E)
+            out["cpu_baseline"] = cpu_dense_state(dense_sample(p["rowptr"], grp2, p["cnt"], lut, G2, n),
+                                                  lik.log_counts()[:n], a.cpu_iters,
+                                                  f"first {n} ECs of the cfg5 workload x the {G2} groups --min-hits 1 keeps")
+            out["cpu_baseline_structured"] = cpu_structured_csr(p["rowptr"], grp2, lutidx, lut, G2, lik.log_counts(), 3,
+                                                                "full cfg5 workload (compacted to the kept groups)")
+            return out
+        return dict(E=E, G=G2, nnz=nnz, logc=None, w=None, cpu=cpu, reads=a.reads,
+                    setup_s={"generate": t_gen, "expand_to_targets": t_aln, "build_likelihood": t_build},
+                    build={"seconds": t_build, "target_hits": hits, "groups_in": G, "groups_kept": G2,
+                           "what": "msw_core_build_likelihood: upload of the pseudoalignment (ec_tptr / ec_targets / "
+                                   "group indicators), K1 EC x group counts, K2 --min-hits 1 mask + compaction, K0 lookup "
+                                   "table, log counts, SELL-64 packing -- host wall clock of the one call"},
+                    desc=f"cfg5: synthetic {a.reads} reads x {G} groups, theta supported on {max(G // 10, 1)} groups, <= 8 listed "
+                         f"groups per read, msw_core_build_likelihood with --min-hits 1 ({G2} groups kept), CSR-of-ECs, one "
+                         "GPU, RCG-VB, fixed iteration count")
+    # cfg3 / cfg4
+    G = a.groups
+    prob = synth.make_csr_problem(a.reads, G, seed=a.seed)
+    E, nnz = len(prob["rowptr"]) - 1, len(prob["grp"])
+    t_gen = time.time() - t0
+    log(f"generated {a.config}: E={E} nnz={nnz} in {t_gen:.1f}s")
+    t0 = time.time()
+    if shard:
+        from msweep_amd.parallel import csr_block, shard_ecs
+        b = shard_ecs(prob["rowptr"], world)
+        blk = csr_block(prob, b[rank], b[rank + 1])
+        lik = from_grouped_counts(core, blk["rowptr"], blk["grp"], blk["cnt"], blk["ec_counts"], prob["group_sizes"])
+    else:
+        lik = from_grouped_counts(core, prob["rowptr"], prob["grp"], prob["cnt"], prob["ec_counts"], prob["group_sizes"])
+    t_up = time.time() - t0
+
+    def cpu():
+        lut = precalc_lls(prob["group_sizes"])
+        n = min(a.cpu_sample_ecs, E)
+        lutidx = (prob["grp"].astype(np.uint32) * lut.shape[1] + prob["cnt"]).astype(np.uint32)
+        logc = np.log(prob["ec_counts"].astype(float))
+        return {"cpu_baseline": cpu_dense_state(dense_sample(prob["rowptr"], prob["grp"], prob["cnt"], lut, G, n), logc[:n],
+                                                a.cpu_iters, f"first {n} ECs of the cfg3 workload x {G} groups"),
+                "cpu_baseline_structured": cpu_structured_csr(prob["rowptr"], prob["grp"], lutidx, lut, G, logc, 5,
+                                                              "full cfg3 workload")}
+    return dict(E=E, G=G, nnz=nnz, logc=lik.log_counts(), w=prob["ec_counts"].astype(np.uint32), cpu=cpu, reads=a.reads,
+                setup_s={"generate": t_gen, "set_csr": t_up},
+                desc="cfg3: synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB (--algorithm rcggpu), "
+                     "fixed iteration count" if a.config == "cfg3" else
+                     "cfg4: cfg3's likelihood (synthetic 10M reads x 5k groups, CSR-of-ECs) + bootstrap: a step = one "
+                     "replicate of the one mt19937_64(--seed 42) stream -- seek / jump-ahead, resampling, RCG solve to "
+                     "--tol 1e-6 -- through msw_core_bootstrap_dist, abundances all-gathered")
+
+
+def bootstrap_leg(core, comm, w, per_rank, world, G):
+    """The real replicate loop (msw_core_bootstrap_dist): per_rank * world replicates over the ranks of comm."""
+    import numpy as np
+    draws = int(w.sum())
+    B = per_rank * world
+    t0 = time.perf_counter()
+    theta, iters = core.bootstrap_dist(comm, w, 42, draws, B, np.ones(G))
+    dt = time.perf_counter() - t0
+    bt = core.last_bootstrap_timing()
+    assert theta.shape == (B, G) and np.all(np.abs(theta.sum(1) - 1.0) < 1e-9)
+    return dt, iters, bt
+
+
 def main():
     a = parse()
     if a.gpus < 1:
@@ -229,6 +380,10 @@ def main():
                  f"(plain `python bench.py --gpus {a.gpus}` starts them itself)")
     if a.launch_selftest:
         return launch_selftest(a, rank, world)
+    if a.config in ("cfg2", "cfg5") and (world > 1 or a.mode == "shard"):
+        sys.exit(f"bench.py: --config {a.config} is a single-GPU line; the N > 1 modes run on cfg3 / cfg4")
+    if a.config == "cfg4" and a.mode == "shard":
+        sys.exit("bench.py: --config cfg4 shards whole replicates, not ECs")
     # ONE JSON line on stdout: libraries that print banners there (RCCL's version block at its first
     # initialisation) are sent to stderr; the line itself goes to the saved descriptor
     global OUT
@@ -246,17 +401,7 @@ def main():
     n_gpus = world
 
     import numpy as np
-    from msweep_amd import synth
-    from msweep_amd.core import Core
-    from msweep_amd.likelihood import from_grouped_counts, precalc_lls
-
-    t0 = time.time()
-    prob = synth.make_csr_problem(a.reads, a.groups, seed=a.seed)
-    G = a.groups
-    E = len(prob["rowptr"]) - 1
-    nnz = len(prob["grp"])
-    t_gen = time.time() - t0
-    log(f"generated cfg3: E={E} nnz={nnz} in {t_gen:.1f}s")
+    from msweep_amd.core import Comm, Core
 
     core = Core(local_rank)
     shard = dist is not None and a.mode == "shard"
@@ -265,43 +410,47 @@ def main():
     if dist is not None:
         # the library's own RCCL communicator (C ABI: msw_comm_create_rccl); torch.distributed only
         # carries the unique id and the barriers around the timed region
-        from msweep_amd.core import Comm
         uid = [Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = Comm.rccl(uid[0], rank, world, local_rank)
         rccl_ranks = comm.rccl_count()     # ncclCommCount
         if rccl_ranks != world:
             sys.exit(f"bench.py: RCCL communicator spans {rccl_ranks} ranks, expected {world}")
+    boot_comm = comm if comm is not None else Comm.local(1)[0]   # one rank: the in-process communicator
+    wl = load_workload(a, core, shard, rank, world)
+    E, G, nnz = wl["E"], wl["G"], wl["nnz"]
     if shard:
-        from msweep_amd.parallel import csr_block, shard_ecs
-        b = shard_ecs(prob["rowptr"], world)
-        blk = csr_block(prob, b[rank], b[rank + 1])
-        lik = from_grouped_counts(core, blk["rowptr"], blk["grp"], blk["cnt"], blk["ec_counts"], prob["group_sizes"])
         core.set_comm(comm)
-    else:
-        lik = from_grouped_counts(core, prob["rowptr"], prob["grp"], prob["cnt"], prob["ec_counts"],
-                                  prob["group_sizes"])
     alpha0 = np.ones(G)
-    if shard:
-        logc = lik.log_counts()
-    elif dist is not None:
+    logc = wl["logc"]
+    if dist is not None and not shard and a.config == "cfg3":
         # replicate `rank` of the bootstrap, drawn on the device from the reference's ONE sequential
         # mt19937_64(--seed 42) stream (src/BootstrapSample.cpp:60-73): rank r owns draws
         # [r * n_reads, (r + 1) * n_reads), exactly what a single-GPU run would give replicate r
-        w = prob["ec_counts"].astype(np.uint32)
-        counts = core.resample_counts(w, 42, int(w.sum()), rank, rank + 1)[0].astype(np.float64)
+        counts = core.resample_counts(wl["w"], 42, int(wl["w"].sum()), rank, rank + 1)[0].astype(np.float64)
         with np.errstate(divide="ignore"):
             logc = np.log(counts)
-    else:
-        logc = lik.log_counts()
     log("likelihood resident")
-    # SURVEY 8(d), second figure, measured FIRST: time to convergence at the reference's defaults
-    # (--tol 1e-6, --max-iters 5000), host inputs handed over per call as at the reference's boundary
-    # (PCIe-inclusive); twice, both reported.  Besides being a figure of its own this is ~80 ms of the same
-    # sweeps: a cold MI355X reaches its working clocks only after 60-80 ms of activity (tools/ramp_check.py:
-    # the SAME twenty iterations take 0.214 ms each on a cold chip, 0.181 ms once it has been busy for 40 ms),
-    # and the timed region below is to measure the path, not the governor.
-    conv = None
+
+    def sync():
+        # barrier + device synchronisation on both sides of the timed region.  The library calls themselves
+        # return only after their HIP streams have drained (they download theta), so with one rank there
+        # is nothing left to wait for and torch is not even imported.
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # Pre-warm, BEFORE the timed region and reported in the line (`prewarm`): SURVEY 8(d)'s second figure --
+    # time to convergence at the reference's defaults (--tol 1e-6, --max-iters 5000), host inputs handed over
+    # per call as at the reference's boundary (PCIe-inclusive), twice -- and the EM leg.  Besides being figures
+    # of their own these are ~100 ms of the same sweeps: a cold MI355X reaches its working clocks only after
+    # 60-80 ms of activity (tools/timing.py ramp: the SAME twenty iterations take 0.214 ms each on a cold chip,
+    # 0.181 ms once it has been busy for 40 ms), and the timed region is to measure the path, not the governor.
+    conv = em = None
+    prewarm = {"ms": 0.0, "what": "none (--no-prewarm)"}
+    t_pre = time.perf_counter()
     if not shard and not a.no_extras:
         runs = []
         for _ in range(2 + int(os.environ.get("MSWEEP_BENCH_PRESOLVES", "0"))):  # developer switch: more of them
@@ -311,71 +460,119 @@ def main():
         conv = {"iters": int(rc["iters"]), "ms": min(r[0] for r in runs), "device_ms": min(r[1] for r in runs),
                 "runs_ms": [round(r[0], 3) for r in runs], "tol": 1e-6,
                 "includes": "upload of log counts and prior, download of theta"}
-    core.set_fixed_iters(True)
-    # the EM optimiser (--algorithm emgpu: one pass-B sweep + one O(G) kernel per iteration), W + K steps on the
-    # same resident inputs; reported beside the headline, which is the reference's default RCG
-    em = None
-    if not shard and not a.no_extras:
-        from msweep_amd.core import ALGO_EM
-        core.run(max_iters=max(a.warmup, 1), algo=ALGO_EM)
-        t1 = time.perf_counter()
-        core.run(max_iters=a.steps, algo=ALGO_EM)
-        t_em = time.perf_counter() - t1
-        em = {"ms_per_step": t_em * 1e3 / a.steps, "iters_per_sec": a.steps / t_em}
-    if conv is None:
-        core.prepare(logc, alpha0)           # inputs resident in HBM before the timed region
-    # (after the convergence run they already are: msw_core_solve = msw_core_prepare + msw_core_run)
-    # W untimed warm-up steps: the first W iterations of the solve (with its set-up: the evaluation of the
-    # initial state and the first iteration's rejected step); the K timed steps are the NEXT K iterations of
-    # the same solve (msw_core_continue) -- every kernel slot they need, rejected steps included
-    core.run(max_iters=max(a.warmup, 1))
-    if dist is not None and not shard:
-        comm.allgather(np.zeros(G))           # RCCL sets its connections up on the first collective: not timed
+        if a.config != "cfg4":
+            # the EM optimiser (--algorithm emgpu: one pass-B sweep + one O(G) kernel per iteration), W + K steps
+            # on the same resident inputs; reported beside the headline, which is the reference's default RCG
+            from msweep_amd.core import ALGO_EM
+            core.set_fixed_iters(True)
+            core.run(max_iters=max(a.warmup, 1), algo=ALGO_EM)
+            t1 = time.perf_counter()
+            core.run(max_iters=a.steps, algo=ALGO_EM)
+            t_em = time.perf_counter() - t1
+            em = {"ms_per_step": t_em * 1e3 / a.steps, "iters_per_sec": a.steps / t_em}
+        prewarm = {"ms": (time.perf_counter() - t_pre) * 1e3,
+                   "what": f"{len(runs)} convergence solves at --tol 1e-6 ({conv['iters']} iterations each)"
+                           + (f" + EM leg of {max(a.warmup, 1)} + {a.steps} iterations" if em else "")
+                           + ", host wall clock, before the W warm-up steps; --no-prewarm skips them"}
 
-    def sync():
-        # barrier + device synchronisation on both sides of the timed region.  core.run() itself
-        # returns only after its HIP stream has drained (it downloads theta), so with one rank there
-        # is nothing left to wait for and torch is not even imported.
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    sync()
-    t0 = time.perf_counter()
-    res = core.continue_(a.steps)             # exactly K steps
-    if dist is not None and not shard:
-        gathered = comm.allgather(res["theta"])   # (world, G): the per-replicate abundances, RCCL all-gather
-        assert gathered.shape == (world, G)
-    sync()
-    dt = time.perf_counter() - t0
-    tm0 = core.last_timing()
-    log(f"timed {a.steps} steps in {dt:.3f}s")
-    assert tm0["iters"] == a.steps, (tm0["iters"], a.steps)
-    # K more steps with HIP events around every sweep launch (on the solve stream) for the
-    # per-kernel durations of the roofline object.  Kept out of the timed run: every event record
-    # is a barrier packet that costs ~6 us of idle GPU between two kernels.
-    core.set_profiling(True)
-    core.run(max_iters=max(a.warmup, 1))      # the same iterations as the timed ones: W, then K
-    core.continue_(a.steps)
-    tm = core.last_timing()
-    core.set_profiling(False)
+    line_extra = {}
+    if a.config == "cfg4":
+        # ---- a step = one bootstrap replicate ---------------------------------------------------------------
+        w = wl["w"]
+        bootstrap_leg(core, boot_comm, w, max(a.warmup, 1), world, G)   # W untimed replicates per rank (builds the
+        sync()                                                          # cumulative table, opens RCCL's connections)
+        t0 = time.perf_counter()
+        dt_call, iters, bt = bootstrap_leg(core, boot_comm, w, a.steps, world, G)
+        sync()
+        dt = time.perf_counter() - t0
+        steps_total = a.steps * world
+        tot_iters = int(iters.sum())
+        cells = float(E) * G * tot_iters
+        line_extra = {"replicates": steps_total, "replicates_per_sec": steps_total / dt,
+                      "iterations_per_replicate": [int(x) for x in iters],
+                      "rank0_split_ms": {k: bt[k] for k in ("table_ms", "solve_ms", "gather_ms")},
+                      "iters_per_sec": tot_iters / dt, "listed_cells_per_sec": float(nnz) * tot_iters / dt,
+                      "reads_x_groups_cells_per_sec": float(wl["reads"]) * G * tot_iters / dt}
+        # per-kernel durations for the roofline object: a fixed-iteration solve with events, as for cfg3
+        core.prepare(logc, alpha0)
+        core.set_fixed_iters(True)
+        core.set_profiling(True)
+        core.run(max_iters=20)
+        core.continue_(100)
+        tm = core.last_timing()
+        tm0 = None
+        core.set_profiling(False)
+    else:
+        core.set_fixed_iters(True)
+        if conv is None:
+            core.prepare(logc, alpha0)           # inputs resident in HBM before the timed region
+        # (after the convergence run they already are: msw_core_solve = msw_core_prepare + msw_core_run)
+        # W untimed warm-up steps: the first W iterations of the solve (with its set-up: the evaluation of the
+        # initial state and the first iteration's rejected step); the K timed steps are the NEXT K iterations of
+        # the same solve (msw_core_continue) -- every kernel slot they need, rejected steps included
+        core.run(max_iters=max(a.warmup, 1))
+        if dist is not None and not shard:
+            comm.allgather(np.zeros(G))           # RCCL sets its connections up on the first collective: not timed
+        sync()
+        t0 = time.perf_counter()
+        res = core.continue_(a.steps)             # exactly K steps
+        if dist is not None and not shard:
+            gathered = comm.allgather(res["theta"])   # (world, G): the per-replicate abundances, RCCL all-gather
+            assert gathered.shape == (world, G)
+        sync()
+        dt = time.perf_counter() - t0
+        tm0 = core.last_timing()
+        log(f"timed {a.steps} steps in {dt:.3f}s")
+        assert tm0["iters"] == a.steps, (tm0["iters"], a.steps)
+        # K more steps with HIP events around every sweep launch (on the solve stream) for the
+        # per-kernel durations of the roofline object.  Kept out of the timed run: every event record
+        # is a barrier packet that costs ~6 us of idle GPU between two kernels.
+        core.set_profiling(True)
+        core.run(max_iters=max(a.warmup, 1))      # the same iterations as the timed ones: W, then K
+        core.continue_(a.steps)
+        tm = core.last_timing()
+        core.set_profiling(False)
+        mult = 1 if shard else n_gpus
+        cells = float(E) * G * a.steps * mult
+        line_extra = {"iters_per_sec": a.steps * mult / dt, "listed_cells_per_sec": float(nnz) * a.steps * mult / dt,
+                      "reads_x_groups_cells_per_sec": float(wl["reads"]) * G * a.steps * mult / dt,
+                      "device_ms_per_step": tm0["solve_ms"] / a.steps}
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64).cuda()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # the real replicate loop beside every cfg3 line: msw_core_bootstrap_dist, fixed replicates per rank
+    boot = None
+    if a.config == "cfg3" and not shard and not a.no_extras and a.bootstrap_per_rank > 0:
+        core.set_fixed_iters(False)
+        w = wl["w"]
+        bootstrap_leg(core, boot_comm, w, 1, world, G)      # not timed: cumulative table, connections, clones
+        sync()
+        t1 = time.perf_counter()
+        _, iters, bt = bootstrap_leg(core, boot_comm, w, a.bootstrap_per_rank, world, G)
+        sync()
+        tb = time.perf_counter() - t1
+        if dist is not None:
+            import torch
+            tt = torch.tensor([tb], dtype=torch.float64).cuda()
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tb = float(tt.item())
+        B = a.bootstrap_per_rank * world
+        boot = {"replicates": B, "per_rank": a.bootstrap_per_rank, "seconds": tb, "replicates_per_sec": B / tb,
+                "iterations": [int(x) for x in iters], "cells_per_sec": float(E) * G * float(iters.sum()) / tb,
+                "rank0_split_ms": {k: bt[k] for k in ("table_ms", "solve_ms", "gather_ms")},
+                "what": "msw_core_bootstrap_dist(--seed 42): every rank seeks (GF(2) jump-ahead) to its block of the one "
+                        "mt19937_64 stream, resamples and solves its replicates to --tol 1e-6, ONE all-gather of the "
+                        "B x (G + 1) table; max over ranks of the host wall clock, barrier on both sides"}
+
     # the practical ceiling beside the specification: the rates this very device reaches with a
     # read-only 16-byte-load sweep and with the triad -- on a buffer the size of the sweeps' record stream (what
     # a kernel that does nothing but read that stream once would get, launch ramp and tail included) and on 4 GiB
-    stream_read = stream_triad = stream_read_4g = stream_triad_4g = None
     if rank == 0:
         stream_read, stream_triad = core.hbm_stream_rates(max(int(tm["bytes_passB"]), 1 << 20), 5)
         stream_read_4g, stream_triad_4g = core.hbm_stream_rates(1 << 32, 3)
-    if rank == 0:
-        cells = float(E) * G * a.steps * (1 if shard else n_gpus)
         msA = tm["passA_ms"] / max(tm["passA_launches"], 1)
         msB = tm["passB_ms"] / max(tm["passB_launches"], 1)
         dom, ms_dom, b_dom = ("k_passB", msB, tm["bytes_passB"]) if msB >= msA else ("k_passA", msA, tm["bytes_passA"])
@@ -383,35 +580,34 @@ def main():
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
         # collected offline on this exact workload and committed under profiles/
         traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))
-            if (a.reads, G, a.seed) == (10_000_000, 5000, 2):  # the profiled workload
-                traffic = next(v["hbm_bytes_per_launch"] for k, v in tj.items() if dom in k)
-                traffic_src = f"profiles/{TRAFFIC_JSON} (offline rocprofv3 --pmc passes on this workload, not this run)"
-        except Exception:
-            traffic = None
+        if a.default_shape:
+            for name in TRAFFIC_JSON[a.config]:
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    traffic = next(v["hbm_bytes_per_launch"] for k, v in tj.items() if dom in k)
+                    traffic_src = f"profiles/{name} (offline rocprofv3 --pmc passes on this workload, not this run)"
+                    break
+                except Exception:
+                    continue
+        gb = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        sharding = "single solve" if n_gpus == 1 else (
+            f"one solve, ECs sharded over {n_gpus} GPUs, RCCL all-reduce of (G+4) fp64 per iteration" if shard else
+            f"bootstrap replicates, 1 per GPU x {n_gpus}: every rank solves on its replicate's RESAMPLED counts (a third of "
+            "the ECs at zero, one in fifty at four or more), a different trajectory from the original counts the "
+            "single-GPU line solves on")
+        if a.config == "cfg4":
+            sharding = f"{a.steps} bootstrap replicates per GPU x {n_gpus}, contiguous blocks of the one random stream"
         line = {
-            "metric": "EM iters/sec + reads×groups cells/sec, 10M reads × 5k groups",
-            "value": cells / dt, "unit": "cells/s",
+            "metric": METRIC, "value": cells / dt, "unit": "cells/s",
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cfg3: synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB "
-                                   "(--algorithm rcggpu), fixed iteration count",
-                       "algorithm": "rcg", "reads": a.reads, "groups": G, "ecs": E, "nnz": nnz, "seed": a.seed,
-                       "sharding": "single solve" if n_gpus == 1 else (
-                           f"one solve, ECs sharded over {n_gpus} GPUs, RCCL all-reduce of (G+4) fp64 per iteration"
-                           if shard else f"bootstrap replicates, 1 per GPU x {n_gpus}: every rank solves on its "
-                                         "replicate's RESAMPLED counts (a third of the ECs at zero, one in fifty at four or "
-                                         "more), a different trajectory from the original counts the single-GPU line "
-                                         "solves on")},
-            "iters_per_sec": a.steps * (1 if shard else n_gpus) / dt,
-            "listed_cells_per_sec": float(nnz) * a.steps * (1 if shard else n_gpus) / dt,
+            "config": {"workload": wl["desc"], "algorithm": "rcg", "reads": wl["reads"], "groups": G, "ecs": E, "nnz": nnz,
+                       "seed": a.seed, "sharding": sharding},
             "value_counts": "logical EC x group cells of the matrix the reference holds (E * G per iteration); "
                             "listed_cells_per_sec counts the cells the CSR-of-ECs form stores (nnz per iteration)",
             "rccl_ranks": rccl_ranks,
-            "reads_x_groups_cells_per_sec": float(a.reads) * G * a.steps * (1 if shard else n_gpus) / dt,
-            "device_ms_per_step": tm0["solve_ms"] / a.steps,
+            "prewarm": prewarm,
             "kernels": {"k_passA_ms": msA, "k_passB_ms": msB, "passA_launches": tm["passA_launches"],
                         "passB_launches": tm["passB_launches"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -422,32 +618,31 @@ def main():
                                                  "what": "msw_core_hbm_stream_rates on this device, best of 7 shapes x "
                                                          "5 launches; same_size = a buffer of algorithmic_bytes_per_launch"},
                          "frac_of_measured_read": achieved / stream_read if stream_read else None,
-                         "kernels": {"k_passA": {"achieved": tm["bytes_passA"] / (msA * 1e-3) / 1e9 if msA > 0 else 0.0,
-                                                 "frac": tm["bytes_passA"] / (msA * 1e-3) / 1e9 / HBM_PEAK_GBS if msA > 0 else 0.0},
-                                     "k_passB": {"achieved": tm["bytes_passB"] / (msB * 1e-3) / 1e9 if msB > 0 else 0.0,
-                                                 "frac": tm["bytes_passB"] / (msB * 1e-3) / 1e9 / HBM_PEAK_GBS if msB > 0 else 0.0}}},
-            "setup_s": {"generate": t_gen},
+                         "kernels": {"k_passA": {"achieved": gb(tm["bytes_passA"], msA), "frac": gb(tm["bytes_passA"], msA) / HBM_PEAK_GBS},
+                                     "k_passB": {"achieved": gb(tm["bytes_passB"], msB), "frac": gb(tm["bytes_passB"], msB) / HBM_PEAK_GBS}}},
+            "setup_s": wl["setup_s"],
         }
+        line.update(line_extra)
+        if "build" in wl:
+            line["likelihood_build"] = wl["build"]
         if conv is not None:
             line["time_to_convergence"] = conv
         if em is not None:
             line["em_algorithm"] = em
+        if boot is not None:
+            line["bootstrap_cfg4"] = boot
         if not a.no_cpu_baseline and n_gpus == 1:   # rank 0 at N = 1 only: the host cores are shared by the ranks
             log("cpu baseline ...")
             try:
-                line["cpu_baseline"] = cpu_baseline(prob, precalc_lls(prob["group_sizes"]), a.cpu_sample_ecs,
-                                                    a.cpu_iters)
+                line.update(wl["cpu"]())
             except Exception as ex:  # the baseline is reporting only
-                line["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port",
-                                        "sample": f"failed: {ex}"}
-            try:
-                line["cpu_baseline_structured"] = cpu_baseline_structured(prob, precalc_lls(prob["group_sizes"]), 5)
-            except Exception as ex:
-                line["cpu_baseline_structured"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port",
-                                                   "sample": f"failed: {ex}"}
+                line.setdefault("cpu_baseline", {"value": None, "unit": "cells/s", "cores": 0, "kind": "port",
+                                                 "sample": f"failed: {ex}"})
         print(json.dumps(line), file=OUT, flush=True)
     core.set_comm(None) if shard else None
     core.close()
+    if comm is None:
+        boot_comm.close()
     if dist is not None:
         dist.barrier()
         comm.close()

@@ -149,7 +149,10 @@ int msw_core_set_trace_theta(msw_handle h, size_t n_iters);
  *   (a rank of an N-GPU job passes its own slice; the stream position of replicate b is
  *   b * bootstrap_count draws).
  * theta_out is (rep_end - rep_begin) x G, row b = abundances of replicate rep_begin+b,
- * normalised by the resampled total as src/mSWEEP.cpp:513 does.  iters_out optional. */
+ * normalised by the resampled total as src/mSWEEP.cpp:513 does.  iters_out optional.
+ * A replicate whose solve fails numerically (likelihood underflow, non-finite bound: the cases in which
+ * the reference writes NaN abundances) yields a row of NaN and the call still returns 0 -- the other
+ * replicates are unaffected; device errors and bad arguments fail the whole call. */
 int msw_core_bootstrap(msw_handle h, const uint32_t *ec_counts, int32_t seed,
                        size_t bootstrap_count, size_t rep_begin, size_t rep_end,
                        const double *alpha0, double tol, size_t max_iters, int algo,
@@ -160,8 +163,10 @@ int msw_core_bootstrap(msw_handle h, const uint32_t *ec_counts, int32_t seed,
  * block [n_replicates * r / P, n_replicates * (r + 1) / P) of the one sequential stream and ONE all-gather
  * (RCCL over xGMI) leaves the complete n_replicates x G block in replicate order -- the rows
  * 1..n_replicates of bootstrap_results (include/Sample.hpp:157,180) -- on EVERY rank; results do not
- * depend on the number of ranks.  Every rank holds the same resident likelihood and passes the same
- * arguments.  iters_out[n_replicates] optional. */
+ * depend on the number of ranks (more ranks than replicates: the surplus ranks solve nothing and still take
+ * part in the exchange).  Every rank holds the same resident likelihood and passes the same
+ * arguments.  iters_out[n_replicates] optional.  A rank whose block fails still joins the all-gather and
+ * reports through a status word: the call then returns non-zero on EVERY rank and no rank is left waiting. */
 struct msw_comm;
 int msw_core_bootstrap_dist(msw_handle h, struct msw_comm *comm, const uint32_t *ec_counts, int32_t seed,
                             size_t bootstrap_count, size_t n_replicates, const double *alpha0, double tol,
@@ -245,6 +250,16 @@ typedef struct msw_timing {
 } msw_timing;
 int msw_core_set_profiling(msw_handle h, int enabled);
 int msw_core_last_timing(msw_handle h, msw_timing *out);
+/* Host wall-clock split of the last msw_core_bootstrap / msw_core_bootstrap_dist on the handle (bench.py's
+ * cfg4 leg): where a rank's time went.  No reference counterpart. */
+typedef struct msw_bootstrap_timing {
+  double table_ms;      /* init_bootstrap (src/BootstrapSample.cpp:33-44): cumulative table on the host + upload */
+  double solve_ms;      /* this rank's block of replicates: seek / jump-ahead, resampling (under the solves), solves */
+  double gather_ms;     /* msw_core_bootstrap_dist: the all-gather, waiting for the slowest rank included */
+  uint64_t replicates;  /* solved on this rank */
+  uint64_t iterations;  /* summed over them */
+} msw_bootstrap_timing;
+int msw_core_last_bootstrap_timing(msw_handle h, msw_bootstrap_timing *out);
 /* Measurement only (bench.py's roofline object): the streaming rates this device reaches on n_bytes of HBM --
  * a read-only 16-byte-load sweep (the shape of the sweeps' record stream) and the triad a = b + 3 c -- best of
  * `reps` launches after two warm-up launches, in GB/s (1e9).  SURVEY.md 8(d): the practical ceiling beside the

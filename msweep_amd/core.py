@@ -28,6 +28,7 @@ EXPORTS = [
     "msw_core_set_fixed_iters", "msw_core_hbm_stream_rates", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
     "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
     "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_core_continue", "msw_core_gamma_block",
+    "msw_core_last_bootstrap_timing",
 ]
 
 
@@ -39,6 +40,11 @@ class Timing(C.Structure):
     _fields_ = [("solve_ms", C.c_double), ("passA_ms", C.c_double), ("passB_ms", C.c_double),
                 ("passA_launches", C.c_uint64), ("passB_launches", C.c_uint64), ("iters", C.c_uint64),
                 ("bytes_passA", C.c_uint64), ("bytes_passB", C.c_uint64)]
+
+
+class BootstrapTiming(C.Structure):
+    _fields_ = [("table_ms", C.c_double), ("solve_ms", C.c_double), ("gather_ms", C.c_double),
+                ("replicates", C.c_uint64), ("iterations", C.c_uint64)]
 
 
 _lib = None
@@ -114,6 +120,7 @@ def load_library():
     L.msw_core_set_fixed_iters.argtypes = [vp, C.c_int]
     L.msw_core_hbm_stream_rates.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.msw_core_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.msw_core_last_bootstrap_timing.argtypes = [vp, C.POINTER(BootstrapTiming)]
     L.msw_comm_unique_id.argtypes = [vp]
     L.msw_comm_create_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.msw_comm_create_local.argtypes = [C.c_int, C.POINTER(vp)]
@@ -271,11 +278,13 @@ class Core:
         return dict(theta=theta, iters=it.value, bound=b.value)
 
     def prepare(self, logc, alpha0):
+        """logc=None: the log counts build_likelihood() left on the device."""
         G, E, _ = self.shape()
-        logc = _arr(logc, np.float64)
+        logc = None if logc is None else _arr(logc, np.float64)
         alpha0 = _arr(alpha0, np.float64)
-        if len(logc) != E or len(alpha0) != G:
-            raise MswError(f"prepare: expected logc[{E}] and alpha0[{G}], got {len(logc)} and {len(alpha0)}")
+        if (logc is not None and len(logc) != E) or len(alpha0) != G:
+            raise MswError(f"prepare: expected logc[{E}] and alpha0[{G}], got "
+                           f"{None if logc is None else len(logc)} and {len(alpha0)}")
         self._check(self._L.msw_core_prepare(self._h, _ptr(logc), _ptr(alpha0)))
 
     def run(self, tol=1e-6, max_iters=5000, algo=ALGO_RCG, prec=PREC_DOUBLE):
@@ -388,6 +397,11 @@ class Core:
         t = Timing()
         self._check(self._L.msw_core_last_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def last_bootstrap_timing(self):
+        t = BootstrapTiming()
+        self._check(self._L.msw_core_last_bootstrap_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in BootstrapTiming._fields_}
 
 
 class Comm:

@@ -52,15 +52,27 @@ struct RcclComm final : msw_comm {
   }
   int rank() const override { return r; }
   int size() const override { return n; }
+  // a rank that gives up between collectives: ncclCommAbort fails the operations its peers have in flight (or
+  // enqueue later) instead of leaving them blocked in ncclAllReduce / ncclAllGather for ever
+  void abort() override {
+    if (comm) (void)ncclCommAbort(comm);
+    comm = nullptr;  // the destructor skips ncclCommDestroy; further collectives on this rank fail below
+  }
+  void need_comm() const {
+    if (!comm) throw HipError("RCCL communicator was aborted after a failure on this rank");
+  }
   void allreduce(double *dev, size_t cnt, hipStream_t stream) override {
+    need_comm();
     const ncclResult_t rc = ncclAllReduce(dev, dev, cnt, ncclDouble, ncclSum, comm, stream);
     if (rc != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
   }
   void allreduce_u64(uint64_t *dev, size_t cnt, hipStream_t stream) override {
+    need_comm();
     const ncclResult_t rc = ncclAllReduce(dev, dev, cnt, ncclUint64, ncclSum, comm, stream);
     if (rc != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
   }
   void allreduce_mixed(uint64_t *a, size_t na, double *b, size_t nb, hipStream_t stream) override {
+    need_comm();
     ncclResult_t rc = ncclGroupStart();
     if (rc == ncclSuccess) rc = ncclAllReduce(a, a, na, ncclUint64, ncclSum, comm, stream);
     if (rc == ncclSuccess) rc = ncclAllReduce(b, b, nb, ncclDouble, ncclSum, comm, stream);
@@ -72,6 +84,7 @@ struct RcclComm final : msw_comm {
   DevBuf<double> ag_send, ag_recv;
   hipStream_t ag_stream = nullptr;
   void allgather_host(const double *send, size_t cnt, double *recv) override {
+    need_comm();
     if (!ag_stream) MSW_HIP(hipStreamCreateWithFlags(&ag_stream, hipStreamNonBlocking));
     ag_send.alloc(cnt);
     ag_recv.alloc(cnt * (size_t)n);
@@ -83,7 +96,7 @@ struct RcclComm final : msw_comm {
   }
   int count() const {  // what RCCL itself says the communicator spans
     int c = 0;
-    return ncclCommCount(comm, &c) == ncclSuccess ? c : -1;
+    return comm && ncclCommCount(comm, &c) == ncclSuccess ? c : -1;
   }
 };
 

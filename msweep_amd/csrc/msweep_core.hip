@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -77,6 +78,7 @@ struct msw_core {
   // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
   size_t lds_attr[2][20] = {};  // dynamic-LDS limit already granted per sweep instantiation
   msw_comm *comm = nullptr;
+  bool in_collective = false;  // a solve / sharded build is under way: a failure now strands the peers (guarded())
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
   // guarded ECs (sell.hpp): per-workgroup lists, per-wavefront bitmaps, error flag
   DevBuf<uint32_t> guard_list, guard_bits;
@@ -116,6 +118,7 @@ struct msw_core {
   // ---- measurement ---------------------------------------------------------------------------
   bool profiling = false, fixed_iters = false;
   msw_timing timing = {};
+  msw_bootstrap_timing btiming = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evA, evB;
   size_t evA_used = 0, evB_used = 0;
@@ -139,6 +142,13 @@ struct Fail : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
+// marks the stretch of a call in which this rank's peers wait for it in collectives
+struct CollectiveScope {
+  msw_core *h;
+  explicit CollectiveScope(msw_core *h_) : h(h_) { h->in_collective = true; }
+  void leave() { h->in_collective = false; }  // on success only: guarded() reads the flag after a throw
+};
+
 template <class F>
 int guarded(msw_handle h, F &&f) {
   if (!h) return 1;
@@ -149,7 +159,10 @@ int guarded(msw_handle h, F &&f) {
   } catch (const std::exception &ex) {
     h->err = ex.what();
     (void)hipGetLastError();
-    if (h->comm) h->comm->abort();  // peers of a sharded solve must not wait for this rank for ever
+    // peers of a sharded solve must not wait for this rank for ever -- but only a failure BETWEEN collectives
+    // (a solve or a sharded build was under way) strands them: argument and state errors touch no collective
+    if (h->comm && h->in_collective) h->comm->abort();
+    h->in_collective = false;
     return 1;
   }
 }
@@ -264,6 +277,8 @@ void alloc_solve_state(msw_core *h) {
   h->partC.alloc(1024);
   if (h->flavor == 0) {
     const uint32_t nb0 = (uint32_t)std::max(h->nblk, 1);
+    // every EC a workgroup can see: its wavefronts take slices (and long ECs) round-robin, SliceStream's stride
+    static_assert(kPassThreads / 64 <= 16 && kPassThreadsB / 64 <= 16, "guard_cap / guard_bits assume <= 16 wavefronts per workgroup");
     h->guard_cap = 64u * ((h->nslices + nb0 - 1) / nb0 + 16u) + (h->n_long + nb0 - 1) / nb0 + 16u;
     h->guard_words = (G + 31u) / 32u;
     h->guard_list.alloc((size_t)nb0 * h->guard_cap);
@@ -592,10 +607,12 @@ void finish_solve(msw_core *h, double *theta_out, size_t *iters_out, double *bou
   MSW_HIP(hipMemcpy(&gerr, h->guard_err.p, sizeof gerr, hipMemcpyDeviceToHost));
   if (gerr) {
     MSW_HIP(hipMemset(h->guard_err.p, 0, sizeof gerr));
+    if (gerr == 2) throw Fail("internal: a workgroup's list of guarded equivalence classes overflowed");
     throw Fail("likelihood underflow: an equivalence class has zero probability under every group "
                "(exp(a * log-likelihood) and the group weights underflow fp64 together)");
   }
-  if (!std::isfinite(h->sc_host->bound))
+  // (an EM run that was asked for no iteration leaves its initial bound, -inf: nothing is wrong)
+  if (h->sc_host->iter > 0 && !std::isfinite(h->sc_host->bound))
     throw Fail("the evidence lower bound is not finite: the likelihood or the prior counts are out of range");
   if (theta_out) {
     if (h->last_algo == MSW_ALGO_EM) {
@@ -633,8 +650,10 @@ void collect_timing(msw_core *h) {
   if (h->flavor == 0) {
     // algorithmic bytes: every real cell record once + the per-EC count vector in
     // pass B; SELL padding, slice offsets and the L2-served second read of pass B are not counted
-    h->timing.bytes_passA = h->nnz * recsz;
-    h->timing.bytes_passB = h->nnz * recsz + 1ull * h->E;  // + one byte per EC (its multiplicity)
+    // (slot tables that do not fit LDS are read from memory: every used 16-byte entry at least once per sweep)
+    const uint64_t tab = h->tlds ? 0ull : 16ull * h->n_area;
+    h->timing.bytes_passA = h->nnz * recsz + tab;
+    h->timing.bytes_passB = h->nnz * recsz + 1ull * h->E + tab;  // + one byte per EC (its multiplicity)
   } else {
     h->timing.bytes_passA = 8ull * h->E * h->G;
     h->timing.bytes_passB = 8ull * h->E * h->G + 8ull * h->E;
@@ -653,6 +672,7 @@ void continue_impl(msw_core *h, size_t n_iters, double *theta_out, size_t *iters
   if (n_iters == 0 || start + n_iters > (size_t)std::numeric_limits<int32_t>::max()) throw Fail("msw_core_continue: iteration count out of range");
   h->timing = {};
   h->evA_used = h->evB_used = 0;
+  CollectiveScope cs(h);
   hipLaunchKernelGGL(k_extend, dim3(1), dim3(1), 0, h->stream, h->sc.p, (int)n_iters);
   MSW_HIP(hipEventRecord(h->ev0, h->stream));
   run_rcg(h, start + n_iters, start);
@@ -660,6 +680,7 @@ void continue_impl(msw_core *h, size_t n_iters, double *theta_out, size_t *iters
   finish_solve(h, theta_out, iters_out, bound_out);
   collect_timing(h);
   h->timing.iters = (uint64_t)h->sc_host->iter - start;
+  cs.leave();
 }
 
 void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, double *theta_out,
@@ -668,6 +689,7 @@ void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, dou
   if (prec != MSW_PREC_DOUBLE && prec != MSW_PREC_FLOAT) throw Fail("unknown precision id");
   h->timing = {};
   h->evA_used = h->evB_used = 0;
+  CollectiveScope cs(h);
   begin_solve(h, tol, max_iters);
   MSW_HIP(hipEventRecord(h->ev0, h->stream));
   if (algo == MSW_ALGO_RCG) run_rcg(h, max_iters);
@@ -676,6 +698,7 @@ void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, dou
   h->last_algo = algo;
   finish_solve(h, theta_out, iters_out, bound_out);
   collect_timing(h);
+  cs.leave();
 }
 
 }  // namespace
@@ -858,12 +881,12 @@ int msw_core_resample_counts(msw_handle h, const uint32_t *ec_counts, size_t n_e
 int msw_core_bootstrap_dist(msw_handle h, msw_comm_t comm, const uint32_t *ec_counts, int32_t seed,
                             size_t bootstrap_count, size_t n_replicates, const double *alpha0, double tol,
                             size_t max_iters, int algo, int prec, double *theta_out, size_t *iters_out) {
-  const int rc = guarded(h, [&] {
+  // (a rank whose block fails still joins the all-gather and reports through its status word: every rank
+  // returns non-zero, none is left waiting, and the communicator stays usable -- host_bootstrap.inc)
+  return guarded(h, [&] {
     bootstrap_dist_impl(h, comm, ec_counts, seed, bootstrap_count, n_replicates, alpha0, tol, max_iters, algo,
                         prec, theta_out, iters_out);
   });
-  if (rc && comm) comm->abort();
-  return rc;
 }
 
 const char *msw_comm_last_error(void) { return g_create_error.c_str(); }
@@ -959,6 +982,13 @@ int msw_core_last_timing(msw_handle h, msw_timing *out) {
   return guarded(h, [&] {
     if (!out) throw Fail("null out");
     *out = h->timing;
+  });
+}
+
+int msw_core_last_bootstrap_timing(msw_handle h, msw_bootstrap_timing *out) {
+  return guarded(h, [&] {
+    if (!out) throw Fail("null out");
+    *out = h->btiming;
   });
 }
 

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
   auto defer = [&](uint32_t p) {
     const uint32_t i = __hip_atomic_fetch_add((lds_u32_t *)(size_t)gcnt_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    GD.list[(size_t)blockIdx.x * GD.cap + i] = p;
+    if (i < GD.cap) GD.list[(size_t)blockIdx.x * GD.cap + i] = p;
+    else *GD.err = 2;  // cannot happen while guard_cap mirrors the stride distribution (alloc_solve_state)
   };
   double nn = 0.0;
   if (skip) return;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   }
   // guarded ECs (sell.hpp): a wavefront each, every group visited -- no background term to cancel against
   __syncthreads();
-  const uint32_t n_guard = *(lds_u32_t *)(size_t)gcnt_off;
+  const uint32_t n_guard = min(*(lds_u32_t *)(size_t)gcnt_off, GD.cap);
   if (n_guard) {
     const uint32_t wv = uniform(tid >> 6), nwv = kPassThreads / 64;
     uint32_t *bits = GD.bits + (size_t)(blockIdx.x * 16 + wv) * GD.words;
@@ -554,7 +555,8 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
   auto defer = [&](uint32_t p) {
     const uint32_t i = __hip_atomic_fetch_add((lds_u32_t *)(size_t)gcnt_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    GD.list[(size_t)blockIdx.x * GD.cap + i] = p;
+    if (i < GD.cap) GD.list[(size_t)blockIdx.x * GD.cap + i] = p;
+    else *GD.err = 2;  // cannot happen while guard_cap mirrors the stride distribution (alloc_solve_state)
   };
   double s_clogZ = 0.0, s_rH = 0.0, s_W = 0.0;
   double lp_mant = 1.0;  // deferred logarithms: product of mantissas in [2^-960, 1] ...
@@ -849,7 +851,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   // EC's c_j directly -- listed: c e_g x / Z, not listed: c e_g p0 / Z -- and the EC stays out of
   // W = sum r_j (the background share of the ordinary ECs).
   __syncthreads();
-  const uint32_t n_guard = (GMODE != 4 || rg.first) ? *(lds_u32_t *)(size_t)gcnt_off : 0u;  // once, not per range run
+  const uint32_t n_guard = (GMODE != 4 || rg.first) ? min(*(lds_u32_t *)(size_t)gcnt_off, GD.cap) : 0u;  // once, not per range run
   if (n_guard) {
     const uint32_t wv = uniform(tid >> 6), nwv = kPassThreadsB / 64;
     uint32_t *bits = GD.bits + (size_t)(blockIdx.x * 16 + wv) * GD.words;

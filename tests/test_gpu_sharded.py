@@ -98,13 +98,13 @@ def test_rccl_transport_single_rank(gpu_core):
     assert_theta(sharded["theta"], plain["theta"])
 
 
-@pytest.mark.parametrize("n_ranks", [2, 3])
-def test_bootstrap_dist_gathers_every_replicate_on_every_rank(gpu_core, n_ranks):
+@pytest.mark.parametrize("n_ranks,B", [(2, 7), (3, 7), (3, 2), (3, 1)])
+def test_bootstrap_dist_gathers_every_replicate_on_every_rank(gpu_core, n_ranks, B):
     """msw_core_bootstrap_dist (the replicate loop of src/mSWEEP.cpp:496-518 over the GPUs of a node):
     thread-ranks with the in-process communicator; every rank ends with the whole B x G table in
     replicate order, equal to the single-handle run whatever the number of ranks."""
     p = synth.make_csr_problem(30000, 80, seed=44, max_other=6)
-    G, B = 80, 7                                     # 7 replicates over 2 / 3 ranks: ragged blocks
+    G = 80                   # 7 replicates over 2 / 3 ranks: ragged blocks; 2 and 1 over 3: ranks with nothing to solve
     alpha0 = np.ones(G)
     w = p["ec_counts"].astype(np.uint32)
     draws = int(w.sum())
@@ -136,6 +136,79 @@ def test_bootstrap_dist_gathers_every_replicate_on_every_rank(gpu_core, n_ranks)
         np.testing.assert_array_equal(iters, it_single)
         for b in range(B):
             assert_theta(theta[b], single[b])
+
+
+def test_bootstrap_dist_failing_rank_fails_every_rank_and_nobody_waits(gpu_core):
+    """A rank whose block of replicates fails (here: a bad draw count on it alone) still joins the all-gather
+    and reports through its status word: EVERY rank gets an error, none is left in the collective, and the
+    communicator is still good for the next call."""
+    p = synth.make_csr_problem(20000, 50, seed=46, max_other=5)
+    G, B, n_ranks = 50, 5, 3
+    alpha0 = np.ones(G)
+    w = p["ec_counts"].astype(np.uint32)
+    draws = int(w.sum())
+    comms = Comm.local(n_ranks)
+    first, second = [None] * n_ranks, [None] * n_ranks
+
+    def work(r):
+        core = Core(0)
+        try:
+            from_grouped_counts(core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+            try:
+                core.bootstrap_dist(comms[r], w, 42, 0 if r == 1 else draws, B, alpha0)
+                first[r] = "ok"
+            except RuntimeError as ex:
+                first[r] = str(ex)
+            second[r] = core.bootstrap_dist(comms[r], w, 42, draws, B, alpha0)
+        except Exception as ex:
+            second[r] = ex
+        finally:
+            core.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+        assert not t.is_alive(), "a rank is still waiting in the exchange"
+    assert "bootstrap_count must be" in first[1], first
+    assert "rank 1 failed" in first[0] and "rank 1 failed" in first[2], first
+    for r in range(n_ranks):
+        assert not isinstance(second[r], Exception), second[r]
+        np.testing.assert_array_equal(second[r][0], second[0][0])
+
+
+def test_api_misuse_on_a_sharded_handle_does_not_poison_the_group(gpu_core):
+    """An argument / state error on a handle with a communicator attached touches no collective: the
+    group must stay usable (the in-process group's failure flag is sticky)."""
+    p = synth.make_csr_problem(20000, 40, seed=47, max_other=5)
+    G, n_ranks = 40, 2
+    bounds = shard_ecs(p["rowptr"], n_ranks)
+    comms = Comm.local(n_ranks)
+    out, err = [None] * n_ranks, []
+
+    def work(r):
+        try:
+            core = Core(0)
+            blk = csr_block(p, bounds[r], bounds[r + 1])
+            lik = from_grouped_counts(core, blk["rowptr"], blk["grp"], blk["cnt"], blk["ec_counts"], p["group_sizes"])
+            core.set_comm(comms[r])
+            if r == 0:
+                with pytest.raises(RuntimeError, match="no solve has run"):
+                    core.gamma_block(0, 1)
+            out[r] = core.solve(lik.log_counts(), np.ones(G), tol=1e-6)
+            core.set_comm(None)
+            core.close()
+        except Exception as ex:
+            err.append(ex)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not err, err
+    np.testing.assert_array_equal(out[0]["theta"], out[1]["theta"])
 
 
 def test_bootstrap_leaves_the_original_estimate_on_the_handle(gpu_core):
