@@ -95,6 +95,21 @@ int msw_core_get_dense_logl(msw_handle h, double *L_out, size_t ld);
 int msw_core_layout_hash(msw_handle h, uint64_t *hash_out);
 /* shape of the resident likelihood */
 int msw_core_shape(msw_handle h, size_t *n_groups, size_t *n_ecs, size_t *nnz);
+/* How the resident CSR-of-ECs likelihood is laid out for the sweeps: reporting only (bench.py, the
+ * timing tools); no reference counterpart. */
+typedef struct msw_layout_info {
+  int32_t record_bytes;        /* 4 or 8 bytes per listed cell */
+  int32_t index_records;       /* 1: (group, entry) index records + hybrid slot area; 0: byte-offset records */
+  int32_t groups_in_lds;       /* the per-group vectors of both sweeps live in LDS */
+  int32_t table_in_lds;        /* the whole slot area lives in LDS */
+  int32_t passB_mode;          /* k_passB GMODE (sweep_kernels.hpp) */
+  uint32_t slot_entries;       /* 16-byte entries of the slot area */
+  uint32_t slot_entries_in_lds;
+  uint32_t n_slices, n_long_ecs;
+  uint64_t rows;               /* slice rows (64 records each), padding included */
+  uint64_t rows_from_memory;   /* ... whose table entries are gathered from memory (cold segments, whole slices) */
+} msw_layout_info;
+int msw_core_layout_info(msw_handle h, msw_layout_info *out);
 
 /* ---- solve --------------------------------------------------------------------------
  * Replaces rcgpar::rcg_optl_torch / rcg_optl_omp / em_torch as called from rcg_optl()

@@ -28,7 +28,7 @@ EXPORTS = [
     "msw_core_set_fixed_iters", "msw_core_hbm_stream_rates", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
     "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
     "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_core_continue", "msw_core_gamma_block",
-    "msw_core_last_bootstrap_timing",
+    "msw_core_last_bootstrap_timing", "msw_core_layout_info",
 ]
 
 
@@ -40,6 +40,13 @@ class Timing(C.Structure):
     _fields_ = [("solve_ms", C.c_double), ("passA_ms", C.c_double), ("passB_ms", C.c_double),
                 ("passA_launches", C.c_uint64), ("passB_launches", C.c_uint64), ("iters", C.c_uint64),
                 ("bytes_passA", C.c_uint64), ("bytes_passB", C.c_uint64)]
+
+
+class LayoutInfo(C.Structure):
+    _fields_ = [("record_bytes", C.c_int32), ("index_records", C.c_int32), ("groups_in_lds", C.c_int32),
+                ("table_in_lds", C.c_int32), ("passB_mode", C.c_int32), ("slot_entries", C.c_uint32),
+                ("slot_entries_in_lds", C.c_uint32), ("n_slices", C.c_uint32), ("n_long_ecs", C.c_uint32),
+                ("rows", C.c_uint64), ("rows_from_memory", C.c_uint64)]
 
 
 class BootstrapTiming(C.Structure):
@@ -121,6 +128,7 @@ def load_library():
     L.msw_core_hbm_stream_rates.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.msw_core_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.msw_core_last_bootstrap_timing.argtypes = [vp, C.POINTER(BootstrapTiming)]
+    L.msw_core_layout_info.argtypes = [vp, C.POINTER(LayoutInfo)]
     L.msw_comm_unique_id.argtypes = [vp]
     L.msw_comm_create_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.msw_comm_create_local.argtypes = [C.c_int, C.POINTER(vp)]
@@ -251,6 +259,12 @@ class Core:
         g, e, n = C.c_size_t(), C.c_size_t(), C.c_size_t()
         self._check(self._L.msw_core_shape(self._h, C.byref(g), C.byref(e), C.byref(n)))
         return g.value, e.value, n.value
+
+    def layout_info(self):
+        """How the resident CSR-of-ECs likelihood is laid out for the sweeps (msw_core_layout_info)."""
+        t = LayoutInfo()
+        self._check(self._L.msw_core_layout_info(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in LayoutInfo._fields_}
 
     def layout_hash(self):
         out = C.c_uint64(0)

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_invert_perm(const uint32_t *perm, uint3
 // order: out[g * ld + (j - e0)], all groups.  A thread per EC: its normaliser lse_j, the background value
 // of every group, then its listed cells.  What msw_core_gamma_block serves --write-probs / the binning input
 // from, block by block (src/Sample.cpp:63-85, src/mSWEEP.cpp:437-469), without a G x E buffer anywhere.
-template <bool WIDE>
+template <int ENC>
 __global__ __launch_bounds__(256) void k_gamma_block(SellDev S, const uint32_t *iperm, uint32_t e0, uint32_t e1,
                                                     double a, double logzi, double tref, const double *u,
                                                     const double *lut, int normalise, double *out, size_t ld) {
@@ -42,13 +42,13 @@ __global__ __launch_bounds__(256) void k_gamma_block(SellDev S, const uint32_t *
     double lse = 0.0;
     if (normalise) {
       double zs = 0.0;
-      for_each_cell<WIDE>(S, p, [&](uint32_t g, uint32_t i) { zs += exp(u[g] - M) * (exp(a * (lut[i] - tref)) - p0); });
+      for_each_cell<ENC>(S, p, [&](uint32_t g, uint32_t i) { zs += exp(u[g] - M) * (exp(a * (lut[i] - tref)) - p0); });
       double Z = p0 * U + zs;
       if (!(Z >= p0 * U * kGuardRatio)) {  // guarded EC (sell.hpp): every group visited instead
         Z = 0.0;
         for (uint32_t g = 0; g < S.n_groups; ++g) {
           double xg = p0;
-          for_each_cell<WIDE>(S, p, [&](uint32_t gg, uint32_t i) { if (gg == g) xg = exp(a * (lut[i] - tref)); });
+          for_each_cell<ENC>(S, p, [&](uint32_t gg, uint32_t i) { if (gg == g) xg = exp(a * (lut[i] - tref)); });
           Z += exp(u[g] - M) * xg;
         }
       }
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_gamma_block(SellDev S, const uint32_t *
     }
     double *col = out + (j - e0);
     for (uint32_t g = 0; g < S.n_groups; ++g) col[(size_t)g * ld] = a * logzi + u[g] - lse;
-    for_each_cell<WIDE>(S, p, [&](uint32_t g, uint32_t i) { col[(size_t)g * ld] = a * lut[i] + u[g] - lse; });
+    for_each_cell<ENC>(S, p, [&](uint32_t g, uint32_t i) { col[(size_t)g * ld] = a * lut[i] + u[g] - lse; });
   }
 }
 

@@ -48,10 +48,16 @@ struct msw_core {
   int flavor = -1;  // -1 none, 0 CSR-of-ECs, 1 dense
   uint32_t G = 0, E = 0, n_lut = 0, nslices = 0, n_long = 0;
   uint64_t nnz = 0, nslots = 0;
-  bool wide = false, glds = true, tlds = true;
+  int enc = kEncNarrow;  // record encoding (sell.hpp): narrow byte offsets / wide / index records (hybrid area)
+  bool glds = true, tlds = true;
   int gmodeB = 1;  // k_passB GMODE (sweep_kernels.hpp)
-  uint32_t enc_shift = 0, enc_mask = 0, enc_bhi = 0;  // record encoding (sell.hpp)
+  uint32_t enc_shift = 0, enc_mask = 0, enc_bhi = 0, enc_bhiA = 0;  // record encoding (sell.hpp)
   uint32_t n_area = 0;                                  // 16-byte entries of the slot area
+  uint32_t n_tab_lds = 0;                               // ... of which the LDS images hold (all, the hot head, none)
+  DevBuf<uint8_t> slice_hot;                            // index records: rows of every slice's hot segment
+  bool wide() const { return enc == kEncWide; }
+  bool hybrid() const { return enc == kEncIndex; }
+  RecDec dec() const { return RecDec{enc_shift, enc_mask, enc_bhi, enc_bhiA}; }
   uint32_t long_row = kLongRow;                         // ECs with more cells go one per wavefront (<= kLongRow)
   DevBuf<uint32_t> area_slot;
   DevBuf<double> lut_area;  // lut[area_slot[i]]: what the per-slot tables are built from, in their order
@@ -76,7 +82,7 @@ struct msw_core {
   TabDev tabs() const { return TabDev{tabA.p, tabB.p}; }
   DevBuf<double> partA, partS, partAcc, partC, partR, totS;
   // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
-  size_t lds_attr[2][20] = {};  // dynamic-LDS limit already granted per sweep instantiation
+  size_t lds_attr[2][30] = {};  // dynamic-LDS limit already granted per sweep instantiation
   msw_comm *comm = nullptr;
   bool in_collective = false;  // a solve / sharded build is under way: a failure now strands the peers (guarded())
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
@@ -197,7 +203,28 @@ SellDev sell_view(msw_core *h) {
   S.shift = h->enc_shift;
   S.mask = h->enc_mask;
   S.bhi = h->enc_bhi;
+  S.bhiA = h->enc_bhiA;
+  S.n_tab_lds = h->n_tab_lds;
+  S.slice_hot = h->slice_hot.p;
   return S;
+}
+
+// pass B's mode for a given placement of the group vectors (glds) and n_tab slot entries in LDS; -1 = no fit
+int passB_mode(const msw_core *h, bool glds, uint32_t n_tab, bool index) {
+  const uint32_t G = h->G;
+  if (glds) {
+    if (pass_lds_bytes(1, n_tab, G, false, index) > kLdsMax) return -1;
+    // column sums at the fixed immediate distance when e_g fits below it and the image still fits
+    if (8ull * (G + kSentinels) <= kAccFixed && pass_lds_bytes(2, n_tab, G, false, index) <= kLdsMax) return 2;
+    return 1;
+  }
+  if (pass_lds_bytes(0, n_tab, G, false, index) > kLdsMax) return -1;
+  if (getenv("MSWEEP_GLOBAL_ATOMICS")) return 0;  // developer switch: mode 0 (column sums in HBM)
+  // too many groups for {e, w} / e + sums in LDS: the column sums alone may still fit (mode 3) ...
+  if (pass_lds_bytes(3, n_tab, G, false, index) <= kLdsMax) return 3;
+  // ... and beyond that one range of groups at a time does (mode 4), whatever the group count
+  if (pass_lds_bytes(4, n_tab, G, false, index) <= kLdsMax) return 4;
+  return 0;
 }
 
 void choose_lds_mode(msw_core *h) {
@@ -205,22 +232,13 @@ void choose_lds_mode(msw_core *h) {
   const char *force = getenv("MSWEEP_FORCE_LDS");  // developer switch: "gt", e.g. "10" = groups in LDS, slots not
   for (auto &o : opts) {
     if (force && strlen(force) == 2 && (o[0] != (force[0] == '1') || o[1] != (force[1] == '1'))) continue;
-    const int gm = o[0] ? 1 : 0;
-    const size_t a = pass_lds_bytes(gm, o[1], h->G, h->n_area, true);
-    const size_t b = pass_lds_bytes(gm, o[1], h->G, h->n_area, false);
-    if (std::max(a, b) <= kLdsMax) {
+    const uint32_t n_tab = o[1] ? h->n_area : 0u;
+    const int gmB = passB_mode(h, o[0], n_tab, false);
+    if (gmB >= 0 && pass_lds_bytes(o[0] ? 1 : 0, n_tab, h->G, true, false) <= kLdsMax) {
       h->glds = o[0];
       h->tlds = o[1];
-      // column sums at the fixed immediate distance when e_g fits below it and the image still fits
-      h->gmodeB = gm;
-      if (o[0] && 8ull * (h->G + kSentinels) <= kAccFixed &&
-          pass_lds_bytes(2, o[1], h->G, h->n_area, false) <= kLdsMax)
-        h->gmodeB = 2;
-      // too many groups for {e, w} / e + sums in LDS: the column sums alone may still fit (mode 3)
-      if (!o[0] && getenv("MSWEEP_GLOBAL_ATOMICS")) return;  // developer switch: mode 0 (column sums in HBM)
-      if (!o[0] && pass_lds_bytes(3, o[1], h->G, h->n_area, false) <= kLdsMax) h->gmodeB = 3;
-      // ... and beyond that one range of groups at a time does (mode 4), whatever the group count
-      else if (!o[0] && pass_lds_bytes(4, o[1], h->G, h->n_area, false) <= kLdsMax) h->gmodeB = 4;
+      h->gmodeB = gmB;
+      h->n_tab_lds = n_tab;
       return;
     }
   }
@@ -231,23 +249,62 @@ void choose_lds_mode(msw_core *h) {
 // 32-bit record that holds both byte offsets, else 8-byte records.  Runs before the SELL packing.
 void choose_layout(msw_core *h) {
   choose_lds_mode(h);
-  h->enc_bhi = sell_bhi(h->tlds, h->n_area);
+  h->enc_bhi = sell_bhi(h->n_tab_lds);
+  h->enc_bhiA = 2 * h->enc_bhi;
   const uint64_t lo_end = 16ull * std::max<uint32_t>(h->n_area, 1);              // lo < lo_end
   const uint64_t hi_end = (uint64_t)h->enc_bhi + 8ull * ((uint64_t)h->G + kSentinels);  // hi < hi_end
-  h->wide = true;
+  h->enc = kEncWide;
   h->enc_shift = 0;
   h->enc_mask = 0xffffffffu;
-  const char *force = getenv("MSWEEP_RECORD_BYTES");  // developer switch: 8 = skip the 4-byte format
+  const char *force = getenv("MSWEEP_RECORD_BYTES");  // developer switch: 8 = skip the 4-byte formats
   for (uint32_t s = 5; s <= 31 && !(force && atoi(force) == 8); ++s) {
     if (lo_end <= (1ull << (s - 1)) && hi_end <= (1ull << (32 - s))) {
-      h->wide = false;
+      h->enc = kEncNarrow;
       h->enc_shift = s;
       h->enc_mask = (1u << (s - 1)) - 1u;
       break;
     }
   }
-  if (h->wide && (hi_end > (1ull << 31) || lo_end > (1ull << 32)))
+  if (h->wide() && (hi_end > (1ull << 31) || lo_end > (1ull << 32)))
     throw Fail("likelihood too large: group / lookup-table offsets exceed the 8-byte record fields");
+}
+
+// The hybrid slot area (sell.hpp, index records) for likelihoods whose slot tables do not fit LDS beside the
+// group vectors: 4-byte records of (group, entry) INDICES when both fit 32 bits, the group vectors where
+// choose_lds_mode put them, and as many of the most-used entries in LDS as both sweeps' images leave room for.
+// Returns false (layout untouched) when it does not apply.
+bool choose_hybrid_layout(msw_core *h) {
+  if (h->tlds) return false;
+  if (const char *e = getenv("MSWEEP_HYBRID"))  // developer switch: 0 = the all-memory tables (and wide records)
+    if (atoi(e) == 0) return false;
+  const char *force = getenv("MSWEEP_RECORD_BYTES");
+  if (force && atoi(force) == 8) return false;
+  uint32_t eb = 1, gb = 1;
+  while ((1ull << eb) < std::max<uint32_t>(h->n_area, 2)) ++eb;
+  while ((1ull << gb) < (uint64_t)h->G + kSentinels) ++gb;
+  if (eb + gb > 32) return false;
+  // room for the table: the largest multiple of 16 entries (256 bytes) that both images hold
+  uint32_t n_hot = 0;
+  {
+    const int gmA = h->glds ? 1 : 0;
+    uint32_t lo = 0, hi = std::min<uint32_t>(h->n_area, (uint32_t)(kLdsMax / 16)) / 16;  // in units of 16 entries
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) / 2, n = mid * 16;
+      const bool ok = pass_lds_bytes(gmA, n, h->G, true, true) <= kLdsMax && passB_mode(h, h->glds, n, true) >= 0 &&
+                      (h->glds || passB_mode(h, false, n, true) == passB_mode(h, false, 0, true));
+      if (ok) lo = mid;
+      else hi = mid - 1;
+    }
+    n_hot = lo * 16;
+  }
+  if (const char *e = getenv("MSWEEP_HYBRID_HOT")) n_hot = std::min<uint32_t>(n_hot, (uint32_t)atoi(e) & ~15u);  // developer switch
+  h->enc = kEncIndex;
+  h->enc_shift = eb;
+  h->enc_mask = (1u << eb) - 1u;
+  h->n_tab_lds = std::min(n_hot, h->n_area);
+  h->enc_bhi = h->enc_bhiA = sell_bhi(h->n_tab_lds);
+  h->gmodeB = passB_mode(h, h->glds, h->n_tab_lds, true);
+  return true;
 }
 
 void alloc_solve_state(msw_core *h) {
@@ -318,19 +375,19 @@ void prepare_sweep(K k, size_t lds, size_t &lds_set) {
     lds_set = lds;
   }
 }
-template <bool W, bool GL, bool TL>
+template <int ENC, bool GL, bool TL>
 void launch_passA_t(msw_core *h) {
-  const size_t lds = pass_lds_bytes(GL ? 1 : 0, TL, h->G, h->n_area, true);
-  auto k = k_passA<W, GL, TL>;
-  prepare_sweep(k, lds, h->lds_attr[0][(W ? 4 : 0) | (GL ? 2 : 0) | (TL ? 1 : 0)]);
+  const size_t lds = pass_lds_bytes(GL ? 1 : 0, h->n_tab_lds, h->G, true, ENC == kEncIndex);
+  auto k = k_passA<ENC, GL, TL>;
+  prepare_sweep(k, lds, h->lds_attr[0][ENC * 4 + (GL ? 2 : 0) + (TL ? 1 : 0)]);
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h),
                      h->ew.p, h->tabA.p, h->partA.p, h->guard_view());
 }
-template <bool W, int GM, bool TL>
+template <int ENC, int GM, bool TL>
 void launch_passB_t(msw_core *h) {
-  const size_t lds = pass_lds_bytes(GM, TL, h->G, h->n_area, false);
-  auto k = k_passB<W, GM, TL>;
-  prepare_sweep(k, lds, h->lds_attr[1][(W ? 10 : 0) + 2 * GM + (TL ? 1 : 0)]);
+  const size_t lds = pass_lds_bytes(GM, h->n_tab_lds, h->G, false, ENC == kEncIndex);
+  auto k = k_passB<ENC, GM, TL>;
+  prepare_sweep(k, lds, h->lds_attr[1][ENC * 10 + 2 * GM + (TL ? 1 : 0)]);
   if (GM == 4) {  // one run per range of groups; the first also delivers the ELBO terms
     for (uint32_t g0 = 0; g0 < h->G; g0 += kRangeGroups)
       hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreadsB), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
@@ -344,42 +401,51 @@ void launch_passB_t(msw_core *h) {
 
 #define MSW_DISPATCH3(fn, ...)                                                       \
   do {                                                                               \
-    const int key = (h->wide ? 4 : 0) | (h->glds ? 2 : 0) | (h->tlds ? 1 : 0);       \
+    const int key = h->enc * 4 + (h->glds ? 2 : 0) + (h->tlds ? 1 : 0);              \
     switch (key) {                                                                   \
-      case 0: fn<false, false, false>(__VA_ARGS__); break;                           \
-      case 1: fn<false, false, true>(__VA_ARGS__); break;                            \
-      case 2: fn<false, true, false>(__VA_ARGS__); break;                            \
-      case 3: fn<false, true, true>(__VA_ARGS__); break;                             \
-      case 4: fn<true, false, false>(__VA_ARGS__); break;                            \
-      case 5: fn<true, false, true>(__VA_ARGS__); break;                             \
-      case 6: fn<true, true, false>(__VA_ARGS__); break;                             \
-      default: fn<true, true, true>(__VA_ARGS__); break;                             \
+      case 0: fn<kEncNarrow, false, false>(__VA_ARGS__); break;                      \
+      case 1: fn<kEncNarrow, false, true>(__VA_ARGS__); break;                       \
+      case 2: fn<kEncNarrow, true, false>(__VA_ARGS__); break;                       \
+      case 3: fn<kEncNarrow, true, true>(__VA_ARGS__); break;                        \
+      case 4: fn<kEncWide, false, false>(__VA_ARGS__); break;                        \
+      case 5: fn<kEncWide, false, true>(__VA_ARGS__); break;                         \
+      case 6: fn<kEncWide, true, false>(__VA_ARGS__); break;                         \
+      case 7: fn<kEncWide, true, true>(__VA_ARGS__); break;                          \
+      case 8: fn<kEncIndex, false, false>(__VA_ARGS__); break;                       \
+      case 10: fn<kEncIndex, true, false>(__VA_ARGS__); break;                       \
+      default: throw Fail("internal: no sweep for this layout");                     \
     }                                                                                \
   } while (0)
 #define MSW_DISPATCH_B(fn, ...)                                                      \
   do {                                                                               \
-    const int key = (h->wide ? 10 : 0) + 2 * h->gmodeB + (h->tlds ? 1 : 0);          \
+    const int key = h->enc * 10 + 2 * h->gmodeB + (h->tlds ? 1 : 0);                 \
     switch (key) {                                                                   \
-      case 0: fn<false, 0, false>(__VA_ARGS__); break;                               \
-      case 1: fn<false, 0, true>(__VA_ARGS__); break;                                \
-      case 2: fn<false, 1, false>(__VA_ARGS__); break;                               \
-      case 3: fn<false, 1, true>(__VA_ARGS__); break;                                \
-      case 4: fn<false, 2, false>(__VA_ARGS__); break;                               \
-      case 5: fn<false, 2, true>(__VA_ARGS__); break;                                \
-      case 6: fn<false, 3, false>(__VA_ARGS__); break;                               \
-      case 7: fn<false, 3, true>(__VA_ARGS__); break;                                \
-      case 8: fn<false, 4, false>(__VA_ARGS__); break;                               \
-      case 9: fn<false, 4, true>(__VA_ARGS__); break;                                \
-      case 10: fn<true, 0, false>(__VA_ARGS__); break;                               \
-      case 11: fn<true, 0, true>(__VA_ARGS__); break;                                \
-      case 12: fn<true, 1, false>(__VA_ARGS__); break;                               \
-      case 13: fn<true, 1, true>(__VA_ARGS__); break;                                \
-      case 14: fn<true, 2, false>(__VA_ARGS__); break;                               \
-      case 15: fn<true, 2, true>(__VA_ARGS__); break;                                \
-      case 16: fn<true, 3, false>(__VA_ARGS__); break;                               \
-      case 17: fn<true, 3, true>(__VA_ARGS__); break;                                \
-      case 18: fn<true, 4, false>(__VA_ARGS__); break;                               \
-      default: fn<true, 4, true>(__VA_ARGS__); break;                                \
+      case 0: fn<kEncNarrow, 0, false>(__VA_ARGS__); break;                          \
+      case 1: fn<kEncNarrow, 0, true>(__VA_ARGS__); break;                           \
+      case 2: fn<kEncNarrow, 1, false>(__VA_ARGS__); break;                          \
+      case 3: fn<kEncNarrow, 1, true>(__VA_ARGS__); break;                           \
+      case 4: fn<kEncNarrow, 2, false>(__VA_ARGS__); break;                          \
+      case 5: fn<kEncNarrow, 2, true>(__VA_ARGS__); break;                           \
+      case 6: fn<kEncNarrow, 3, false>(__VA_ARGS__); break;                          \
+      case 7: fn<kEncNarrow, 3, true>(__VA_ARGS__); break;                           \
+      case 8: fn<kEncNarrow, 4, false>(__VA_ARGS__); break;                          \
+      case 9: fn<kEncNarrow, 4, true>(__VA_ARGS__); break;                           \
+      case 10: fn<kEncWide, 0, false>(__VA_ARGS__); break;                           \
+      case 11: fn<kEncWide, 0, true>(__VA_ARGS__); break;                            \
+      case 12: fn<kEncWide, 1, false>(__VA_ARGS__); break;                           \
+      case 13: fn<kEncWide, 1, true>(__VA_ARGS__); break;                            \
+      case 14: fn<kEncWide, 2, false>(__VA_ARGS__); break;                           \
+      case 15: fn<kEncWide, 2, true>(__VA_ARGS__); break;                            \
+      case 16: fn<kEncWide, 3, false>(__VA_ARGS__); break;                           \
+      case 17: fn<kEncWide, 3, true>(__VA_ARGS__); break;                            \
+      case 18: fn<kEncWide, 4, false>(__VA_ARGS__); break;                           \
+      case 19: fn<kEncWide, 4, true>(__VA_ARGS__); break;                            \
+      case 20: fn<kEncIndex, 0, false>(__VA_ARGS__); break;                          \
+      case 22: fn<kEncIndex, 1, false>(__VA_ARGS__); break;                          \
+      case 24: fn<kEncIndex, 2, false>(__VA_ARGS__); break;                          \
+      case 26: fn<kEncIndex, 3, false>(__VA_ARGS__); break;                          \
+      case 28: fn<kEncIndex, 4, false>(__VA_ARGS__); break;                          \
+      default: throw Fail("internal: no sweep for this layout");                     \
     }                                                                                \
   } while (0)
 
@@ -646,12 +712,13 @@ void collect_timing(msw_core *h) {
     }
   }
   h->timing.iters = (uint64_t)h->sc_host->iter;
-  const uint64_t recsz = h->wide ? 8 : 4;
+  const uint64_t recsz = h->wide() ? 8 : 4;
   if (h->flavor == 0) {
     // algorithmic bytes: every real cell record once + the per-EC count vector in
     // pass B; SELL padding, slice offsets and the L2-served second read of pass B are not counted
     // (slot tables that do not fit LDS are read from memory: every used 16-byte entry at least once per sweep)
-    const uint64_t tab = h->tlds ? 0ull : 16ull * h->n_area;
+    // (a hybrid area: the entries beyond its LDS-resident head)
+    const uint64_t tab = h->tlds ? 0ull : 16ull * (h->n_area - h->n_tab_lds);
     h->timing.bytes_passA = h->nnz * recsz + tab;
     h->timing.bytes_passB = h->nnz * recsz + 1ull * h->E + tab;  // + one byte per EC (its multiplicity)
   } else {
@@ -783,6 +850,34 @@ int msw_core_build_likelihood(msw_handle h, const uint64_t *ec_tptr, const uint3
     build_likelihood_impl(h, ec_tptr, ec_targets, n_ecs, target_group, n_targets, group_sizes,
                           n_groups, ec_counts, q, e, zero_inflation, min_hits, n_groups_out, mask_out,
                           logc_out);
+  });
+}
+
+int msw_core_layout_info(msw_handle h, msw_layout_info *out) {
+  return guarded(h, [&] {
+    if (!out) throw Fail("null out");
+    if (h->flavor != 0) throw Fail("msw_core_layout_info: no CSR-of-ECs likelihood resident");
+    msw_layout_info li = {};
+    li.record_bytes = h->wide() ? 8 : 4;
+    li.index_records = h->hybrid() ? 1 : 0;
+    li.groups_in_lds = h->glds ? 1 : 0;
+    li.table_in_lds = h->tlds ? 1 : 0;
+    li.passB_mode = h->gmodeB;
+    li.slot_entries = h->n_area;
+    li.slot_entries_in_lds = h->n_tab_lds;
+    li.n_slices = h->nslices;
+    li.n_long_ecs = h->n_long;
+    std::vector<uint32_t> off((size_t)h->nslices + 1);
+    MSW_HIP(hipMemcpy(off.data(), h->slice_off.p, off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    li.rows = off[h->nslices];
+    if (h->hybrid()) {
+      std::vector<uint8_t> hot(std::max<uint32_t>(h->nslices, 1));
+      MSW_HIP(hipMemcpy(hot.data(), h->slice_hot.p, hot.size(), hipMemcpyDeviceToHost));
+      for (uint32_t s2 = 0; s2 < h->nslices; ++s2) li.rows_from_memory += (off[s2 + 1] - off[s2]) - hot[s2];
+    } else if (!h->tlds) {
+      li.rows_from_memory = li.rows;
+    }
+    *out = li;
   });
 }
 

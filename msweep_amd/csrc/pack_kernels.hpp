@@ -20,14 +20,26 @@ __device__ __constant__ uint8_t kRPosDev[64] = {0,  1,  2,  3,  0,  1,  2,  3,  
                                                 0,  1,  2,  3,  0,  1,  2,  3,  4,  5,  6,  7,  4,  5,  6,  7,
                                                 8,  9,  10, 11, 8,  9,  10, 11, 12, 13, 14, 15, 12, 13, 14, 15};
 
-// sort key of an EC: 0 = long (plain CSR part), else 1 + (kLongRow - cells): ascending = SELL order
+// Cold class of an EC for the hybrid slot area (sell.hpp, index records): 0 = no cell refers to an entry beyond
+// the n_hot LDS-resident ones, 1 = one or two do, 2 = three or four, 3 = more (such a slice is taken from memory
+// as a whole).  ECs of equal length are sorted by it, so that a slice's cold segment is as short as its ECs allow.
+__host__ __device__ inline uint32_t cold_class(uint32_t n_cold) {
+  return n_cold == 0 ? 0u : (n_cold <= 2 ? 1u : (n_cold <= (uint32_t)kColdRows ? 2u : 3u));
+}
+constexpr uint32_t kPackKeyBits = 11;  // (1 + kLongRow) * 4 + 3 < 2^11
+// sort key of an EC: 0 = long (plain CSR part), else (1 + (kLongRow - cells)) * 4 + cold class: ascending = SELL
+// order.  canon == nullptr: no hybrid area, every cold class 0.
 __global__ __launch_bounds__(256) void k_pack_keys(const uint32_t *rowptr, uint32_t E, uint32_t long_row,
+                                                  const uint32_t *idx, const uint32_t *canon, uint32_t n_hot,
                                                   uint32_t *key, uint32_t *val, uint32_t *n_long) {
   uint32_t mine = 0;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < E; j += gridDim.x * blockDim.x) {
-    const uint32_t len = rowptr[j + 1] - rowptr[j];
+    const uint32_t b = rowptr[j], len = rowptr[j + 1] - b;
     const bool lg = len > long_row;  // long_row <= kLongRow
-    key[j] = lg ? 0u : 1u + ((uint32_t)kLongRow - len);
+    uint32_t cc = 0;
+    if (canon && len <= 16u)  // slices of more rows take every entry from memory anyway
+      for (uint32_t k = 0; k < len; ++k) cc += canon[idx[b + k]] >= n_hot;
+    key[j] = lg ? 0u : (1u + ((uint32_t)kLongRow - len)) * 4u + cold_class(cc);
     val[j] = j;
     mine += lg;
   }
@@ -78,29 +90,30 @@ __global__ __launch_bounds__(256) void k_gather_f64(const double *src, const uin
 struct PackEnc {
   const uint32_t *canon;     // [n_lut] slot -> entry of the compact part of the slot area
   const uint32_t *hot_rank;  // [n_lut] rank among the replicated slots, UINT32_MAX = not replicated
-  uint32_t rep_base, shift, bhi, n_groups, sentinel_slot;
+  uint32_t rep_base, n_groups, sentinel_slot;
+  RecDec dec;
+  uint32_t n_hot;            // hybrid area (index records): entries below it are LDS-resident
+  uint8_t *slice_hot;        // hybrid area: rows of every slice's hot segment (written by k_pack_slices)
 };
 __device__ __forceinline__ uint32_t pack_entry(const PackEnc &pe, int lane, uint32_t idx) {
   const uint32_t j = pe.hot_rank[idx];
   if (lane < 0 || j == UINT32_MAX) return pe.canon[idx];
   return pe.rep_base + (j >> 1) * 16 + 2 * (kRPosDev[lane] >> 1) + (j & 1);
 }
-template <bool WIDE>
+template <int ENC>
 __device__ __forceinline__ void pack_put(uint32_t *dst, size_t slot, const PackEnc &pe, uint32_t g, uint32_t entry) {
-  const uint32_t hi = pe.bhi + 8u * g, lo = 16u * entry;
-  if (WIDE) reinterpret_cast<uint2 *>(dst)[slot] = make_uint2(hi, lo);
-  else dst[slot] = (hi << pe.shift) | lo;
+  reinterpret_cast<typename Rec<ENC>::T *>(dst)[slot] = Rec<ENC>::make(g, entry, pe.dec);
 }
 
 // records of the long ECs (plain CSR, any lane reads them: compact slot entries)
-template <bool WIDE>
+template <int ENC>
 __global__ __launch_bounds__(256) void k_pack_long(const uint32_t *rowptr, const uint32_t *grp, const uint32_t *idx,
                                                   const uint32_t *perm, const uint32_t *long_ptr, uint32_t n_long,
                                                   PackEnc pe, uint32_t *rec_long) {
   for (uint32_t p = blockIdx.x; p < n_long; p += gridDim.x) {
     const uint32_t b = rowptr[perm[p]], n = long_ptr[p + 1] - long_ptr[p], o = long_ptr[p];
     for (uint32_t k = threadIdx.x; k < n; k += blockDim.x)
-      pack_put<WIDE>(rec_long, (size_t)o + k, pe, grp[b + k], pack_entry(pe, -1, idx[b + k]));
+      pack_put<ENC>(rec_long, (size_t)o + k, pe, grp[b + k], pack_entry(pe, -1, idx[b + k]));
   }
 }
 
@@ -108,8 +121,11 @@ __global__ __launch_bounds__(256) void k_pack_long(const uint32_t *rowptr, const
 // static LDS-bank scheduling: per step the lanes choose, one after the other in rotating priority,
 // the unplaced cell that is free in most bank sets -- identical to the host packer's loop.  Longer
 // slices (the streaming path) keep the CSR order.
+// Index records (hybrid slot area): the rows [0, nhot) of a slice hold cells of LDS-resident entries only (the
+// greedy scheduling runs over those), the rows [nhot, L) whatever is left in CSR order -- nhot = L - the
+// even-rounded largest number of cold cells of one EC, or 0 when that exceeds kColdRows.
 constexpr int kPackCells = 16;
-template <bool WIDE>
+template <int ENC>
 __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, const uint32_t *grp, const uint32_t *idx,
                                                    const uint32_t *perm, const uint32_t *slice_off, uint32_t n_long,
                                                    uint32_t n_sell, uint32_t nslices, PackEnc pe, uint32_t *rec) {
@@ -135,18 +151,28 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
     }
     if (L > (uint32_t)kPackCells) {
       for (uint32_t k = 0; k < L; ++k) {
-        if (k < mylen) pack_put<WIDE>(rec, base + (size_t)k * 64 + lane, pe, grp[b + k], pack_entry(pe, lane, idx[b + k]));
-        else pack_put<WIDE>(rec, base + (size_t)k * 64 + lane, pe, pe.n_groups + lane, pe.canon[pe.sentinel_slot]);
+        if (k < mylen) pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, grp[b + k], pack_entry(pe, lane, idx[b + k]));
+        else pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, pe.n_groups + lane, pe.canon[pe.sentinel_slot]);
       }
+      if (ENC == kEncIndex && lane == 0) pe.slice_hot[s] = 0;
       continue;
     }
+    uint32_t mycold = 0;
     for (uint32_t c = 0; c < mylen; ++c) {
       cg[c][lane] = grp[b + c];
       ce[c][lane] = pack_entry(pe, lane, idx[b + c]);
+      mycold += ce[c][lane] >= pe.n_hot;
     }
-    uint32_t taken = 0;
+    uint32_t taken = 0, nhot = L;
+    if constexpr (ENC == kEncIndex) {
+      uint32_t mc = mycold;  // largest cold count of the slice's ECs
+      for (int d = 32; d; d >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, d));
+      const uint32_t ncold = (mc + 1u) & ~1u;
+      nhot = mc > (uint32_t)kColdRows ? 0u : L - ncold;
+      if (lane == 0) pe.slice_hot[s] = (uint8_t)nhot;
+    }
     const int R = kRGroupDev[lane], C = lane >> 4, H = lane >> 5;
-    for (uint32_t k = 0; k < L; ++k) {
+    for (uint32_t k = 0; k < nhot; ++k) {
       for (int t = lane; t < 196; t += 64) reinterpret_cast<uint32_t *>(&bk)[t] = t < 192 ? 0xffffffffu : 0u;
       uint32_t pick_g = pe.n_groups + lane, pick_e = pe.canon[pe.sentinel_slot];
       __syncthreads();
@@ -157,6 +183,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
           for (uint32_t c = 0; c < mylen; ++c) {
             if (taken >> c & 1) continue;
             const uint32_t g = cg[c][lane], i = ce[c][lane];
+            if (ENC == kEncIndex && i >= pe.n_hot) continue;  // a cold cell: not in the hot segment
             int score = 0;
             if (!(at[C] >> (g & 15) & 1)) score += MSW_W_AT;                              // atomic: bank pair free
             if (rg[R][g & 15] == 0xffffffffu || rg[R][g & 15] == g) score += MSW_W_EW;   // {e,w} b128
@@ -181,7 +208,18 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
         }
         __syncthreads();
       }
-      pack_put<WIDE>(rec, base + (size_t)k * 64 + lane, pe, pick_g, pick_e);
+      pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, pick_g, pick_e);
+    }
+    // the cold segment (index records; nhot = L otherwise): what is left, in CSR order, then the lane's sentinel
+    uint32_t c = 0;
+    for (uint32_t k = nhot; k < L; ++k) {
+      while (c < mylen && (taken >> c & 1)) ++c;
+      if (c < mylen) {
+        pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, cg[c][lane], ce[c][lane]);
+        ++c;
+      } else {
+        pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, pe.n_groups + lane, pe.canon[pe.sentinel_slot]);
+      }
     }
     __syncthreads();
   }

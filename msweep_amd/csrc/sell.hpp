@@ -20,8 +20,18 @@ namespace msw {
 //     lo = 16 * entry        (byte offset of the cell's 16-byte entry in the SLOT AREA: the LUT
 //                             slots some cell refers to, compacted, followed by 8 bank-private
 //                             replicas of the hottest ones -- see upload_sell)
-//   narrow record (4 B): hi << shift | lo, with lo < 2^(shift-1) so that rec >> (shift-1) == 2*hi;
-//   wide record (8 B): {hi, lo}.
+//   narrow record (4 B, ENC 0): hi << shift | lo, with lo < 2^(shift-1) so that rec >> (shift-1) == 2*hi;
+//   wide record (8 B, ENC 1): {hi, lo};
+//   index record (4 B, ENC 2): group << shift | entry -- for slot areas that do not fit LDS beside the group
+//     vectors (thousands of used (group size, hit count) pairs: real groupings have sizes up to hundreds) and
+//     whose byte offsets would need 8-byte records: two VALU operations per gather instead of one, half the
+//     record stream.  Always goes with the HYBRID slot area: the entries are ordered by use, the first
+//     n_tab_lds of them are kept in LDS as well, and every slice of up to 16 rows is cut into a HOT segment
+//     (rows [0, nhot): every lane's cell refers to an LDS-resident entry -- the straight-line LDS code) and a
+//     COLD one (rows [nhot, len), at most kColdRows: gathered from the table in memory, issued before the hot
+//     segment is worked through and consumed after it).  The split is wave-uniform (one byte per slice,
+//     slice_hot): no per-gather branch.  Slices whose ECs hold more cold cells than kColdRows take every table
+//     entry from memory (nhot = 0), like the streaming slices of more than 16 rows.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kSentinels = 64;  // one sentinel group per lane: padding never shares an address
 
@@ -34,8 +44,11 @@ struct SellDev {
   const double *cvec;         // [E] EC multiplicities, permuted order
   const uint8_t *c8;          // [E] the same as a byte; kC8Escape = not a small integer, read cvec
   const uint32_t *area_slot;  // [n_area] LUT slot held by each 16-byte entry of the slot area
+  const uint8_t *slice_hot;   // [nslices] index records: rows of the slice's hot segment (0: all from memory)
   uint32_t nslices, n_long, n_ecs, n_groups, n_lut, n_area;
-  uint32_t shift, mask, bhi;  // record encoding (narrow: shift / lo mask; both: bhi)
+  uint32_t n_tab_lds;         // slot-area entries held in LDS (all of them, the hot head of a hybrid area, or 0)
+  uint32_t shift, mask, bhi;  // record encoding (narrow: shift / lo mask; all: bhi = LDS byte offset of e_g[0])
+  uint32_t bhiA;              // LDS byte offset of pass A's {e, w}[0] (2 * bhi but for index records)
 };
 
 constexpr uint32_t kC8Escape = 255;
@@ -48,75 +61,107 @@ constexpr uint32_t kC8Escape = 255;
 #define MSW_W_E 2
 #endif
 constexpr int kLongRow = 256;  // ECs with more cells than this take the workgroup path
+constexpr int kColdRows = 4;   // index records: rows of a slice's cold segment (beyond: the whole slice from memory)
+constexpr uint32_t kGeoHotShift = 27;  // slice geometry in LDS: rows of the hot segment above the slice offset
 
-template <bool WIDE>
+// what a sweep needs to decode a record (SGPRs)
+struct RecDec {
+  uint32_t shift, mask, bhi, bhiA;
+};
+enum { kEncNarrow = 0, kEncWide = 1, kEncIndex = 2 };
+template <int ENC>
 struct Rec;
+//   e_off : byte offset of e_g in pass B's LDS image      ew_off: of {e, w}_g in pass A's
+//   t_off : byte offset of the cell's entry in the slot area (LDS image and the tables in memory alike)
 template <>
-struct Rec<false> {
+struct Rec<kEncNarrow> {
   using T = uint32_t;
   static __device__ __forceinline__ T load(const uint32_t *p, size_t i) { return p[i]; }
-  static __device__ __forceinline__ uint32_t hi(T r, uint32_t shift) { return r >> shift; }
-  static __device__ __forceinline__ uint32_t hi2(T r, uint32_t shift) { return r >> (shift - 1); }
-  static __device__ __forceinline__ uint32_t lo(T r, uint32_t mask) { return r & mask; }
+  static __device__ __forceinline__ uint32_t e_off(T r, const RecDec &d) { return r >> d.shift; }
+  static __device__ __forceinline__ uint32_t ew_off(T r, const RecDec &d) { return r >> (d.shift - 1); }
+  static __host__ __device__ __forceinline__ uint32_t t_off(T r, const RecDec &d) { return r & d.mask; }
+  static __host__ __device__ __forceinline__ uint32_t grp(T r, const RecDec &d) { return ((r >> d.shift) - d.bhi) >> 3; }
+  static __host__ __device__ __forceinline__ T make(uint32_t g, uint32_t entry, const RecDec &d) {
+    return ((d.bhi + 8u * g) << d.shift) | (16u * entry);
+  }
 };
 template <>
-struct Rec<true> {
+struct Rec<kEncWide> {
   using T = uint2;
   static __device__ __forceinline__ T load(const uint32_t *p, size_t i) {
     return reinterpret_cast<const uint2 *>(p)[i];
   }
-  static __device__ __forceinline__ uint32_t hi(T r, uint32_t) { return r.x; }
-  static __device__ __forceinline__ uint32_t hi2(T r, uint32_t) { return r.x << 1; }
-  static __device__ __forceinline__ uint32_t lo(T r, uint32_t) { return r.y; }
+  static __device__ __forceinline__ uint32_t e_off(T r, const RecDec &) { return r.x; }
+  static __device__ __forceinline__ uint32_t ew_off(T r, const RecDec &) { return r.x << 1; }
+  static __host__ __device__ __forceinline__ uint32_t t_off(T r, const RecDec &) { return r.y; }
+  static __host__ __device__ __forceinline__ uint32_t grp(T r, const RecDec &d) { return (r.x - d.bhi) >> 3; }
+  static __host__ __device__ __forceinline__ T make(uint32_t g, uint32_t entry, const RecDec &d) {
+    return make_uint2(d.bhi + 8u * g, 16u * entry);
+  }
 };
+template <>
+struct Rec<kEncIndex> {
+  using T = uint32_t;
+  static __device__ __forceinline__ T load(const uint32_t *p, size_t i) { return p[i]; }
+  static __device__ __forceinline__ uint32_t e_off(T r, const RecDec &d) { return ((r >> d.shift) << 3) + d.bhi; }
+  static __device__ __forceinline__ uint32_t ew_off(T r, const RecDec &d) { return ((r >> d.shift) << 4) + d.bhiA; }
+  static __host__ __device__ __forceinline__ uint32_t t_off(T r, const RecDec &d) { return (r & d.mask) << 4; }
+  static __host__ __device__ __forceinline__ uint32_t grp(T r, const RecDec &d) { return r >> d.shift; }
+  static __host__ __device__ __forceinline__ T make(uint32_t g, uint32_t entry, const RecDec &d) { return (g << d.shift) | entry; }
+};
+__host__ __device__ inline RecDec rec_dec(const SellDev &S) { return RecDec{S.shift, S.mask, S.bhi, S.bhiA}; }
 // group id / LUT slot of a record (utility kernels; the sweeps never form them)
-template <bool WIDE>
-__device__ __forceinline__ uint32_t rec_grp(const SellDev &S, typename Rec<WIDE>::T r) {
-  return (Rec<WIDE>::hi(r, S.shift) - S.bhi) >> 3;
+template <int ENC>
+__device__ __forceinline__ uint32_t rec_grp(const SellDev &S, typename Rec<ENC>::T r) {
+  return Rec<ENC>::grp(r, rec_dec(S));
 }
-template <bool WIDE>
-__device__ __forceinline__ uint32_t rec_idx(const SellDev &S, typename Rec<WIDE>::T r) {
-  return S.area_slot[Rec<WIDE>::lo(r, S.mask) >> 4];
+template <int ENC>
+__device__ __forceinline__ uint32_t rec_entry(const SellDev &S, typename Rec<ENC>::T r) {
+  return Rec<ENC>::t_off(r, rec_dec(S)) >> 4;
+}
+template <int ENC>
+__device__ __forceinline__ uint32_t rec_idx(const SellDev &S, typename Rec<ENC>::T r) {
+  return S.area_slot[rec_entry<ENC>(S, r)];
 }
 
 // Visit the cells of the EC at permuted position p (utility kernels only).
-template <bool WIDE, class F>
+template <int ENC, class F>
 __device__ __forceinline__ void for_each_cell(const SellDev &S, uint32_t p, F f) {
-  using R = Rec<WIDE>;
+  using R = Rec<ENC>;
   if (p < S.n_long) {
     for (uint32_t k = S.long_ptr[p]; k < S.long_ptr[p + 1]; ++k) {
       const typename R::T r = R::load(S.rec_long, k);
-      f(rec_grp<WIDE>(S, r), rec_idx<WIDE>(S, r));
+      f(rec_grp<ENC>(S, r), rec_idx<ENC>(S, r));
     }
   } else {
     const uint32_t q = p - S.n_long, s = q >> 6, lane = q & 63;
     const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;
     for (uint32_t k = 0; k < len; ++k) {
       const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + lane);
-      const uint32_t g = rec_grp<WIDE>(S, r);
-      if (g < S.n_groups) f(g, rec_idx<WIDE>(S, r));
+      const uint32_t g = rec_grp<ENC>(S, r);
+      if (g < S.n_groups) f(g, rec_idx<ENC>(S, r));
     }
   }
 }
 
 // The cells of the EC at permuted position p, one per lane and step, for a whole wavefront:
 // f(group id, slot-area entry).  Sentinel padding is skipped.  (Rare-path code: the guarded ECs.)
-template <bool WIDE, class F>
+template <int ENC, class F>
 __device__ __forceinline__ void wave_cells(const SellDev &S, uint32_t p, uint32_t lane, F f) {
-  using R = Rec<WIDE>;
+  using R = Rec<ENC>;
   if (p < S.n_long) {
     const uint32_t k0 = S.long_ptr[p], k1 = S.long_ptr[p + 1];
     for (uint32_t k = k0 + lane; k < k1; k += 64) {
       const typename R::T r = R::load(S.rec_long, k);
-      f(rec_grp<WIDE>(S, r), R::lo(r, S.mask) >> 4);
+      f(rec_grp<ENC>(S, r), rec_entry<ENC>(S, r));
     }
   } else {
     const uint32_t q = p - S.n_long, s = q >> 6, le = q & 63;
     const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;
     for (uint32_t k = lane; k < len; k += 64) {
       const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + le);
-      const uint32_t g = rec_grp<WIDE>(S, r);
-      if (g < S.n_groups) f(g, R::lo(r, S.mask) >> 4);
+      const uint32_t g = rec_grp<ENC>(S, r);
+      if (g < S.n_groups) f(g, rec_entry<ENC>(S, r));
     }
   }
 }
@@ -143,14 +188,15 @@ struct GuardDev {
   uint32_t cap, words;
 };
 
-// LDS image of the sweeps (byte offsets; bhi = sell_bhi()):
-//   [0, 16 * n_area)                    slot area: 16-byte per-slot entries of the pass (tlds)
-//   pass A: [2 * bhi, 2 * bhi + 16 * Gp)  {e_g, wc_g}                         (glds)
+// LDS image of the sweeps (byte offsets; bhi = sell_bhi(n_tab_lds)):
+//   [0, 16 * n_tab_lds)                 slot area: 16-byte per-slot entries of the pass -- all of them (tlds), the
+//                                       hot head of a hybrid area (index records), or none
+//   pass A: [bhiA, bhiA + 16 * Gp)      {e_g, wc_g}   (glds; bhiA = 2 * bhi, index records: bhi)
 //   pass B: [bhi, bhi + 8 * Gp) e_g,  column sums pass_acc_off() bytes behind      (glds);
 //           with too many groups for both (GMODE 3) the column sums alone, e_g gathered from memory
 //   then 32 doubles of reduction scratch and 8 KB of slice geometry.   Gp = G + kSentinels
-__host__ __device__ inline uint32_t sell_bhi(bool tlds, uint32_t n_area) {
-  return tlds ? ((16u * n_area + 255u) & ~255u) : 0u;
+__host__ __device__ inline uint32_t sell_bhi(uint32_t n_tab_lds) {
+  return n_tab_lds ? ((16u * n_tab_lds + 255u) & ~255u) : 0u;
 }
 constexpr uint32_t kGeoStride = 66 * 8;  // bytes of slice geometry per wavefront
 constexpr uint32_t kAccFixed = 65528;  // largest 8-byte-aligned ds immediate offset
@@ -165,18 +211,18 @@ struct RangeB {
   uint32_t g0, n;  // groups [g0, g0 + n) of this run
   int first;       // the run that also delivers the per-EC ELBO terms
 };
-__host__ __device__ inline size_t pass_scratch_off(int gmode, bool tlds, uint32_t G, uint32_t n_area,
-                                                   bool passA) {
-  const size_t bhi = sell_bhi(tlds, n_area), Gp = (size_t)G + kSentinels;
+// index = index records (pass A's group entries right behind the table instead of at twice pass B's offset)
+__host__ __device__ inline size_t pass_scratch_off(int gmode, uint32_t n_tab_lds, uint32_t G, bool passA, bool index) {
+  const size_t bhi = sell_bhi(n_tab_lds), Gp = (size_t)G + kSentinels;
   if (gmode == 0 || (passA && gmode >= 3)) return bhi;  // pass A of modes 3, 4 gathers {e, w} from memory
-  if (passA) return 2 * bhi + 16 * Gp;
+  if (passA) return (index ? bhi : 2 * bhi) + 16 * Gp;
   if (gmode == 4) return bhi + 8 * (size_t)kRangeGroups;
   return bhi + pass_acc_off(gmode, G) + 8 * Gp;
 }
-__host__ __device__ inline size_t pass_lds_bytes(int gmode, bool tlds, uint32_t G, uint32_t n_area,
-                                                 bool passA) {
+constexpr size_t kPassTailBytes = 32 * sizeof(double) + 16 * kGeoStride;  // scratch + per-wave slice geometry
+__host__ __device__ inline size_t pass_lds_bytes(int gmode, uint32_t n_tab_lds, uint32_t G, bool passA, bool index) {
   // + per-wave slice geometry (sweep_kernels.hpp SliceStream): 16 waves x (64 + 2) pairs
-  return pass_scratch_off(gmode, tlds, G, n_area, passA) + 32 * sizeof(double) + 16 * kGeoStride;
+  return pass_scratch_off(gmode, n_tab_lds, G, passA, index) + kPassTailBytes;
 }
 
 }  // namespace msw

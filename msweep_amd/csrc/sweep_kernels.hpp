@@ -67,31 +67,50 @@ __device__ __forceinline__ double uniform_d(double v) {
 
 // One slice held in registers (<= kRegCells cells per EC): records, geometry and -- pass B -- the
 // EC's multiplicity.
-template <bool WIDE>
+template <int ENC>
 struct SliceBuf {
-  typename Rec<WIDE>::T r[kRegCells];
-  uint32_t sl, o, len;
+  typename Rec<ENC>::T r[kRegCells];
+  // index records (sell.hpp): the rows of the slice's cold segment; r then holds the hot rows only
+  typename Rec<ENC>::T rc[ENC == kEncIndex ? kColdRows : 1];
+  uint32_t sl, o, len, nhot;
   uint32_t c8;  // byte image of the EC's multiplicity (sell.hpp)
 };
 
 // Issue the loads of one slice (<= kRegCells cells per EC, even count) into registers.
-template <bool WIDE>
+template <int ENC>
 __device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uint32_t len,
-                                           typename Rec<WIDE>::T (&r)[kRegCells]) {
+                                           typename Rec<ENC>::T (&r)[kRegCells]) {
 #pragma unroll
   for (int k = 0; k < kRegCells; k += 2) {
     if ((uint32_t)k < len) {
-      r[k] = Rec<WIDE>::load(rec, base + (size_t)k * 64);
-      r[k + 1] = Rec<WIDE>::load(rec, base + (size_t)(k + 1) * 64);
+      r[k] = Rec<ENC>::load(rec, base + (size_t)k * 64);
+      r[k + 1] = Rec<ENC>::load(rec, base + (size_t)(k + 1) * 64);
     }
   }
 }
+// index records: rows [0, nhot) into r, the cold rows [nhot, len) -- at most kColdRows, or the packer has set
+// nhot = 0 and the whole slice is taken from memory -- into rc
+__device__ __forceinline__ void load_slice_split(const uint32_t *rec, size_t base, uint32_t len, uint32_t nhot,
+                                                 uint32_t (&r)[kRegCells], uint32_t (&rc)[kColdRows]) {
+  const uint32_t ncold = len - nhot;
+  if (ncold <= (uint32_t)kColdRows) {
+    load_slice<kEncIndex>(rec, base, nhot, r);
+#pragma unroll
+    for (int j = 0; j < kColdRows; j += 2) {
+      if ((uint32_t)j < ncold) {
+        rc[j] = rec[base + (size_t)(nhot + j) * 64];
+        rc[j + 1] = rec[base + (size_t)(nhot + j + 1) * 64];
+      }
+    }
+  } else {
+    load_slice<kEncIndex>(rec, base, len, r);
+  }
+}
 
-// a record that contributes nothing: group offset hi (a sentinel group: e = 0), slot entry 0
-template <bool WIDE>
-__device__ __forceinline__ typename Rec<WIDE>::T null_record(uint32_t hi, uint32_t shift) {
-  if constexpr (WIDE) return make_uint2(hi, 0u);
-  else return hi << shift;
+// a record that contributes nothing: sentinel group g (e = 0), slot entry 0
+template <int ENC>
+__device__ __forceinline__ typename Rec<ENC>::T null_record(uint32_t g, const RecDec &d) {
+  return Rec<ENC>::make(g, 0u, d);
 }
 
 // s_waitcnt vmcnt(0), leaving the other counters alone (gfx9 layout: vmcnt = imm[3:0] | imm[15:14] << 4)
@@ -107,7 +126,7 @@ __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70);
 // measured: no faster -- the stream already runs at the achievable HBM rate -- and it needs a fixed
 // number of loads per slice plus dummy fetches to keep the compiler's path-insensitive vmcnt
 // accounting exact.
-template <bool WIDE, bool REVERSE>
+template <int ENC, bool REVERSE>
 struct SliceStream {
   const SellDev &S;
   uint32_t s_first, nw, n_mine, lane;
@@ -133,6 +152,8 @@ struct SliceStream {
     if (i < n_mine) {
       const uint32_t sl = slice_at(i);
       pend = make_uint2(S.slice_off[sl], S.slice_off[sl + 1]);
+      // index records: the rows of the slice's hot segment ride above its offset (< 2^27: checked at upload)
+      if constexpr (ENC == kEncIndex) pend.x |= (uint32_t)S.slice_hot[sl] << kGeoHotShift;
     }
   }
   __device__ __forceinline__ void commit_offs() {
@@ -144,14 +165,22 @@ struct SliceStream {
   }
   // j = position inside the current 64-slice chunk; j >= n_chunk fetches an empty slice
   template <class Issue>
-  __device__ __forceinline__ void fetch(uint32_t base, uint32_t j, SliceBuf<WIDE> &b, Issue &issue) {
+  __device__ __forceinline__ void fetch(uint32_t base, uint32_t j, SliceBuf<ENC> &b, Issue &issue) {
     typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const v2u_t lds_cu2_t;
     const v2u_t oe = *(lds_cu2_t *)(size_t)(geo + j * 8);
     b.sl = slice_at(base + j);
-    b.o = uniform(oe.x);
-    b.len = uniform(oe.y) - b.o;
-    if (b.len <= (uint32_t)kRegCells) load_slice<WIDE>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r);
+    if constexpr (ENC == kEncIndex) {
+      const uint32_t ox = uniform(oe.x);
+      b.o = ox & ((1u << kGeoHotShift) - 1u);
+      b.nhot = ox >> kGeoHotShift;
+      b.len = uniform(oe.y) - b.o;
+      if (b.len <= (uint32_t)kRegCells) load_slice_split(S.rec, (size_t)b.o * 64 + lane, b.len, b.nhot, b.r, b.rc);
+    } else {
+      b.o = uniform(oe.x);
+      b.len = uniform(oe.y) - b.o;
+      if (b.len <= (uint32_t)kRegCells) load_slice<ENC>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r);
+    }
     issue(b);
   }
   // issue(buf): further loads of a slice; process(buf): its arithmetic; chunk_end(): every 64 slices
@@ -162,7 +191,7 @@ struct SliceStream {
       if (base) gather_offs(base >> 6);
       commit_offs();
       const uint32_t n_chunk = n_mine > base ? (n_mine - base < 64u ? n_mine - base : 64u) : 0u;
-      SliceBuf<WIDE> A = {}, B = {};
+      SliceBuf<ENC> A = {}, B = {};
       uint32_t j = 0;
       fetch(base, 0, A, issue);
       for (;;) {
@@ -223,42 +252,50 @@ __device__ __forceinline__ void cellA(AccA &c, const double p0, const double e, 
   c.t2 = fma(e, fma(xD, D, w * fma(2.0, xD, wx)), c.t2);
 }
 
-template <bool WIDE, bool GLDS, bool TLDS>
+// ENC = kEncIndex (index records): the hybrid slot area -- TLDS is then false by convention, the LDS image
+// holds the hot head of the area (S.n_tab_lds entries) and the whole area lives in memory (sell.hpp).
+template <int ENC, bool GLDS, bool TLDS>
 __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellDev S,
                                                        const double2 *ew_g, const double2 *tabA_g,
                                                        double *partA, GuardDev GD) {
   extern __shared__ __align__(16) unsigned char smem[];
-  using R = Rec<WIDE>;
+  using R = Rec<ENC>;
   using RT = typename R::T;
+  constexpr bool HYB = ENC == kEncIndex;
+  static_assert(!(HYB && TLDS), "index records go with the hybrid slot area");
+  constexpr bool TL = TLDS || HYB;  // the LDS image starts with (a part of) the slot table
+  const RecDec D = rec_dec(S);
+  const uint32_t n_tab = S.n_tab_lds;
   // a pending re-evaluation skips pass A; the test sits behind the LDS fill so that the fill's loads
   // do not wait for this one (one memory round trip less at the head of every sweep)
   const int skip = sc->done | sc->reset_pending;
   const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t G = S.n_groups, n_lut = S.n_area, Gp = G + kSentinels;  // n_lut: entries of the slot area
-  const uint32_t shift = S.shift, mask = S.mask, bhi2 = 2 * S.bhi;
-  double *sh = reinterpret_cast<double *>(smem + pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true));
+  const uint32_t G = S.n_groups, Gp = G + kSentinels;
+  const uint32_t bhiA = S.bhiA;
+  const uint32_t scratch_off = (uint32_t)pass_scratch_off(GLDS ? 1 : 0, n_tab, G, true, HYB);
+  double *sh = reinterpret_cast<double *>(smem + scratch_off);
   // slice geometry of this wave: the gather is in flight while the LDS image is filled
-  SliceStream<WIDE, false> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
+  SliceStream<ENC, false> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
                               gridDim.x * (kPassThreads / 64), (uint32_t)lane,
-                              (uint32_t)pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true) + 256u +
-                                  uniform(tid >> 6) * kGeoStride);
-  if (TLDS) {
+                              scratch_off + 256u + uniform(tid >> 6) * kGeoStride);
+  if (TL) {
     double2 *t = reinterpret_cast<double2 *>(smem);
-    for (uint32_t i = tid; i < n_lut; i += kPassThreads) t[i] = tabA_g[i];
+    for (uint32_t i = tid; i < n_tab; i += kPassThreads) t[i] = tabA_g[i];
   }
   if (GLDS) {
-    double2 *t = reinterpret_cast<double2 *>(smem + bhi2);
+    double2 *t = reinterpret_cast<double2 *>(smem + bhiA);
     for (uint32_t g = tid; g < Gp; g += kPassThreads) t[g] = ew_g[g];
   }
   // global fallbacks see the same byte offsets as the LDS image
-  const unsigned char *ew_b = reinterpret_cast<const unsigned char *>(ew_g) - bhi2;
+  const unsigned char *ew_b = reinterpret_cast<const unsigned char *>(ew_g) - bhiA;
   const unsigned char *xt_b = reinterpret_cast<const unsigned char *>(tabA_g);
-  auto EW_ = [&](RT r) -> double2 { return tab16<GLDS>(ew_b, R::hi2(r, shift)); };
-  auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
+  auto EW_ = [&](RT r) -> double2 { return tab16<GLDS>(ew_b, R::ew_off(r, D)); };
+  auto XT_ = [&](RT r) -> double2 { return tab16<TL>(xt_b, R::t_off(r, D)); };      // hybrid: hot entries only
+  auto XTg_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::t_off(r, D)); };   // any entry (hybrid: from memory)
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, b1 = p0 * uniform_d(sc->V1c), b2 = p0 * uniform_d(sc->V2c);
   const double gthr = fmax(zbase * kGuardRatio, 2.2250738585072014e-308);  // (Z = 0 is set aside too: reported, not divided by)  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
-  const uint32_t gcnt_off = (uint32_t)pass_scratch_off(GLDS ? 1 : 0, TLDS, G, n_lut, true) + 128u;
+  const uint32_t gcnt_off = scratch_off + 128u;
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
   auto defer = [&](uint32_t p) {
     const uint32_t i = __hip_atomic_fetch_add((lds_u32_t *)(size_t)gcnt_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -271,13 +308,14 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
-  auto issue = [&](SliceBuf<WIDE> &) {};
-  auto process = [&](SliceBuf<WIDE> &sb) {
+  auto issue = [&](SliceBuf<ENC> &) {};
+  auto process = [&](SliceBuf<ENC> &sb) {
     const uint32_t len = sb.len;
     AccA c = {0.0, 0.0, 0.0};
     // straight-line code per cell count (wave-uniform and even): all LDS gathers of a batch can be
     // in flight together instead of one scalar-branched pair at a time
-    auto fixed = [&](RT(&b)[kRegCells], auto LEN) {
+    // (ANY: the cells may refer to any entry of a hybrid slot area -- gathered from memory)
+    auto fixed = [&](RT(&b)[kRegCells], auto LEN, auto ANY) {
       constexpr int L = decltype(LEN)::value;
       constexpr int B = MSW_PASSA_BATCH;  // cells gathered together (2 x ds_read_b128 each)
 #pragma unroll
@@ -287,7 +325,8 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
         for (int k = 0; k < B; ++k) {
           if (k0 + k < L) {
             ewv[k] = EW_(b[k0 + k]);
-            xtv[k] = XT_(b[k0 + k]);
+            if constexpr (decltype(ANY)::value) xtv[k] = XTg_(b[k0 + k]);
+            else xtv[k] = XT_(b[k0 + k]);
           }
         }
 #pragma unroll
@@ -298,18 +337,57 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
     auto cells = [&](RT(&b)[kRegCells], uint32_t n) {
       switch (n) {
         case 0: break;
-        case 2: fixed(b, std::integral_constant<int, 2>{}); break;
-        case 4: fixed(b, std::integral_constant<int, 4>{}); break;
-        case 6: fixed(b, std::integral_constant<int, 6>{}); break;
-        case 8: fixed(b, std::integral_constant<int, 8>{}); break;
-        case 10: fixed(b, std::integral_constant<int, 10>{}); break;
-        case 12: fixed(b, std::integral_constant<int, 12>{}); break;
-        case 14: fixed(b, std::integral_constant<int, 14>{}); break;
-        default: fixed(b, std::integral_constant<int, 16>{}); break;
+        case 2: fixed(b, std::integral_constant<int, 2>{}, std::false_type{}); break;
+        case 4: fixed(b, std::integral_constant<int, 4>{}, std::false_type{}); break;
+        case 6: fixed(b, std::integral_constant<int, 6>{}, std::false_type{}); break;
+        case 8: fixed(b, std::integral_constant<int, 8>{}, std::false_type{}); break;
+        case 10: fixed(b, std::integral_constant<int, 10>{}, std::false_type{}); break;
+        case 12: fixed(b, std::integral_constant<int, 12>{}, std::false_type{}); break;
+        case 14: fixed(b, std::integral_constant<int, 14>{}, std::false_type{}); break;
+        default: fixed(b, std::integral_constant<int, 16>{}, std::false_type{}); break;
+      }
+    };
+    // a slice from memory, pair by pair (rare shapes only: no second copy of the per-count code)
+    auto pairs_any = [&](RT(&b)[kRegCells], uint32_t n) {
+#pragma unroll
+      for (int k = 0; k < kRegCells; k += 2) {
+        if ((uint32_t)k < n) {
+          const double2 a0 = EW_(b[k]), a1 = EW_(b[k + 1]);
+          const double2 x0 = XTg_(b[k]), x1 = XTg_(b[k + 1]);
+          cellA(c, p0, a0.x, a0.y, x0.x, x0.y);
+          cellA(c, p0, a1.x, a1.y, x1.x, x1.y);
+        }
       }
     };
     if (len <= (uint32_t)kRegCells) {
-      cells(sb.r, len);
+      if constexpr (HYB) {
+        const uint32_t nhot = sb.nhot, ncold = len - nhot;
+        if (ncold <= (uint32_t)kColdRows) {
+          // the cold rows' table entries come from memory: issued first, consumed after the hot rows
+          double2 cew[kColdRows], cxt[kColdRows];
+#pragma unroll
+          for (int j = 0; j < kColdRows; j += 2) {
+            if ((uint32_t)j < ncold) {
+              cxt[j] = XTg_(sb.rc[j]);
+              cxt[j + 1] = XTg_(sb.rc[j + 1]);
+              cew[j] = EW_(sb.rc[j]);
+              cew[j + 1] = EW_(sb.rc[j + 1]);
+            }
+          }
+          cells(sb.r, nhot);
+#pragma unroll
+          for (int j = 0; j < kColdRows; j += 2) {
+            if ((uint32_t)j < ncold) {
+              cellA(c, p0, cew[j].x, cew[j].y, cxt[j].x, cxt[j].y);
+              cellA(c, p0, cew[j + 1].x, cew[j + 1].y, cxt[j + 1].x, cxt[j + 1].y);
+            }
+          }
+        } else {
+          pairs_any(sb.r, len);
+        }
+      } else {
+        cells(sb.r, len);
+      }
     } else {
       // more cells per EC than the registers hold (the stream has not fetched this slice): chunks of
       // kRegCells records through the same registers and the same straight-line code; the other
@@ -320,22 +398,14 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
       RT t[kRegCells];
       uint32_t k0 = 0;
       for (; k0 + (uint32_t)kRegCells <= len; k0 += kRegCells) {
-        load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, kRegCells, t);
-        fixed(t, std::integral_constant<int, kRegCells>{});
+        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, kRegCells, t);
+        fixed(t, std::integral_constant<int, kRegCells>{}, std::true_type{});
       }
       if (k0 < len) {  // the last chunk: pair by pair (a second copy of the per-count code costs the
                        // short path 5 % through its sheer size)
         const uint32_t n = len - k0;
-        load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, n, t);
-#pragma unroll
-        for (int k = 0; k < kRegCells; k += 2) {
-          if ((uint32_t)k < n) {
-            const double2 a0 = EW_(t[k]), a1 = EW_(t[k + 1]);
-            const double2 x0 = XT_(t[k]), x1 = XT_(t[k + 1]);
-            cellA(c, p0, a0.x, a0.y, x0.x, x0.y);
-            cellA(c, p0, a1.x, a1.y, x1.x, x1.y);
-          }
-        }
+        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t);
+        pairs_any(t, n);
       }
     }
     if (sb.sl * 64 + lane < n_sell) {
@@ -354,12 +424,12 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   // distinct, so the gathers of a step never meet on an address, and the three sums are wave
   // reductions (no barrier)
   // (lanes past the end take a record of their own sentinel group)
-  const RT null_rec = null_record<WIDE>(S.bhi + 8u * (G + (uint32_t)lane), shift);
+  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D);
   // The wavefront's ECs are one sequence of steps of LS * 64 cells; the records of the NEXT step (of
   // this EC or of the next one) are always in flight while a step is processed -- a step costs a
   // full memory round trip otherwise, and a wavefront walks some sixty of them one after the other.
   {
-    constexpr int LS = WIDE ? 4 : kLongStep;  // 8-byte records: twice the registers
+    constexpr int LS = ENC == kEncWide ? 4 : kLongStep;  // 8-byte records: twice the registers
     auto load_long = [&](uint32_t kb, uint32_t k1, RT(&dst)[LS]) {
 #pragma unroll
       for (int u = 0; u < LS; ++u) {
@@ -389,7 +459,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
         if (kb + 64u * q < k1) {  // wave-uniform: quads past the end are skipped
           double2 a0[4], x0[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) a0[u] = EW_(cur[q + u]), x0[u] = XT_(cur[q + u]);
+          for (int u = 0; u < 4; ++u) a0[u] = EW_(cur[q + u]), x0[u] = XTg_(cur[q + u]);
 #pragma unroll
           for (int u = 0; u < 4; ++u) cellA(c, p0, a0[u].x, a0[u].y, x0[u].x, x0[u].y);
         }
@@ -423,7 +493,7 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
     for (uint32_t i = wv; i < n_guard; i += nwv) {
       const uint32_t p = GD.list[(size_t)blockIdx.x * GD.cap + i];
       double z = 0.0, t1 = 0.0, t2 = 0.0;
-      wave_cells<WIDE>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
+      wave_cells<ENC>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
         const double T = GD.lut_area[ent], x = exp(a * (T - tref)), sv = oma * (T - logzi) + ew_g[g].y;
         const double q = ew_g[g].x * x;
         atomicOr(&bits[g >> 5], 1u << (g & 31));
@@ -475,28 +545,33 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
 // 0 = e_g / column sums in global memory; 1 = in LDS, column sums right behind e_g;
 // 2 = in LDS, column sums at the fixed distance kAccFixed (an instruction immediate: one VALU
 // operation less per scattered cell; needs 8 * Gp <= kAccFixed).
-template <bool WIDE, int GMODE, bool TLDS>
+template <int ENC, int GMODE, bool TLDS>
 __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
                                                        const double2 *tabB_g, double *partAcc,
                                                        double *partS, double *accGlobal, RangeB rg, GuardDev GD) {
   extern __shared__ __align__(16) unsigned char smem[];
-  using R = Rec<WIDE>;
+  using R = Rec<ENC>;
   using RT = typename R::T;
+  constexpr bool HYB = ENC == kEncIndex;  // index records + hybrid slot area (see k_passA)
+  static_assert(!(HYB && TLDS), "index records go with the hybrid slot area");
+  constexpr bool TL = TLDS || HYB;
+  const RecDec D = rec_dec(S);
+  const uint32_t n_tab = S.n_tab_lds;
   const int skip = sc->done;  // tested behind the LDS fill (see pass A)
   const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t G = S.n_groups, n_lut = S.n_area, Gp = G + kSentinels;  // n_lut: entries of the slot area
-  const uint32_t shift = S.shift, mask = S.mask, bhi = S.bhi;
+  const uint32_t G = S.n_groups, Gp = G + kSentinels;
+  const uint32_t bhi = S.bhi;
   constexpr bool GLDS = GMODE == 1 || GMODE == 2;  // e_g in LDS
   constexpr bool ALDS = GMODE > 0;                  // column sums in LDS
   const uint32_t acc_off = pass_acc_off(GMODE, G);
-  double *sh = reinterpret_cast<double *>(smem + pass_scratch_off(GMODE, TLDS, G, n_lut, false));
-  SliceStream<WIDE, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (kPassThreadsB / 64) + (tid >> 6)),
+  const uint32_t scratch_off = (uint32_t)pass_scratch_off(GMODE, n_tab, G, false, HYB);
+  double *sh = reinterpret_cast<double *>(smem + scratch_off);
+  SliceStream<ENC, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (kPassThreadsB / 64) + (tid >> 6)),
                               gridDim.x * (kPassThreadsB / 64), (uint32_t)lane,
-                              (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 256u +
-                                  uniform(tid >> 6) * kGeoStride);
-  if (TLDS) {
+                              scratch_off + 256u + uniform(tid >> 6) * kGeoStride);
+  if (TL) {
     double2 *t = reinterpret_cast<double2 *>(smem);
-    for (uint32_t i = tid; i < n_lut; i += kPassThreadsB) t[i] = tabB_g[i];
+    for (uint32_t i = tid; i < n_tab; i += kPassThreadsB) t[i] = tabB_g[i];
   }
   if (ALDS) {
     double *el = reinterpret_cast<double *>(smem + bhi), *al = reinterpret_cast<double *>(smem + bhi + acc_off);
@@ -509,15 +584,16 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   const unsigned char *e_b = reinterpret_cast<const unsigned char *>(e_g) - bhi;
   unsigned char *acc_b = reinterpret_cast<unsigned char *>(accGlobal) - bhi;
   const unsigned char *xt_b = reinterpret_cast<const unsigned char *>(tabB_g);
-  auto E_ = [&](RT r) -> double { return tab8<GLDS>(e_b, R::hi(r, shift)); };
-  auto XT_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::lo(r, mask)); };
-  auto XM_ = [&](RT r) -> double { return tab8<TLDS>(xt_b, R::lo(r, mask)); };
+  auto E_ = [&](RT r) -> double { return tab8<GLDS>(e_b, R::e_off(r, D)); };
+  auto XT_ = [&](RT r) -> double2 { return tab16<TL>(xt_b, R::t_off(r, D)); };      // hybrid: hot entries only
+  auto XTg_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::t_off(r, D)); };   // any entry (hybrid: from memory)
+  auto XMg_ = [&](RT r) -> double { return tab8<TLDS>(xt_b, R::t_off(r, D)); };
   typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
   // one column-sum update: v = the value to add (fp64 build), or its fixed-point image (kFx)
   auto addACC = [&](RT r, auto v) {
     using V = decltype(v);
     using LT = typename std::conditional<std::is_same<V, double>::value, lds_d_t, lds_u64_t>::type;
-    const uint32_t off = R::hi(r, shift);
+    const uint32_t off = R::e_off(r, D);
     if constexpr (GMODE == 2)
       __hip_atomic_fetch_add((LT *)(size_t)(off + kAccFixed), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if constexpr (GMODE == 1)
@@ -551,7 +627,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   const int fxe = (int)uniform((uint32_t)fx_expbits(sc->fx_shift));
   const double fxs = uniform_d(sc->fx_scale), fxb = ldexp(uniform_d(sc->xb), 1 - (int)uniform((uint32_t)sc->fx_shift));
   const double gthr = fmax(zbase * kGuardRatio, 2.2250738585072014e-308);  // (Z = 0 is set aside too: reported, not divided by)  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
-  const uint32_t gcnt_off = (uint32_t)pass_scratch_off(GMODE, TLDS, G, n_lut, false) + 128u;
+  const uint32_t gcnt_off = scratch_off + 128u;
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
   auto defer = [&](uint32_t p) {
     const uint32_t i = __hip_atomic_fetch_add((lds_u32_t *)(size_t)gcnt_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -571,12 +647,12 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
-  auto issue = [&](SliceBuf<WIDE> &sb) {
+  auto issue = [&](SliceBuf<ENC> &sb) {
     const uint32_t q = sb.sl * 64 + lane;
     const uint32_t cj = S.c8[S.n_long + (q < n_sell ? q : 0u)];
     sb.c8 = q < n_sell ? cj : 0u;
   };
-  auto process = [&](SliceBuf<WIDE> &sb) {
+  auto process = [&](SliceBuf<ENC> &sb) {
     const uint32_t o = sb.o, len = sb.len;
     double c = (double)sb.c8;
     // not a small integer: rare.  A wave-uniform branch with the wait for its load INSIDE: loads return in
@@ -592,9 +668,10 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     // cells stays in registers for the scatter, any others are gathered a second time (with 16
     // wavefronts per workgroup all 16 would push the kernel into scratch, and a scratch reload
     // drains the record prefetch: hence 12 wavefronts, common.hpp).
-    constexpr int KEEPN = WIDE ? 4 : MSW_B_KEEPN;  // 8-byte records take twice the registers
+    constexpr int KEEPN = ENC == kEncWide ? 4 : MSW_B_KEEPN;  // 8-byte records take twice the registers
     double xv[KEEPN > 0 ? KEEPN : 1];
-    auto fixed = [&](RT(&b)[kRegCells], auto LEN, auto KEEP) {
+    // (ANY: the cells may refer to any entry of a hybrid slot area -- gathered from memory)
+    auto fixed = [&](RT(&b)[kRegCells], auto LEN, auto KEEP, auto ANY) {
       constexpr int L = decltype(LEN)::value;
       constexpr bool KP = decltype(KEEP)::value;
       constexpr int B = MSW_PASSB_BATCH;  // cells whose gathers are issued together
@@ -606,7 +683,8 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         for (int k = 0; k < B; ++k) {
           if (k0 + k < L) {
             ev[k] = E_(b[k0 + k]);
-            xt[k] = XT_(b[k0 + k]);
+            if constexpr (decltype(ANY)::value) xt[k] = XTg_(b[k0 + k]);
+            else xt[k] = XT_(b[k0 + k]);
           }
         }
 #pragma unroll
@@ -624,14 +702,29 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     auto cells = [&](RT(&b)[kRegCells], uint32_t n, auto KEEP) {
       switch (n) {
         case 0: break;
-        case 2: fixed(b, std::integral_constant<int, 2>{}, KEEP); break;
-        case 4: fixed(b, std::integral_constant<int, 4>{}, KEEP); break;
-        case 6: fixed(b, std::integral_constant<int, 6>{}, KEEP); break;
-        case 8: fixed(b, std::integral_constant<int, 8>{}, KEEP); break;
-        case 10: fixed(b, std::integral_constant<int, 10>{}, KEEP); break;
-        case 12: fixed(b, std::integral_constant<int, 12>{}, KEEP); break;
-        case 14: fixed(b, std::integral_constant<int, 14>{}, KEEP); break;
-        default: fixed(b, std::integral_constant<int, 16>{}, KEEP); break;
+        case 2: fixed(b, std::integral_constant<int, 2>{}, KEEP, std::false_type{}); break;
+        case 4: fixed(b, std::integral_constant<int, 4>{}, KEEP, std::false_type{}); break;
+        case 6: fixed(b, std::integral_constant<int, 6>{}, KEEP, std::false_type{}); break;
+        case 8: fixed(b, std::integral_constant<int, 8>{}, KEEP, std::false_type{}); break;
+        case 10: fixed(b, std::integral_constant<int, 10>{}, KEEP, std::false_type{}); break;
+        case 12: fixed(b, std::integral_constant<int, 12>{}, KEEP, std::false_type{}); break;
+        case 14: fixed(b, std::integral_constant<int, 14>{}, KEEP, std::false_type{}); break;
+        default: fixed(b, std::integral_constant<int, 16>{}, KEEP, std::false_type{}); break;
+      }
+    };
+    // row sums of a slice from memory, pair by pair (rare shapes only: no second copy of the per-count code);
+    // keeps nothing: the scatter gathers again
+    auto pairs_any = [&](RT(&b)[kRegCells], uint32_t n) {
+#pragma unroll
+      for (int k = 0; k < kRegCells; k += 2) {
+        if ((uint32_t)k < n) {
+          const double e0 = E_(b[k]), e1 = E_(b[k + 1]);
+          const double2 t0 = XTg_(b[k]), t1 = XTg_(b[k + 1]);
+          zs = fma(e0, t0.x, zs);
+          hs = fma(e0, t0.y, hs);
+          zs = fma(e1, t1.x, zs);
+          hs = fma(e1, t1.y, hs);
+        }
       }
     };
     // scatter of up to kRegCells cells held in b; padding records point at the lane's own sentinel
@@ -645,8 +738,8 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         if ((uint32_t)k < n) {
           double x0, x1;
           if constexpr (kFx) {
-            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : fx_factor(E_(b[k]), fxe) * XM_(b[k]);
-            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : fx_factor(E_(b[k + 1]), fxe) * XM_(b[k + 1]);
+            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : fx_factor(E_(b[k]), fxe) * XMg_(b[k]);
+            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : fx_factor(E_(b[k + 1]), fxe) * XMg_(b[k + 1]);
             if constexpr (WA) {
               addFXwide(b[k], rj, x0);
               addFXwide(b[k + 1], rj, x1);
@@ -655,8 +748,8 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
               addFX(b[k + 1], rj, x1);
             }
           } else {
-            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : XM_(b[k]);
-            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : XM_(b[k + 1]);
+            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : XMg_(b[k]);
+            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : XMg_(b[k + 1]);
             addACC(b[k], rj * x0);
             addACC(b[k + 1], rj * x1);
           }
@@ -664,7 +757,62 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
       }
     };
     if (len <= (uint32_t)kRegCells) {
-      cells(sb.r, len, std::true_type{});
+      // index records: the slice is cut into a hot segment (rows in sb.r, LDS table) and a cold one of at most
+      // kColdRows rows (sb.rc, table entries from memory: issued first, consumed after the hot rows) -- or,
+      // with more cold cells than that, taken from memory as a whole (all rows in sb.r)
+      [[maybe_unused]] double xc[kColdRows];
+      uint32_t nsc = len, ncold = 0;  // rows the scatter finds in sb.r / in sb.rc
+      bool kept = true;
+      if constexpr (HYB) {
+        const uint32_t nhot = sb.nhot;
+        if (len - nhot <= (uint32_t)kColdRows) {
+          ncold = len - nhot;
+          nsc = nhot;
+          double ce[kColdRows];
+          double2 cx[kColdRows];
+#pragma unroll
+          for (int j = 0; j < kColdRows; j += 2) {
+            if ((uint32_t)j < ncold) {
+              cx[j] = XTg_(sb.rc[j]);
+              cx[j + 1] = XTg_(sb.rc[j + 1]);
+              ce[j] = E_(sb.rc[j]);
+              ce[j + 1] = E_(sb.rc[j + 1]);
+            }
+          }
+          cells(sb.r, nhot, std::true_type{});
+#pragma unroll
+          for (int j = 0; j < kColdRows; ++j) {
+            if ((uint32_t)(j & ~1) < ncold) {
+              zs = fma(ce[j], cx[j].x, zs);
+              hs = fma(ce[j], cx[j].y, hs);
+              xc[j] = kFx ? fx_factor(ce[j], fxe) * cx[j].x : cx[j].x;
+            }
+          }
+        } else {
+          pairs_any(sb.r, len);
+          kept = false;
+        }
+      } else {
+        cells(sb.r, len, std::true_type{});
+      }
+      // scatter of the slice: the rows held in sb.r, then the cold rows
+      auto scatter_all = [&](double rs, auto WIDE_ADD) {
+        if (kept) scatter(sb.r, nsc, rs, std::true_type{}, WIDE_ADD);
+        else scatter(sb.r, nsc, rs, std::false_type{}, WIDE_ADD);
+        if constexpr (HYB) {
+#pragma unroll
+          for (int j = 0; j < kColdRows; ++j) {
+            if ((uint32_t)(j & ~1) < ncold) {
+              if constexpr (kFx) {
+                if constexpr (decltype(WIDE_ADD)::value) addFXwide(sb.rc[j], rs, xc[j]);
+                else addFX(sb.rc[j], rs, xc[j]);
+              } else {
+                addACC(sb.rc[j], rs * xc[j]);
+              }
+            }
+          }
+        }
+      };
       if (c != 0.0 && !(zbase + zs >= gthr)) {
         defer(S.n_long + sb.sl * 64 + lane);
       } else if (c != 0.0) {
@@ -674,10 +822,10 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         s_W += rj;
         if constexpr (kFx) {
           const double rs = rj * fxs;
-          if (rs * fmax(Z + zbase, fxb) < 0x1p51) scatter(sb.r, len, rs, std::true_type{}, std::false_type{});
-          else scatter(sb.r, len, rs, std::true_type{}, std::true_type{});
+          if (rs * fmax(Z + zbase, fxb) < 0x1p51) scatter_all(rs, std::false_type{});
+          else scatter_all(rs, std::true_type{});
         } else {
-          scatter(sb.r, len, rj, std::true_type{}, std::false_type{});
+          scatter_all(rj, std::false_type{});
         }
         // sum c log Z after the scatter (its registers are free by now).  For the multiplicities
         // 1..15 the logarithm is deferred: the mantissas are multiplied up per lane and one log per 64
@@ -718,23 +866,13 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
       RT t[kRegCells];
       uint32_t k0 = 0;
       for (; k0 + (uint32_t)kRegCells <= len; k0 += kRegCells) {
-        load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, kRegCells, t);
-        fixed(t, std::integral_constant<int, kRegCells>{}, std::false_type{});
+        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, kRegCells, t);
+        fixed(t, std::integral_constant<int, kRegCells>{}, std::false_type{}, std::true_type{});
       }
       if (k0 < len) {
         const uint32_t n = len - k0;
-        load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, n, t);
-#pragma unroll
-        for (int k = 0; k < kRegCells; k += 2) {
-          if ((uint32_t)k < n) {
-            const double e0 = E_(t[k]), e1 = E_(t[k + 1]);
-            const double2 t0 = XT_(t[k]), t1 = XT_(t[k + 1]);
-            zs = fma(e0, t0.x, zs);
-            hs = fma(e0, t0.y, hs);
-            zs = fma(e1, t1.x, zs);
-            hs = fma(e1, t1.y, hs);
-          }
-        }
+        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t);
+        pairs_any(t, n);
       }
       if (c != 0.0 && !(zbase + zs >= gthr)) {
         defer(S.n_long + sb.sl * 64 + lane);
@@ -748,7 +886,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
         const bool narrow = !kFx || rs * fmax(Z + zbase, fxb) < 0x1p51;
         for (k0 = 0; k0 < len; k0 += kRegCells) {
           const uint32_t n = len - k0 < (uint32_t)kRegCells ? len - k0 : (uint32_t)kRegCells;
-          load_slice<WIDE>(S.rec, base + (size_t)k0 * 64, n, t);
+          load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t);
           if (narrow) scatter(t, n, rs, std::false_type{}, std::false_type{});
           else scatter(t, n, rs, std::false_type{}, std::true_type{});
         }
@@ -757,7 +895,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   };
   stream.run(issue, process, flush_logs);
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step (see pass A)
-  const RT null_rec = null_record<WIDE>(bhi + 8u * (G + (uint32_t)lane), shift);
+  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D);
   // The current EC's first kLongStep * 64 records stay in registers for the scatter (one reload less: 10 % on
   // ECs of 300..1000 cells), and the next EC's first ones are fetched before the current one is
   // processed.  (The same prefetch changes nothing in pass A, which keeps the plain loop: the
@@ -793,7 +931,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
             double eg[4];
             double2 t[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) eg[u] = E_(rc[q + u]), t[u] = XT_(rc[q + u]);
+            for (int u = 0; u < 4; ++u) eg[u] = E_(rc[q + u]), t[u] = XTg_(rc[q + u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               zs = fma(eg[u], t[u].x, zs);
@@ -827,7 +965,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
             if (kb + 64u * q < c1) {
               double xm[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) xm[u] = kFx ? fx_factor(E_(rc[q + u]), fxe) * XM_(rc[q + u]) : XM_(rc[q + u]);
+              for (int u = 0; u < 4; ++u) xm[u] = kFx ? fx_factor(E_(rc[q + u]), fxe) * XMg_(rc[q + u]) : XMg_(rc[q + u]);
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 if constexpr (kFx) {
@@ -872,7 +1010,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
       const uint32_t p = GD.list[(size_t)blockIdx.x * GD.cap + i];
       const double c = S.cvec[p];
       double z = 0.0, h = 0.0;
-      wave_cells<WIDE>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
+      wave_cells<ENC>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
         const double T = GD.lut_area[ent], q = e_g[g] * exp(a * (T - tref));
         atomicOr(&bits[g >> 5], 1u << (g & 31));
         z += q;
@@ -895,7 +1033,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
           s_clogZ += c * log(Z);
           s_rH += rj * H;
         }
-        wave_cells<WIDE>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
+        wave_cells<ENC>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
           add_share(g, e_g[g] * rj * exp(a * (GD.lut_area[ent] - tref)));
         });
         for (uint32_t w0 = lane; w0 < GD.words; w0 += 64) {

@@ -11,8 +11,14 @@ def _group_sizes(rng, G, lam=9.0):
     return (1 + rng.poisson(lam, G)).astype(np.uint64)
 
 
+def diverse_group_sizes(rng, G, max_size=400):
+    """Group sizes as real groupings have them: log-normal, 1 .. max_size sequences per group (thousands of used
+    (group size, hit count) pairs: the slot tables of the sweeps no longer fit LDS)."""
+    return np.minimum(1 + rng.lognormal(3.0, 1.2, G).astype(np.int64), max_size).astype(np.uint64)
+
+
 def make_csr_problem(n_reads, n_groups, seed=2, max_other=15, dirichlet=0.05, theta_support=None,
-                     p_src=0.65, p_other=0.1, chunk=1_000_000):
+                     p_src=0.65, p_other=0.1, chunk=1_000_000, group_sizes=None):
     """cfg3 / cfg5 style problem: reads drawn from theta ~ Dirichlet, each read hits its
     source group with count ~ max(1, Binomial(n_g, p_src)) plus 0..max_other other groups with
     count ~ max(1, Binomial(n_g, p_other)); identical reads are collapsed into ECs.
@@ -22,7 +28,7 @@ def make_csr_problem(n_reads, n_groups, seed=2, max_other=15, dirichlet=0.05, th
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     G = int(n_groups)
-    sizes = _group_sizes(rng, G)
+    sizes = _group_sizes(rng, G) if group_sizes is None else group_sizes(rng, G)   # group_sizes: callable(rng, G)
     sup = None
     if theta_support is not None and theta_support < G:
         # cfg5: reads (source AND spurious hits) only touch `theta_support` groups, so that

@@ -129,6 +129,32 @@ def test_cfg3_csr_10M_x_5k_lockstep(gpu_core, oracle_mt, cfg3):
         np.testing.assert_array_equal(again["theta"], res["theta"])
 
 
+def test_diverse_group_sizes_10M_x_5k_lockstep(gpu_core, oracle_mt):
+    """cfg3's reads and groups with the group sizes of real groupings (log-normal, up to 400 sequences: 12 910 used
+    (size, count) pairs, 207 KB of slot table per sweep): the hybrid slot area -- index records, the most-used
+    entries in LDS, cold segments from memory -- at full size, every iteration against the structured oracle."""
+    G = 5000
+    p = synth.make_csr_problem(10_000_000, G, seed=2, group_sizes=synth.diverse_group_sizes)
+    lut = precalc_lls(p["group_sizes"])
+    p["lut"], p["lutidx"] = lut, lutidx_of(p, lut)
+    alpha0 = np.ones(G)
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    li = gpu_core.layout_info()
+    print(li)
+    assert li["index_records"] == 1 and li["record_bytes"] == 4 and 0 < li["slot_entries_in_lds"] < li["slot_entries"]
+    assert 0 < li["rows_from_memory"] < li["rows"] // 10
+    gpu_core.set_trace_theta(1024)
+    res = gpu_core.solve(lik.log_counts(), alpha0)
+    assert res["iters"] < 1000
+    tr = gpu_core.trace(res["iters"], with_theta=True)
+    gpu_core.set_trace_theta(0)
+    ref_tr = oracle_csr_trace(oracle_mt, p, lik.log_counts(), alpha0, res["iters"] + 2)
+    check_against_oracle("diverse sizes", res, tr, ref_tr)
+    again = gpu_core.solve(lik.log_counts(), alpha0)
+    assert again["iters"] == res["iters"] and again["bound"] == res["bound"]
+    np.testing.assert_array_equal(again["theta"], res["theta"])
+
+
 def test_cfg4_bootstrap_10M_x_5k(gpu_core, oracle_mt, cfg3):
     """cfg4 on one GPU: msw_core_bootstrap over the resident cfg3 likelihood.  The resampled counts of
     every replicate are bit-exact with libstdc++'s mt19937_64 + discrete_distribution (the types

@@ -1,0 +1,58 @@
+"""GPU, needs >= 2 devices (skips cleanly on a one-GPU box): the two multi-GPU modes over REAL RCCL ranks --
+one fresh process per GPU (tests/_rank_worker.py), the library's own communicator (msw_comm_create_rccl),
+checked against the single-GPU answers computed here.
+  * msw_core_bootstrap_dist (src/mSWEEP.cpp:496-518 over the GPUs): the gathered B x G table is the same on
+    every rank and BIT-IDENTICAL to the single-GPU run (every replicate is a whole solve on one GPU; only the
+    placement changes), ragged blocks and fewer replicates than ranks included;
+  * the EC-sharded solve: every rank returns the same bits; against the single-GPU solve the iteration count
+    and theta at the north-star tolerance."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from msweep_amd import synth
+from msweep_amd.likelihood import from_grouped_counts
+from test_gpu_rcg import assert_theta
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def n_devices():
+    import torch
+    return torch.cuda.device_count()     # does not initialise the GPU
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_ranks_bootstrap_and_sharded_solve(gpu_core, tmp_path, world):
+    if n_devices() < world:
+        pytest.skip(f"needs {world} GPUs, {n_devices()} visible")
+    d = str(tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rank_worker.py"), str(r), str(world), d],
+                              env=env) for r in range(world)]
+    try:
+        rcs = [p.wait(timeout=600) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert rcs == [0] * world, rcs
+    out = [np.load(os.path.join(d, f"out_{r}.npz")) for r in range(world)]
+    p = synth.make_csr_problem(60000, 200, seed=41, max_other=8)
+    G, B = 200, 2 * world + 1
+    lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    w = p["ec_counts"].astype(np.uint32)
+    single_b, iters_b = gpu_core.bootstrap(w, 42, int(w.sum()), 0, B, np.ones(G))
+    single = gpu_core.solve(lik.log_counts(), np.ones(G), tol=1e-6, max_iters=20000)
+    for r in range(world):
+        np.testing.assert_array_equal(out[r]["theta_b"], single_b)
+        np.testing.assert_array_equal(out[r]["iters_b"], iters_b)
+        np.testing.assert_array_equal(out[r]["one"], single_b[:1])
+        np.testing.assert_array_equal(out[r]["theta"], out[0]["theta"])
+        assert int(out[r]["iters"]) == int(out[0]["iters"]) and float(out[r]["bound"]) == float(out[0]["bound"])
+    assert int(out[0]["iters"]) == single["iters"]
+    assert_theta(out[0]["theta"], single["theta"])
