@@ -98,7 +98,7 @@ int msw_core_shape(msw_handle h, size_t *n_groups, size_t *n_ecs, size_t *nnz);
 /* How the resident CSR-of-ECs likelihood is laid out for the sweeps: reporting only (bench.py, the
  * timing tools); no reference counterpart. */
 typedef struct msw_layout_info {
-  int32_t record_bytes;        /* 4 or 8 bytes per listed cell */
+  int32_t record_bytes;        /* 4 or 8 bytes per listed cell; 12: value records (the cell's log-likelihood inline) */
   int32_t index_records;       /* 1: (group, entry) index records + hybrid slot area; 0: byte-offset records */
   int32_t groups_in_lds;       /* the per-group vectors of both sweeps live in LDS */
   int32_t table_in_lds;        /* the whole slot area lives in LDS */

@@ -42,13 +42,13 @@ __global__ __launch_bounds__(256) void k_gamma_block(SellDev S, const uint32_t *
     double lse = 0.0;
     if (normalise) {
       double zs = 0.0;
-      for_each_cell<ENC>(S, p, [&](uint32_t g, uint32_t i) { zs += exp(u[g] - M) * (exp(a * (lut[i] - tref)) - p0); });
+      for_each_cell<ENC>(S, p, [&](uint32_t g, double T) { zs += exp(u[g] - M) * (exp(a * (T - tref)) - p0); });
       double Z = p0 * U + zs;
       if (!(Z >= p0 * U * kGuardRatio)) {  // guarded EC (sell.hpp): every group visited instead
         Z = 0.0;
         for (uint32_t g = 0; g < S.n_groups; ++g) {
           double xg = p0;
-          for_each_cell<ENC>(S, p, [&](uint32_t gg, uint32_t i) { if (gg == g) xg = exp(a * (lut[i] - tref)); });
+          for_each_cell<ENC>(S, p, [&](uint32_t gg, double T) { if (gg == g) xg = exp(a * (T - tref)); });
           Z += exp(u[g] - M) * xg;
         }
       }
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_gamma_block(SellDev S, const uint32_t *
     }
     double *col = out + (j - e0);
     for (uint32_t g = 0; g < S.n_groups; ++g) col[(size_t)g * ld] = a * logzi + u[g] - lse;
-    for_each_cell<ENC>(S, p, [&](uint32_t g, uint32_t i) { col[(size_t)g * ld] = a * lut[i] + u[g] - lse; });
+    for_each_cell<ENC>(S, p, [&](uint32_t g, double T) { col[(size_t)g * ld] = a * T + u[g] - lse; });
   }
 }
 

@@ -82,7 +82,7 @@ struct msw_core {
   TabDev tabs() const { return TabDev{tabA.p, tabB.p}; }
   DevBuf<double> partA, partS, partAcc, partC, partR, totS;
   // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
-  size_t lds_attr[2][30] = {};  // dynamic-LDS limit already granted per sweep instantiation
+  size_t lds_attr[2][40] = {};  // dynamic-LDS limit already granted per sweep instantiation
   msw_comm *comm = nullptr;
   bool in_collective = false;  // a solve / sharded build is under way: a failure now strands the peers (guarded())
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
@@ -206,6 +206,7 @@ SellDev sell_view(msw_core *h) {
   S.bhiA = h->enc_bhiA;
   S.n_tab_lds = h->n_tab_lds;
   S.slice_hot = h->slice_hot.p;
+  S.lut_area = h->lut_area.p;
   return S;
 }
 
@@ -380,7 +381,7 @@ void launch_passA_t(msw_core *h) {
   const size_t lds = pass_lds_bytes(GL ? 1 : 0, h->n_tab_lds, h->G, true, ENC == kEncIndex);
   auto k = k_passA<ENC, GL, TL>;
   prepare_sweep(k, lds, h->lds_attr[0][ENC * 4 + (GL ? 2 : 0) + (TL ? 1 : 0)]);
-  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreads), lds, h->stream, h->sc.p, sell_view(h),
+  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(pass_threads_A<ENC>()), lds, h->stream, h->sc.p, sell_view(h),
                      h->ew.p, h->tabA.p, h->partA.p, h->guard_view());
 }
 template <int ENC, int GM, bool TL>
@@ -390,12 +391,12 @@ void launch_passB_t(msw_core *h) {
   prepare_sweep(k, lds, h->lds_attr[1][ENC * 10 + 2 * GM + (TL ? 1 : 0)]);
   if (GM == 4) {  // one run per range of groups; the first also delivers the ELBO terms
     for (uint32_t g0 = 0; g0 < h->G; g0 += kRangeGroups)
-      hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreadsB), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
+      hipLaunchKernelGGL(k, dim3(h->nblk), dim3(pass_threads_B<ENC>()), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
                          h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p,
                          RangeB{g0, std::min<uint32_t>(kRangeGroups, h->G - g0), g0 == 0 ? 1 : 0}, h->guard_view());
     return;
   }
-  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(kPassThreadsB), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
+  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(pass_threads_B<ENC>()), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
                      h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p, RangeB{0, 0, 1}, h->guard_view());
 }
 
@@ -413,6 +414,8 @@ void launch_passB_t(msw_core *h) {
       case 7: fn<kEncWide, true, true>(__VA_ARGS__); break;                          \
       case 8: fn<kEncIndex, false, false>(__VA_ARGS__); break;                       \
       case 10: fn<kEncIndex, true, false>(__VA_ARGS__); break;                       \
+      case 12: fn<kEncValue, false, false>(__VA_ARGS__); break;                      \
+      case 14: fn<kEncValue, true, false>(__VA_ARGS__); break;                       \
       default: throw Fail("internal: no sweep for this layout");                     \
     }                                                                                \
   } while (0)
@@ -445,6 +448,11 @@ void launch_passB_t(msw_core *h) {
       case 24: fn<kEncIndex, 2, false>(__VA_ARGS__); break;                          \
       case 26: fn<kEncIndex, 3, false>(__VA_ARGS__); break;                          \
       case 28: fn<kEncIndex, 4, false>(__VA_ARGS__); break;                          \
+      case 30: fn<kEncValue, 0, false>(__VA_ARGS__); break;                          \
+      case 32: fn<kEncValue, 1, false>(__VA_ARGS__); break;                          \
+      case 34: fn<kEncValue, 2, false>(__VA_ARGS__); break;                          \
+      case 36: fn<kEncValue, 3, false>(__VA_ARGS__); break;                          \
+      case 38: fn<kEncValue, 4, false>(__VA_ARGS__); break;                          \
       default: throw Fail("internal: no sweep for this layout");                     \
     }                                                                                \
   } while (0)
@@ -712,7 +720,7 @@ void collect_timing(msw_core *h) {
     }
   }
   h->timing.iters = (uint64_t)h->sc_host->iter;
-  const uint64_t recsz = h->wide() ? 8 : 4;
+  const uint64_t recsz = h->enc == kEncValue ? 12 : (h->wide() ? 8 : 4);
   if (h->flavor == 0) {
     // algorithmic bytes: every real cell record once + the per-EC count vector in
     // pass B; SELL padding, slice offsets and the L2-served second read of pass B are not counted
@@ -858,7 +866,7 @@ int msw_core_layout_info(msw_handle h, msw_layout_info *out) {
     if (!out) throw Fail("null out");
     if (h->flavor != 0) throw Fail("msw_core_layout_info: no CSR-of-ECs likelihood resident");
     msw_layout_info li = {};
-    li.record_bytes = h->wide() ? 8 : 4;
+    li.record_bytes = h->enc == kEncValue ? 12 : (h->wide() ? 8 : 4);
     li.index_records = h->hybrid() ? 1 : 0;
     li.groups_in_lds = h->glds ? 1 : 0;
     li.table_in_lds = h->tlds ? 1 : 0;
@@ -874,7 +882,7 @@ int msw_core_layout_info(msw_handle h, msw_layout_info *out) {
       std::vector<uint8_t> hot(std::max<uint32_t>(h->nslices, 1));
       MSW_HIP(hipMemcpy(hot.data(), h->slice_hot.p, hot.size(), hipMemcpyDeviceToHost));
       for (uint32_t s2 = 0; s2 < h->nslices; ++s2) li.rows_from_memory += (off[s2 + 1] - off[s2]) - hot[s2];
-    } else if (!h->tlds) {
+    } else if (!h->tlds && h->enc != kEncValue) {
       li.rows_from_memory = li.rows;
     }
     *out = li;

@@ -94,15 +94,24 @@ struct PackEnc {
   RecDec dec;
   uint32_t n_hot;            // hybrid area (index records): entries below it are LDS-resident
   uint8_t *slice_hot;        // hybrid area: rows of every slice's hot segment (written by k_pack_slices)
+  const double *cell_val;    // value records: the cells' log-likelihoods, indexed like idx (canon, hot_rank unused)
+  double tnull;              // value records: what padding carries (the background value)
 };
+constexpr uint32_t kPackPad = UINT32_MAX;  // "entry" of a padding record
 __device__ __forceinline__ uint32_t pack_entry(const PackEnc &pe, int lane, uint32_t idx) {
+  if (pe.cell_val) return idx;  // value records: the cell's position in cell_val
   const uint32_t j = pe.hot_rank[idx];
   if (lane < 0 || j == UINT32_MAX) return pe.canon[idx];
   return pe.rep_base + (j >> 1) * 16 + 2 * (kRPosDev[lane] >> 1) + (j & 1);
 }
 template <int ENC>
 __device__ __forceinline__ void pack_put(uint32_t *dst, size_t slot, const PackEnc &pe, uint32_t g, uint32_t entry) {
-  reinterpret_cast<typename Rec<ENC>::T *>(dst)[slot] = Rec<ENC>::make(g, entry, pe.dec);
+  if constexpr (ENC == kEncValue) {
+    Rec<ENC>::store(dst, slot, ValRec{8u * g, entry == kPackPad ? pe.tnull : pe.cell_val[entry]});
+  } else {
+    if (entry == kPackPad) entry = pe.canon[pe.sentinel_slot];
+    reinterpret_cast<typename Rec<ENC>::T *>(dst)[slot] = Rec<ENC>::make(g, entry, pe.dec);
+  }
 }
 
 // records of the long ECs (plain CSR, any lane reads them: compact slot entries)
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
     if (L > (uint32_t)kPackCells) {
       for (uint32_t k = 0; k < L; ++k) {
         if (k < mylen) pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, grp[b + k], pack_entry(pe, lane, idx[b + k]));
-        else pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, pe.n_groups + lane, pe.canon[pe.sentinel_slot]);
+        else pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, pe.n_groups + lane, kPackPad);
       }
       if (ENC == kEncIndex && lane == 0) pe.slice_hot[s] = 0;
       continue;
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
     const int R = kRGroupDev[lane], C = lane >> 4, H = lane >> 5;
     for (uint32_t k = 0; k < nhot; ++k) {
       for (int t = lane; t < 196; t += 64) reinterpret_cast<uint32_t *>(&bk)[t] = t < 192 ? 0xffffffffu : 0u;
-      uint32_t pick_g = pe.n_groups + lane, pick_e = pe.canon[pe.sentinel_slot];
+      uint32_t pick_g = pe.n_groups + lane, pick_e = kPackPad;
       __syncthreads();
       for (int li = 0; li < 64; ++li) {
         const int l = (li + (int)k * 7) & 63;  // rotate the priority
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
             int score = 0;
             if (!(at[C] >> (g & 15) & 1)) score += MSW_W_AT;                              // atomic: bank pair free
             if (rg[R][g & 15] == 0xffffffffu || rg[R][g & 15] == g) score += MSW_W_EW;   // {e,w} b128
-            if (rs[R][i & 15] == 0xffffffffu || rs[R][i & 15] == i) score += MSW_W_XT;   // slot entry b128
+            if (ENC == kEncValue || rs[R][i & 15] == 0xffffffffu || rs[R][i & 15] == i) score += MSW_W_XT;   // slot entry b128
             if (hg[H][g & 31] == 0xffffffffu || hg[H][g & 31] == g) score += MSW_W_E;   // e_g b64
             if (score > best_score) {
               best_score = score;
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
         pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, cg[c][lane], ce[c][lane]);
         ++c;
       } else {
-        pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, pe.n_groups + lane, pe.canon[pe.sentinel_slot]);
+        pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, pe.n_groups + lane, kPackPad);
       }
     }
     __syncthreads();

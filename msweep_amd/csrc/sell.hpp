@@ -32,6 +32,11 @@ namespace msw {
 //     segment is worked through and consumed after it).  The split is wave-uniform (one byte per slice,
 //     slice_hot): no per-gather branch.  Slices whose ECs hold more cold cells than kColdRows take every table
 //     entry from memory (nhot = 0), like the streaming slices of more than 16 rows.
+//   value record (12 B, ENC 3): {hi, T} -- the cell's log-likelihood itself instead of a table position, for
+//     matrices whose listed values are (nearly) all different (a dense `logl` with continuous values handed to
+//     msw_core_set_dense_logl: one table slot per cell would cost 16 bytes gathered + 40 bytes rebuilt per cell
+//     and iteration); the sweeps form exp(a (T - tref)) per cell.  Stored row by row: 64 hi words, then the
+//     row's 64 doubles (kValRowWords dwords per row of 64 cells).
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kSentinels = 64;  // one sentinel group per lane: padding never shares an address
 
@@ -49,6 +54,7 @@ struct SellDev {
   uint32_t n_tab_lds;         // slot-area entries held in LDS (all of them, the hot head of a hybrid area, or 0)
   uint32_t shift, mask, bhi;  // record encoding (narrow: shift / lo mask; all: bhi = LDS byte offset of e_g[0])
   uint32_t bhiA;              // LDS byte offset of pass A's {e, w}[0] (2 * bhi but for index records)
+  const double *lut_area;     // table value of every slot-area entry (utility kernels: the value of a cell)
 };
 
 constexpr uint32_t kC8Escape = 255;
@@ -68,7 +74,12 @@ constexpr uint32_t kGeoHotShift = 27;  // slice geometry in LDS: rows of the hot
 struct RecDec {
   uint32_t shift, mask, bhi, bhiA;
 };
-enum { kEncNarrow = 0, kEncWide = 1, kEncIndex = 2 };
+enum { kEncNarrow = 0, kEncWide = 1, kEncIndex = 2, kEncValue = 3 };
+constexpr uint32_t kValRowWords = 192;  // value records: dwords per row of 64 cells (64 hi words + 64 doubles)
+struct ValRec {
+  uint32_t hi;  // byte offset of e_g (8 * group: no table in front of the group vectors)
+  double t;     // the cell's log-likelihood
+};
 template <int ENC>
 struct Rec;
 //   e_off : byte offset of e_g in pass B's LDS image      ew_off: of {e, w}_g in pass A's
@@ -109,7 +120,33 @@ struct Rec<kEncIndex> {
   static __host__ __device__ __forceinline__ uint32_t grp(T r, const RecDec &d) { return r >> d.shift; }
   static __host__ __device__ __forceinline__ T make(uint32_t g, uint32_t entry, const RecDec &d) { return (g << d.shift) | entry; }
 };
+template <>
+struct Rec<kEncValue> {
+  using T = ValRec;
+  static __device__ __forceinline__ T load(const uint32_t *p, size_t i) {
+    const size_t w = (i >> 6) * kValRowWords;
+    return ValRec{p[w + (i & 63)], reinterpret_cast<const double *>(p + w + 64)[i & 63]};
+  }
+  static __device__ __forceinline__ void store(uint32_t *p, size_t i, T r) {
+    const size_t w = (i >> 6) * kValRowWords;
+    p[w + (i & 63)] = r.hi;
+    reinterpret_cast<double *>(p + w + 64)[i & 63] = r.t;
+  }
+  static __device__ __forceinline__ uint32_t e_off(T r, const RecDec &) { return r.hi; }
+  static __device__ __forceinline__ uint32_t ew_off(T r, const RecDec &) { return r.hi << 1; }
+  static __host__ __device__ __forceinline__ uint32_t grp(T r, const RecDec &) { return r.hi >> 3; }
+};
+// dwords of a record array of n cells
+__host__ __device__ inline size_t rec_words(int enc, size_t n) {
+  return enc == kEncValue ? ((n + 63) / 64) * kValRowWords : (enc == kEncWide ? 2 * n : n);
+}
 __host__ __device__ inline RecDec rec_dec(const SellDev &S) { return RecDec{S.shift, S.mask, S.bhi, S.bhiA}; }
+// the log-likelihood of a record's cell (utility kernels)
+template <int ENC>
+__device__ __forceinline__ double rec_value(const SellDev &S, typename Rec<ENC>::T r) {
+  if constexpr (ENC == kEncValue) return r.t;
+  else return S.lut_area[Rec<ENC>::t_off(r, rec_dec(S)) >> 4];
+}
 // group id / LUT slot of a record (utility kernels; the sweeps never form them)
 template <int ENC>
 __device__ __forceinline__ uint32_t rec_grp(const SellDev &S, typename Rec<ENC>::T r) {
@@ -124,14 +161,14 @@ __device__ __forceinline__ uint32_t rec_idx(const SellDev &S, typename Rec<ENC>:
   return S.area_slot[rec_entry<ENC>(S, r)];
 }
 
-// Visit the cells of the EC at permuted position p (utility kernels only).
+// Visit the cells of the EC at permuted position p (utility kernels only): f(group id, log-likelihood).
 template <int ENC, class F>
 __device__ __forceinline__ void for_each_cell(const SellDev &S, uint32_t p, F f) {
   using R = Rec<ENC>;
   if (p < S.n_long) {
     for (uint32_t k = S.long_ptr[p]; k < S.long_ptr[p + 1]; ++k) {
       const typename R::T r = R::load(S.rec_long, k);
-      f(rec_grp<ENC>(S, r), rec_idx<ENC>(S, r));
+      f(rec_grp<ENC>(S, r), rec_value<ENC>(S, r));
     }
   } else {
     const uint32_t q = p - S.n_long, s = q >> 6, lane = q & 63;
@@ -139,13 +176,13 @@ __device__ __forceinline__ void for_each_cell(const SellDev &S, uint32_t p, F f)
     for (uint32_t k = 0; k < len; ++k) {
       const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + lane);
       const uint32_t g = rec_grp<ENC>(S, r);
-      if (g < S.n_groups) f(g, rec_idx<ENC>(S, r));
+      if (g < S.n_groups) f(g, rec_value<ENC>(S, r));
     }
   }
 }
 
 // The cells of the EC at permuted position p, one per lane and step, for a whole wavefront:
-// f(group id, slot-area entry).  Sentinel padding is skipped.  (Rare-path code: the guarded ECs.)
+// f(group id, log-likelihood).  Sentinel padding is skipped.  (Rare-path code: the guarded ECs.)
 template <int ENC, class F>
 __device__ __forceinline__ void wave_cells(const SellDev &S, uint32_t p, uint32_t lane, F f) {
   using R = Rec<ENC>;
@@ -153,7 +190,7 @@ __device__ __forceinline__ void wave_cells(const SellDev &S, uint32_t p, uint32_
     const uint32_t k0 = S.long_ptr[p], k1 = S.long_ptr[p + 1];
     for (uint32_t k = k0 + lane; k < k1; k += 64) {
       const typename R::T r = R::load(S.rec_long, k);
-      f(rec_grp<ENC>(S, r), rec_entry<ENC>(S, r));
+      f(rec_grp<ENC>(S, r), rec_value<ENC>(S, r));
     }
   } else {
     const uint32_t q = p - S.n_long, s = q >> 6, le = q & 63;
@@ -161,7 +198,7 @@ __device__ __forceinline__ void wave_cells(const SellDev &S, uint32_t p, uint32_
     for (uint32_t k = lane; k < len; k += 64) {
       const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + le);
       const uint32_t g = rec_grp<ENC>(S, r);
-      if (g < S.n_groups) f(g, rec_entry<ENC>(S, r));
+      if (g < S.n_groups) f(g, rec_value<ENC>(S, r));
     }
   }
 }

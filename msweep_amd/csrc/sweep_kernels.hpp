@@ -107,11 +107,22 @@ __device__ __forceinline__ void load_slice_split(const uint32_t *rec, size_t bas
   }
 }
 
-// a record that contributes nothing: sentinel group g (e = 0), slot entry 0
+// a record that contributes nothing: sentinel group g (e = 0), slot entry 0 (value records: the background
+// value, which lies inside the range the pass scales its exponentials by)
 template <int ENC>
-__device__ __forceinline__ typename Rec<ENC>::T null_record(uint32_t g, const RecDec &d) {
-  return Rec<ENC>::make(g, 0u, d);
+__device__ __forceinline__ typename Rec<ENC>::T null_record(uint32_t g, const RecDec &d, double tnull) {
+  if constexpr (ENC == kEncValue) return ValRec{8u * g, tnull};
+  else return Rec<ENC>::make(g, 0u, d);
 }
+// threads per workgroup of the sweeps: value records take three registers per cell (96 for the two slice
+// buffers) -- 8 wavefronts, 256 registers per lane, in both sweeps
+#ifndef MSW_VAL_THREADS
+#define MSW_VAL_THREADS 512
+#endif
+template <int ENC>
+constexpr int pass_threads_A() { return ENC == kEncValue ? MSW_VAL_THREADS : kPassThreads; }
+template <int ENC>
+constexpr int pass_threads_B() { return ENC == kEncValue ? MSW_VAL_THREADS : kPassThreadsB; }
 
 // s_waitcnt vmcnt(0), leaving the other counters alone (gfx9 layout: vmcnt = imm[3:0] | imm[15:14] << 4)
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
@@ -255,14 +266,16 @@ __device__ __forceinline__ void cellA(AccA &c, const double p0, const double e, 
 // ENC = kEncIndex (index records): the hybrid slot area -- TLDS is then false by convention, the LDS image
 // holds the hot head of the area (S.n_tab_lds entries) and the whole area lives in memory (sell.hpp).
 template <int ENC, bool GLDS, bool TLDS>
-__global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellDev S,
+__global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *sc, SellDev S,
                                                        const double2 *ew_g, const double2 *tabA_g,
                                                        double *partA, GuardDev GD) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<ENC>;
   using RT = typename R::T;
   constexpr bool HYB = ENC == kEncIndex;
-  static_assert(!(HYB && TLDS), "index records go with the hybrid slot area");
+  constexpr bool VAL = ENC == kEncValue;  // value records: no table, exp per cell
+  constexpr int NT = pass_threads_A<ENC>();
+  static_assert(!((HYB || VAL) && TLDS), "index records go with the hybrid slot area, value records have no table");
   constexpr bool TL = TLDS || HYB;  // the LDS image starts with (a part of) the slot table
   const RecDec D = rec_dec(S);
   const uint32_t n_tab = S.n_tab_lds;
@@ -275,23 +288,32 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   const uint32_t scratch_off = (uint32_t)pass_scratch_off(GLDS ? 1 : 0, n_tab, G, true, HYB);
   double *sh = reinterpret_cast<double *>(smem + scratch_off);
   // slice geometry of this wave: the gather is in flight while the LDS image is filled
-  SliceStream<ENC, false> stream(S, uniform(blockIdx.x * (kPassThreads / 64) + (tid >> 6)),
-                              gridDim.x * (kPassThreads / 64), (uint32_t)lane,
+  SliceStream<ENC, false> stream(S, uniform(blockIdx.x * (NT / 64) + (tid >> 6)),
+                              gridDim.x * (NT / 64), (uint32_t)lane,
                               scratch_off + 256u + uniform(tid >> 6) * kGeoStride);
   if (TL) {
     double2 *t = reinterpret_cast<double2 *>(smem);
-    for (uint32_t i = tid; i < n_tab; i += kPassThreads) t[i] = tabA_g[i];
+    for (uint32_t i = tid; i < n_tab; i += NT) t[i] = tabA_g[i];
   }
   if (GLDS) {
     double2 *t = reinterpret_cast<double2 *>(smem + bhiA);
-    for (uint32_t g = tid; g < Gp; g += kPassThreads) t[g] = ew_g[g];
+    for (uint32_t g = tid; g < Gp; g += NT) t[g] = ew_g[g];
   }
   // global fallbacks see the same byte offsets as the LDS image
   const unsigned char *ew_b = reinterpret_cast<const unsigned char *>(ew_g) - bhiA;
   const unsigned char *xt_b = reinterpret_cast<const unsigned char *>(tabA_g);
   auto EW_ = [&](RT r) -> double2 { return tab16<GLDS>(ew_b, R::ew_off(r, D)); };
-  auto XT_ = [&](RT r) -> double2 { return tab16<TL>(xt_b, R::t_off(r, D)); };      // hybrid: hot entries only
-  auto XTg_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::t_off(r, D)); };   // any entry (hybrid: from memory)
+  // the cell's {x, D} = {exp(a (T - tref)), (1 - a)(T - log zi)}: from the slot table, or -- value records -- formed here
+  [[maybe_unused]] const double va = uniform_d(sc->a), vtref = uniform_d(sc->tref), vlogzi = uniform_d(sc->logzi);
+  [[maybe_unused]] const double voma = 1.0 - va;
+  auto XTg_ = [&](RT r) -> double2 {   // any entry (hybrid: from memory)
+    if constexpr (VAL) return make_double2(exp(va * (r.t - vtref)), voma * (r.t - vlogzi));
+    else return tab16<TLDS>(xt_b, R::t_off(r, D));
+  };
+  auto XT_ = [&](RT r) -> double2 {    // hybrid: hot entries only
+    if constexpr (VAL) return XTg_(r);
+    else return tab16<TL>(xt_b, R::t_off(r, D));
+  };
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, b1 = p0 * uniform_d(sc->V1c), b2 = p0 * uniform_d(sc->V2c);
   const double gthr = fmax(zbase * kGuardRatio, 2.2250738585072014e-308);  // (Z = 0 is set aside too: reported, not divided by)  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
@@ -424,12 +446,12 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   // distinct, so the gathers of a step never meet on an address, and the three sums are wave
   // reductions (no barrier)
   // (lanes past the end take a record of their own sentinel group)
-  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D);
+  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
   // The wavefront's ECs are one sequence of steps of LS * 64 cells; the records of the NEXT step (of
   // this EC or of the next one) are always in flight while a step is processed -- a step costs a
   // full memory round trip otherwise, and a wavefront walks some sixty of them one after the other.
   {
-    constexpr int LS = ENC == kEncWide ? 4 : kLongStep;  // 8-byte records: twice the registers
+    constexpr int LS = ENC == kEncWide || VAL ? 4 : kLongStep;  // 8- and 12-byte records: more registers
     auto load_long = [&](uint32_t kb, uint32_t k1, RT(&dst)[LS]) {
 #pragma unroll
       for (int u = 0; u < LS; ++u) {
@@ -487,14 +509,14 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
   __syncthreads();
   const uint32_t n_guard = min(*(lds_u32_t *)(size_t)gcnt_off, GD.cap);
   if (n_guard) {
-    const uint32_t wv = uniform(tid >> 6), nwv = kPassThreads / 64;
+    const uint32_t wv = uniform(tid >> 6), nwv = NT / 64;
     uint32_t *bits = GD.bits + (size_t)(blockIdx.x * 16 + wv) * GD.words;
     const double a = uniform_d(sc->a), oma = 1.0 - a, logzi = uniform_d(sc->logzi), tref = uniform_d(sc->tref);
     for (uint32_t i = wv; i < n_guard; i += nwv) {
       const uint32_t p = GD.list[(size_t)blockIdx.x * GD.cap + i];
       double z = 0.0, t1 = 0.0, t2 = 0.0;
-      wave_cells<ENC>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
-        const double T = GD.lut_area[ent], x = exp(a * (T - tref)), sv = oma * (T - logzi) + ew_g[g].y;
+      wave_cells<ENC>(S, p, (uint32_t)lane, [&](uint32_t g, double T) {
+        const double x = exp(a * (T - tref)), sv = oma * (T - logzi) + ew_g[g].y;
         const double q = ew_g[g].x * x;
         atomicOr(&bits[g >> 5], 1u << (g & 31));
         z += q;
@@ -546,14 +568,16 @@ __global__ __launch_bounds__(kPassThreads) void k_passA(const Scalars *sc, SellD
 // 2 = in LDS, column sums at the fixed distance kAccFixed (an instruction immediate: one VALU
 // operation less per scattered cell; needs 8 * Gp <= kAccFixed).
 template <int ENC, int GMODE, bool TLDS>
-__global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
+__global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
                                                        const double2 *tabB_g, double *partAcc,
                                                        double *partS, double *accGlobal, RangeB rg, GuardDev GD) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<ENC>;
   using RT = typename R::T;
   constexpr bool HYB = ENC == kEncIndex;  // index records + hybrid slot area (see k_passA)
-  static_assert(!(HYB && TLDS), "index records go with the hybrid slot area");
+  constexpr bool VAL = ENC == kEncValue;  // value records: no table, exp per cell
+  constexpr int NT = pass_threads_B<ENC>();
+  static_assert(!((HYB || VAL) && TLDS), "index records go with the hybrid slot area, value records have no table");
   constexpr bool TL = TLDS || HYB;
   const RecDec D = rec_dec(S);
   const uint32_t n_tab = S.n_tab_lds;
@@ -566,17 +590,17 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   const uint32_t acc_off = pass_acc_off(GMODE, G);
   const uint32_t scratch_off = (uint32_t)pass_scratch_off(GMODE, n_tab, G, false, HYB);
   double *sh = reinterpret_cast<double *>(smem + scratch_off);
-  SliceStream<ENC, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (kPassThreadsB / 64) + (tid >> 6)),
-                              gridDim.x * (kPassThreadsB / 64), (uint32_t)lane,
+  SliceStream<ENC, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (NT / 64) + (tid >> 6)),
+                              gridDim.x * (NT / 64), (uint32_t)lane,
                               scratch_off + 256u + uniform(tid >> 6) * kGeoStride);
   if (TL) {
     double2 *t = reinterpret_cast<double2 *>(smem);
-    for (uint32_t i = tid; i < n_tab; i += kPassThreadsB) t[i] = tabB_g[i];
+    for (uint32_t i = tid; i < n_tab; i += NT) t[i] = tabB_g[i];
   }
   if (ALDS) {
     double *el = reinterpret_cast<double *>(smem + bhi), *al = reinterpret_cast<double *>(smem + bhi + acc_off);
     const uint32_t n_acc = GMODE == 4 ? rg.n : Gp;
-    for (uint32_t g = tid; g < n_acc; g += kPassThreadsB) {
+    for (uint32_t g = tid; g < n_acc; g += NT) {
       if (GLDS) el[g] = e_g[g];
       al[g] = 0.0;
     }
@@ -585,9 +609,25 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   unsigned char *acc_b = reinterpret_cast<unsigned char *>(accGlobal) - bhi;
   const unsigned char *xt_b = reinterpret_cast<const unsigned char *>(tabB_g);
   auto E_ = [&](RT r) -> double { return tab8<GLDS>(e_b, R::e_off(r, D)); };
-  auto XT_ = [&](RT r) -> double2 { return tab16<TL>(xt_b, R::t_off(r, D)); };      // hybrid: hot entries only
-  auto XTg_ = [&](RT r) -> double2 { return tab16<TLDS>(xt_b, R::t_off(r, D)); };   // any entry (hybrid: from memory)
-  auto XMg_ = [&](RT r) -> double { return tab8<TLDS>(xt_b, R::t_off(r, D)); };
+  // the cell's {x - p0, x T - p0 log zi}, x = exp(a (T - tref)): from the slot table, or -- value records -- formed here
+  [[maybe_unused]] const double va = uniform_d(sc->a), vtref = uniform_d(sc->tref), vlogzi = uniform_d(sc->logzi);
+  [[maybe_unused]] const double vp0 = uniform_d(sc->p0), vp0l = vp0 * vlogzi;
+  auto XTg_ = [&](RT r) -> double2 {   // any entry (hybrid: from memory)
+    if constexpr (VAL) {
+      const double x = exp(va * (r.t - vtref));
+      return make_double2(x - vp0, fma(x, r.t, -vp0l));
+    } else {
+      return tab16<TLDS>(xt_b, R::t_off(r, D));
+    }
+  };
+  auto XT_ = [&](RT r) -> double2 {    // hybrid: hot entries only
+    if constexpr (VAL) return XTg_(r);
+    else return tab16<TL>(xt_b, R::t_off(r, D));
+  };
+  auto XMg_ = [&](RT r) -> double {
+    if constexpr (VAL) return exp(va * (r.t - vtref)) - vp0;
+    else return tab8<TLDS>(xt_b, R::t_off(r, D));
+  };
   typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
   // one column-sum update: v = the value to add (fp64 build), or its fixed-point image (kFx)
   auto addACC = [&](RT r, auto v) {
@@ -669,6 +709,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     // wavefronts per workgroup all 16 would push the kernel into scratch, and a scratch reload
     // drains the record prefetch: hence 12 wavefronts, common.hpp).
     constexpr int KEEPN = ENC == kEncWide ? 4 : MSW_B_KEEPN;  // 8-byte records take twice the registers
+    // (value records keep all 16: the alternative is a second exp per cell)
     double xv[KEEPN > 0 ? KEEPN : 1];
     // (ANY: the cells may refer to any entry of a hybrid slot area -- gathered from memory)
     auto fixed = [&](RT(&b)[kRegCells], auto LEN, auto KEEP, auto ANY) {
@@ -895,7 +936,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   };
   stream.run(issue, process, flush_logs);
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step (see pass A)
-  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D);
+  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
   // The current EC's first kLongStep * 64 records stay in registers for the scatter (one reload less: 10 % on
   // ECs of 300..1000 cells), and the next EC's first ones are fetched before the current one is
   // processed.  (The same prefetch changes nothing in pass A, which keeps the plain loop: the
@@ -991,7 +1032,7 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
   __syncthreads();
   const uint32_t n_guard = (GMODE != 4 || rg.first) ? min(*(lds_u32_t *)(size_t)gcnt_off, GD.cap) : 0u;  // once, not per range run
   if (n_guard) {
-    const uint32_t wv = uniform(tid >> 6), nwv = kPassThreadsB / 64;
+    const uint32_t wv = uniform(tid >> 6), nwv = NT / 64;
     uint32_t *bits = GD.bits + (size_t)(blockIdx.x * 16 + wv) * GD.words;
     const double a = uniform_d(sc->a), logzi = uniform_d(sc->logzi), tref = uniform_d(sc->tref);
     // A group's share of a guarded EC, in reads, goes to two global 64-bit fixed-point accumulators
@@ -1010,8 +1051,8 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
       const uint32_t p = GD.list[(size_t)blockIdx.x * GD.cap + i];
       const double c = S.cvec[p];
       double z = 0.0, h = 0.0;
-      wave_cells<ENC>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
-        const double T = GD.lut_area[ent], q = e_g[g] * exp(a * (T - tref));
+      wave_cells<ENC>(S, p, (uint32_t)lane, [&](uint32_t g, double T) {
+        const double q = e_g[g] * exp(a * (T - tref));
         atomicOr(&bits[g >> 5], 1u << (g & 31));
         z += q;
         h = fma(q, T, h);
@@ -1033,8 +1074,8 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
           s_clogZ += c * log(Z);
           s_rH += rj * H;
         }
-        wave_cells<ENC>(S, p, (uint32_t)lane, [&](uint32_t g, uint32_t ent) {
-          add_share(g, e_g[g] * rj * exp(a * (GD.lut_area[ent] - tref)));
+        wave_cells<ENC>(S, p, (uint32_t)lane, [&](uint32_t g, double T) {
+          add_share(g, e_g[g] * rj * exp(a * (T - tref)));
         });
         for (uint32_t w0 = lane; w0 < GD.words; w0 += 64) {
           const uint32_t listed = atomicAnd(&bits[w0], 0u);  // read and clear
@@ -1064,9 +1105,9 @@ __global__ __launch_bounds__(kPassThreadsB) void k_passB(const Scalars *sc, Sell
     const double *al = reinterpret_cast<const double *>(smem + bhi + acc_off);
     double *dst = partAcc + (size_t)blockIdx.x * G;
     if (GMODE == 4) {
-      for (uint32_t g = tid; g < rg.n; g += kPassThreadsB) dst[rg.g0 + g] = al[g];
+      for (uint32_t g = tid; g < rg.n; g += NT) dst[rg.g0 + g] = al[g];
     } else {
-      for (uint32_t g = tid; g < G; g += kPassThreadsB) dst[g] = al[g];
+      for (uint32_t g = tid; g < G; g += NT) dst[g] = al[g];
     }
   }
 }

@@ -10,11 +10,18 @@ OpenMP) runs the same number of iterations as the HIP path with a theta snapshot
   (i)   k <= 20: theta / bound at rel 1e-9, |g|^2 at 1e-7, identical reset decisions;
   (ii)  EVERY iteration up to the last one both sides ran: theta at the north-star tolerance
         (rel 1e-6 on weights >= 1e-4, abs 1e-8 below) -- the worst component is printed;
-  (iii) the stop: the oracle's own stop rule applied to its own bound trace must fire within three
-        iterations of the HIP path's (the bound is ~1e8 and the rule compares a gain with 1e-6: near the
-        end the gains hover around that value for several iterations and the oracle's own bound carries
-        +-2e-7 of rounding noise -- tools/stop_debug.py; the reference's own count moves by ten with -t,
-        docs/gpubenchmarks.md:15-17); when both stop together the converged theta is compared once more.
+  (iii) the stop.  ROOT CAUSE of the one-to-eight-iteration differences seen at this size (round 2: 209 / 208 ...,
+        round 3: 229 / 221 on the diverse-size input, with theta equal to 2e-10 at every iteration): the bound is
+        ~1e8 and is the sum of per-group terms lgamma(N_g) and (M - u_g) Nc_g of magnitude 1e7 each; evaluated in
+        fp64 from fp64 N_g and u_g they carry ~1e-9 of rounding each, ~1e-7 in total, in the oracle (whose long
+        double accumulators do not help: the noise is in the terms) as in the kernels -- measured |bound_hip -
+        bound_oracle| <= 3.2e-7 with theta equal to 1e-13 (gpurun_out r3_stop_debug.log, tools/stop_debug.py) -- while
+        the rule compares a gain with 1e-6 and the gains sit within 2e-7 of it for the last five to ten
+        iterations.  Which of those iterations stops is decided by that noise on either side (the reference's own
+        count moves by ten with -t, docs/gpubenchmarks.md:15-17).  The gate is therefore what the cause allows
+        and no more: with NOISE = 5e-7, the HIP path must not stop while the oracle's gain is still above
+        tol + NOISE, and must have stopped once it has fallen below tol - NOISE; when both stop together the
+        converged theta is compared once more.
 """
 import time
 
@@ -28,6 +35,7 @@ from test_gpu_rcg import FLOOR, REL, ABS, lockstep
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
+NOISE = 5e-7          # rounding noise of a bound difference at ~1e8 (measured <= 3.2e-7): module docstring, (iii)
 INIT_BOUND = -100000.0
 
 
@@ -53,6 +61,17 @@ def oracle_stop(tr, tol=TOL):
     return None
 
 
+def assert_stop_within_noise(k_gpu, ref_tr, tag=""):
+    """(iii): the HIP path stopped after k_gpu iterations -- allowed iff the oracle's own gains say that the stop
+    rule was within its rounding noise of firing there: no earlier iteration with a gain below tol - NOISE (it
+    should have stopped before), and a gain below tol + NOISE at k_gpu itself."""
+    earliest = oracle_stop(ref_tr, TOL + NOISE)     # nobody may stop before this
+    latest = oracle_stop(ref_tr, TOL - NOISE)       # everybody has stopped by then (None: beyond the trace)
+    print(f"{tag}: stop window allowed by the oracle's gains +- {NOISE:.0e}: [{earliest}, {latest}], hip {k_gpu}")
+    assert earliest is not None and k_gpu >= earliest, (k_gpu, earliest)
+    assert latest is None or k_gpu <= latest, (k_gpu, latest)
+
+
 def check_against_oracle(tag, res, tr, ref_tr):
     """(i)-(iii) of the module docstring; tr / ref_tr: per-iteration traces with theta."""
     lockstep(tr, ref_tr, 20)
@@ -72,7 +91,7 @@ def check_against_oracle(tag, res, tr, ref_tr):
           f"worst abs err below the floor {w_abs:.2e}; bound rel diff at the end "
           f"{abs(tr['bound'][n - 1] - ref_tr['bound'][n - 1]) / abs(ref_tr['bound'][n - 1]):.1e}")
     assert w_rel <= REL and w_abs <= ABS
-    assert k_orc is not None and abs(k_gpu - k_orc) <= 3, (k_gpu, k_orc)
+    assert_stop_within_noise(k_gpu, ref_tr, tag)
     if k_gpu == k_orc:
         r, g, a = worst(res["theta"], ref_tr["theta"][k_orc - 1])
         assert r <= REL and a <= ABS
@@ -115,7 +134,7 @@ def test_cfg3_csr_10M_x_5k_lockstep(gpu_core, oracle_mt, cfg3):
     tr = gpu_core.trace(res["iters"], with_theta=True)
     gpu_core.set_trace_theta(0)
     t0 = time.time()
-    ref_tr = oracle_csr_trace(oracle_mt, p, lik.log_counts(), alpha0, res["iters"] + 2)
+    ref_tr = oracle_csr_trace(oracle_mt, p, lik.log_counts(), alpha0, res["iters"] + 8)
     print(f"oracle: {res['iters'] + 2} iterations in {time.time() - t0:.0f} s")
     check_against_oracle("cfg3", res, tr, ref_tr)
     ok = tr["didreset"] == 0
@@ -148,7 +167,7 @@ def test_diverse_group_sizes_10M_x_5k_lockstep(gpu_core, oracle_mt):
     assert res["iters"] < 1000
     tr = gpu_core.trace(res["iters"], with_theta=True)
     gpu_core.set_trace_theta(0)
-    ref_tr = oracle_csr_trace(oracle_mt, p, lik.log_counts(), alpha0, res["iters"] + 2)
+    ref_tr = oracle_csr_trace(oracle_mt, p, lik.log_counts(), alpha0, res["iters"] + 8)
     check_against_oracle("diverse sizes", res, tr, ref_tr)
     again = gpu_core.solve(lik.log_counts(), alpha0)
     assert again["iters"] == res["iters"] and again["bound"] == res["bound"]
@@ -182,13 +201,13 @@ def test_cfg4_bootstrap_10M_x_5k(gpu_core, oracle_mt, cfg3):
         with np.errstate(divide="ignore"):
             logc = np.log(counts[b].astype(float))                   # -inf for ECs drawn zero times (:70)
         k = int(iters[b])
-        ref_tr = oracle_csr_trace(oracle_mt, p, logc, alpha0, k + 2)
+        ref_tr = oracle_csr_trace(oracle_mt, p, logc, alpha0, k + 8)
         k_orc = oracle_stop(ref_tr)
         r, g, a = worst(theta[b], ref_tr["theta"][k - 1])
         print(f"cfg4 replicate {b}: iterations hip {k} / oracle {k_orc}; theta after {k} iterations: worst rel err "
               f"{r:.2e} (group {g}, theta {ref_tr['theta'][k - 1][g]:.3e}), worst abs err below the floor {a:.2e}")
         assert r <= REL and a <= ABS
-        assert k_orc is not None and abs(k - k_orc) <= 3      # see the module docstring, (iii)
+        assert_stop_within_noise(k, ref_tr, f"cfg4 replicate {b}")      # see the module docstring, (iii)
         assert theta[b].sum() == pytest.approx(1.0, abs=1e-11)       # normalised by the resampled total (:513)
 
 
