@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--reads", type=int, default=None, help="cfg3/4/5: reads (default 10M; cfg5 50M); cfg2: ECs (1M)")
     ap.add_argument("--groups", type=int, default=None, help="default 5000 (cfg2: 500, cfg5: 20000)")
     ap.add_argument("--seed", type=int, default=None, help="generator seed (default: 2; cfg2: 1; cfg5: 3)")
+    ap.add_argument("--group-sizes", choices=["poisson", "diverse"], default="poisson",
+                    help="cfg3/cfg4 generator: group sizes 1 + Poisson(9) (SURVEY 8d, default) or log-normal up to 400 as "
+                         "real groupings have them (thousands of used table slots: the hybrid slot area)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", "--no-prewarm", dest="no_extras", action="store_true",
                     help="skip the convergence solves and the EM leg that run BEFORE the timed region (and warm "
@@ -74,7 +77,7 @@ def parse():
     a = ap.parse_args()
     dflt = {"cfg2": (1_000_000, 500, 1), "cfg3": (10_000_000, 5000, 2), "cfg4": (10_000_000, 5000, 2),
             "cfg5": (50_000_000, 20_000, 3)}[a.config]
-    a.default_shape = (a.reads, a.groups, a.seed) == (None, None, None)
+    a.default_shape = (a.reads, a.groups, a.seed) == (None, None, None) and a.group_sizes == "poisson"
     a.reads = dflt[0] if a.reads is None else a.reads
     a.groups = dflt[1] if a.groups is None else a.groups
     a.seed = dflt[2] if a.seed is None else a.seed
@@ -321,7 +324,8 @@ def load_workload(a, core, shard, rank, world):
                          "GPU, RCG-VB, fixed iteration count")
     # cfg3 / cfg4
     G = a.groups
-    prob = synth.make_csr_problem(a.reads, G, seed=a.seed)
+    prob = synth.make_csr_problem(a.reads, G, seed=a.seed,
+                                  group_sizes=synth.diverse_group_sizes if a.group_sizes == "diverse" else None)
     E, nnz = len(prob["rowptr"]) - 1, len(prob["grp"])
     t_gen = time.time() - t0
     log(f"generated {a.config}: E={E} nnz={nnz} in {t_gen:.1f}s")
@@ -344,6 +348,12 @@ def load_workload(a, core, shard, rank, world):
                                                 a.cpu_iters, f"first {n} ECs of the cfg3 workload x {G} groups"),
                 "cpu_baseline_structured": cpu_structured_csr(prob["rowptr"], prob["grp"], lutidx, lut, G, logc, 5,
                                                               "full cfg3 workload")}
+    if a.group_sizes == "diverse":
+        return dict(E=E, G=G, nnz=nnz, logc=lik.log_counts(), w=prob["ec_counts"].astype(np.uint32), cpu=cpu, reads=a.reads,
+                    setup_s={"generate": t_gen, "set_csr": t_up},
+                    desc=f"{a.config} with DIVERSE group sizes (log-normal, up to 400 sequences per group: "
+                         f"{int(prob['group_sizes'].max())} here; thousands of used lookup-table slots -> index records + hybrid "
+                         "slot area): synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB, fixed iteration count")
     return dict(E=E, G=G, nnz=nnz, logc=lik.log_counts(), w=prob["ec_counts"].astype(np.uint32), cpu=cpu, reads=a.reads,
                 setup_s={"generate": t_gen, "set_csr": t_up},
                 desc="cfg3: synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB (--algorithm rcggpu), "
@@ -622,6 +632,10 @@ def main():
                                      "k_passB": {"achieved": gb(tm["bytes_passB"], msB), "frac": gb(tm["bytes_passB"], msB) / HBM_PEAK_GBS}}},
             "setup_s": wl["setup_s"],
         }
+        try:
+            line["layout"] = core.layout_info()
+        except Exception:
+            pass
         line.update(line_extra)
         if "build" in wl:
             line["likelihood_build"] = wl["build"]
