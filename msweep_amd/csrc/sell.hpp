@@ -67,7 +67,11 @@ constexpr uint32_t kC8Escape = 255;
 #define MSW_W_E 2
 #endif
 constexpr int kLongRow = 256;  // ECs with more cells than this take the workgroup path
-constexpr int kColdRows = 4;   // index records: rows of a slice's cold segment (beyond: the whole slice from memory)
+#ifndef MSW_COLD_ROWS
+#define MSW_COLD_ROWS 2
+#endif
+constexpr int kColdRows = MSW_COLD_ROWS;  // index records: rows of a slice's cold segment, 2 or 4 (beyond: the whole slice from memory)
+static_assert(kColdRows == 2 || kColdRows == 4, "cold segments are cut in pairs of rows");
 constexpr uint32_t kGeoHotShift = 27;  // slice geometry in LDS: rows of the hot segment above the slice offset
 
 // what a sweep needs to decode a record (SGPRs)

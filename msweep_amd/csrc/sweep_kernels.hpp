@@ -119,8 +119,15 @@ __device__ __forceinline__ typename Rec<ENC>::T null_record(uint32_t g, const Re
 #ifndef MSW_VAL_THREADS
 #define MSW_VAL_THREADS 512
 #endif
+#ifndef MSW_HYB_THREADS_A
+#define MSW_HYB_THREADS_A MSW_PASS_THREADS_A
+#endif
+// (index records: the cold segment's records and gathered entries push pass A past the 128 registers of 16
+// wavefronts -- 12, like pass B)
 template <int ENC>
-constexpr int pass_threads_A() { return ENC == kEncValue ? MSW_VAL_THREADS : kPassThreads; }
+constexpr int pass_threads_A() {
+  return ENC == kEncValue ? MSW_VAL_THREADS : (ENC == kEncIndex ? MSW_HYB_THREADS_A : kPassThreads);
+}
 template <int ENC>
 constexpr int pass_threads_B() { return ENC == kEncValue ? MSW_VAL_THREADS : kPassThreadsB; }
 
