@@ -57,6 +57,34 @@ __device__ __forceinline__ unsigned long long fx_bits(double scaled_r, double pk
   return ((unsigned long long)hi << 32) | (uint32_t)__double2loint(v);
 }
 
+// c / z and 1 / z for the EC epilogues of the sweeps: z is a softmax denominator that passed the guard test
+// (sell.hpp) -- a normal number between 2^-8 of the background sum and twice the number of groups -- so the
+// operand scaling and the special-case fix-up of the IEEE division (4 of its 12 instructions, 7 of 12 for a
+// reciprocal) are not needed.  Reciprocal estimate, two Newton steps, one residual correction: within one ulp
+// of the quotient.  (The guarded ECs' own evaluation, whose z may be anything above zero, divides in full.)
+#ifndef MSW_FAST_DIV
+#define MSW_FAST_DIV 1
+#endif
+__device__ __forceinline__ double ec_rcp(double z) {
+#if MSW_FAST_DIV
+  double r = __builtin_amdgcn_rcp(z);
+  r = fma(fma(-z, r, 1.0), r, r);
+  r = fma(fma(-z, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / z;
+#endif
+}
+__device__ __forceinline__ double ec_div(double c, double z) {
+#if MSW_FAST_DIV
+  const double r = ec_rcp(z);
+  const double q = c * r;
+  return fma(fma(-z, q, c), r, q);
+#else
+  return c / z;
+#endif
+}
+
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 // a wave-uniform double that was loaded through a vector load: move it to SGPRs
 __device__ __forceinline__ double uniform_d(double v) {
@@ -440,7 +468,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
     if (sb.sl * 64 + lane < n_sell) {
       const double Zt = zbase + c.zs;
       if (Zt >= gthr) {
-        const double iZ = 1.0 / Zt;
+        const double iZ = ec_rcp(Zt);
         const double S1 = (b1 + c.t1) * iZ, S2 = (b2 + c.t2) * iZ;
         nn += S2 - S1 * S1;
       } else {
@@ -498,7 +526,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
         if (lane == 0) {
           const double Zt = zbase + zs;
           if (Zt >= gthr) {
-            const double iZ = 1.0 / Zt;
+            const double iZ = ec_rcp(Zt);
             const double S1 = (b1 + t1) * iZ, S2 = (b2 + t2) * iZ;
             nn += S2 - S1 * S1;
           } else {
@@ -673,6 +701,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   const double zbase = p0 * U, hbase = p0 * uniform_d(sc->logzi) * U;
   const int fxe = (int)uniform((uint32_t)fx_expbits(sc->fx_shift));
   const double fxs = uniform_d(sc->fx_scale), fxb = ldexp(uniform_d(sc->xb), 1 - (int)uniform((uint32_t)sc->fx_shift));
+  const double fxt1 = 0x1p51 / fxs, fxt2 = 0x1p51 / (fxs * fxb);  // the narrow-add test of an EC (below)
   const double gthr = fmax(zbase * kGuardRatio, 2.2250738585072014e-308);  // (Z = 0 is set aside too: reported, not divided by)  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
   const uint32_t gcnt_off = scratch_off + 128u;
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
@@ -865,12 +894,13 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         defer(S.n_long + sb.sl * 64 + lane);
       } else if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
-        const double rj = c / Z;
+        const double rj = ec_div(c, Z);
         s_rH += rj * H;
         s_W += rj;
         if constexpr (kFx) {
           const double rs = rj * fxs;
-          if (rs * fmax(Z + zbase, fxb) < 0x1p51) scatter_all(rs, std::false_type{});
+          // rs (Z + zbase) = 2^K (c + r_j zbase) and rs fxb against 2^51: two comparisons with per-pass constants
+          if (fma(rj, zbase, c) < fxt1 && rj < fxt2) scatter_all(rs, std::false_type{});
           else scatter_all(rs, std::true_type{});
         } else {
           scatter_all(rj, std::false_type{});
@@ -926,12 +956,12 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         defer(S.n_long + sb.sl * 64 + lane);
       } else if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
-        const double rj = c / Z;
+        const double rj = ec_div(c, Z);
         s_clogZ += c * log(Z);
         s_rH += rj * H;
         s_W += rj;
         const double rs = kFx ? rj * fxs : rj;
-        const bool narrow = !kFx || rs * fmax(Z + zbase, fxb) < 0x1p51;
+        const bool narrow = !kFx || (fma(rj, zbase, c) < fxt1 && rj < fxt2);
         for (k0 = 0; k0 < len; k0 += kRegCells) {
           const uint32_t n = len - k0 < (uint32_t)kRegCells ? len - k0 : (uint32_t)kRegCells;
           load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t);
@@ -997,7 +1027,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         if (lane == 0) defer(r);
       } else if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
-        const double rj = c / Z;
+        const double rj = ec_div(c, Z);
         if (lane == 0) {
           s_clogZ += c * log(Z);
           s_rH += rj * H;
@@ -1006,7 +1036,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
 #pragma unroll
         for (int u = 0; u < kLongStep; ++u) rc[u] = first[u];
         const double rs = kFx ? rj * fxs : rj;
-        const bool narrow = !kFx || rs * fmax(Z + zbase, fxb) < 0x1p51;  // wave-uniform
+        const bool narrow = !kFx || (fma(rj, zbase, c) < fxt1 && rj < fxt2);  // wave-uniform
         for (uint32_t kb = c0;;) {
 #pragma unroll
           for (int q = 0; q < kLongStep; q += 4) {
