@@ -236,6 +236,8 @@ const char *msw_comm_last_error(void);
  * ec_counts[n_ecs] (Alignment::reads_in_ec, :220), plus ec_rptr[n_ecs + 1] / ec_reads[n_aligned]
  * (Alignment::reads_assigned_to_ec, :229: the read ids of every EC, ascending).  n_reads is the line
  * count of the last strand (Alignment::n_reads, :219).  Any output pointer may be NULL.
+ * gzip-compressed files (Themisto --gzip-output; the reference opens its inputs through bxzstr, which detects
+ * the compression by its magic bytes) are inflated with zlib; bzip2 / xz files are refused by name.
  * The compact alignment-writer format is not supported (BitMagic): convert to plaintext. */
 typedef struct msw_alignment *msw_alignment_t;
 #define MSW_MERGE_INTERSECTION 0

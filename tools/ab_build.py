@@ -100,7 +100,7 @@ args = sys.argv[1:]
 for name, flags in zip(args[0::2], args[1::2]):
     out = os.path.join(R, "build_ab", f"lib_{name}.so")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", *flags.split(),
-           "-o", out, os.path.join(X, "msweep_amd", "csrc", "msweep_core.hip"), "-L/opt/rocm/lib", "-lrccl",
+           "-o", out, os.path.join(X, "msweep_amd", "csrc", "msweep_core.hip"), "-L/opt/rocm/lib", "-lrccl", "-lz",
            "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     print(name, "OK" if r.returncode == 0 else "FAILED\n" + "\n".join(l for l in r.stderr.splitlines() if "error" in l)[:2000])
