@@ -38,6 +38,9 @@ constexpr int kLongStep = MSW_LONG_STEP;  // records per lane and step on the wa
 #ifndef MSW_PASSB_BATCH
 #define MSW_PASSB_BATCH 4
 #endif
+#ifndef MSW_LONG_KEEP
+#define MSW_LONG_KEEP 1
+#endif
 // Column sums in 64-bit FIXED POINT (default): a cell adds rint(2^K * f_g * r_j * (x - p0)) with an INTEGER
 // LDS atomic (f_g: e_g, or a power-of-two multiple of it for the groups far below the largest --
 // device_util.hpp fx_factor); k_redfin turns the totals back into reads.  Integer addition is associative:
@@ -940,6 +943,8 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       // kRegCells records through the same registers -- once for the row sums, once more (from L2)
       // for the scatter; the other wavefronts of the workgroup cover each chunk's load latency
       // (registers of their own: see pass A)
+      // (keeping the first chunk's f_g (x - p0) for the scatter, like a short slice's, was tried in round 3: the
+      // values live across the chunk loops push every instantiation into 300 bytes of scratch)
       const size_t base = (size_t)o * 64 + lane;
       RT t[kRegCells];
       uint32_t k0 = 0;
@@ -1002,6 +1007,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       for (int u = 0; u < kLongStep; ++u) first[u] = rc[u] = pre[u];
       load_long(n0, n1, pre);
       double zs = 0.0, hs = 0.0;
+      double pkf[kLongStep];  // f_g (x - p0) of the first step's cells: no second gather (or exponential) for them
       for (uint32_t kb = c0;;) {
 #pragma unroll
         for (int q = 0; q < kLongStep; q += 4) {
@@ -1015,6 +1021,12 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
               zs = fma(eg[u], t[u].x, zs);
               hs = fma(eg[u], t[u].y, hs);
             }
+#if MSW_LONG_KEEP
+            if (kb == c0) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) pkf[q + u] = kFx ? fx_factor(eg[u], fxe) * t[u].x : t[u].x;
+            }
+#endif
           }
         }
         kb += kLongStep * 64;
@@ -1042,8 +1054,13 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
           for (int q = 0; q < kLongStep; q += 4) {
             if (kb + 64u * q < c1) {
               double xm[4];
+              if (MSW_LONG_KEEP && kb == c0) {
 #pragma unroll
-              for (int u = 0; u < 4; ++u) xm[u] = kFx ? fx_factor(E_(rc[q + u]), fxe) * XMg_(rc[q + u]) : XMg_(rc[q + u]);
+                for (int u = 0; u < 4; ++u) xm[u] = pkf[q + u];
+              } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xm[u] = kFx ? fx_factor(E_(rc[q + u]), fxe) * XMg_(rc[q + u]) : XMg_(rc[q + u]);
+              }
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 if constexpr (kFx) {

@@ -10,8 +10,11 @@ from msweep_amd.likelihood import from_grouped_counts
 
 core = Core(0)
 CASES = [(2_000_000, 1000, 6), (2_000_000, 1000, 40), (1_000_000, 1000, 200), (200_000, 1000, 800), (60_000, 3000, 2500)]
-if len(sys.argv) > 1:
+if len(sys.argv) == 2:
     CASES = CASES[int(sys.argv[1]):]
+elif len(sys.argv) > 2:   # reads groups max_other [reads groups max_other ...]
+    a = [int(x) for x in sys.argv[1:]]
+    CASES = [tuple(a[i:i + 3]) for i in range(0, len(a), 3)]
 print("MSWEEP_LONG_ROW =", os.environ.get("MSWEEP_LONG_ROW", "(default)"))
 for R, G, mo in CASES:
     p = synth.make_csr_problem(R, G, seed=2, max_other=mo)
