@@ -997,6 +997,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
     };
     RT pre[kLongStep];
     load_long(c0, c1, pre);
+    uint32_t n_deferred = 0;  // ECs whose logarithm sits in lp_mant / lp_exp (wave-uniform)
     while (r < S.n_long) {
       const uint32_t rn = r + stream.nw;
       uint32_t n0 = 0, n1 = 0;
@@ -1040,8 +1041,30 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       } else if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
         const double rj = ec_div(c, Z);
-        if (lane == 0) {
+        // c log Z deferred as in the slices (multiplicities 1..15: the mantissas multiplied up in lane 0, one
+        // logarithm per 32 ECs): the full logarithm is 70 dependent instructions in the middle of a
+        // wavefront's one-EC-at-a-time chain
+        const uint32_t c8l = uniform((uint32_t)S.c8[r]);
+        if (c8l <= 15u) {
+          if (lane == 0) {
+            int ez;
+            const double m = frexp(Z, &ez);
+            const double m2 = m * m, m4 = m2 * m2, m8 = m4 * m4;
+            double pw = (c8l & 1u) ? m : 1.0;
+            pw *= (c8l & 2u) ? m2 : 1.0;
+            pw *= (c8l & 4u) ? m4 : 1.0;
+            pw *= (c8l & 8u) ? m8 : 1.0;
+            lp_mant *= pw;
+            lp_exp += ez * (int)c8l;
+          }
+          if (++n_deferred == 32u) {
+            flush_logs();
+            n_deferred = 0;
+          }
+        } else if (lane == 0) {
           s_clogZ += c * log(Z);
+        }
+        if (lane == 0) {
           s_rH += rj * H;
           s_W += rj;
         }
@@ -1079,6 +1102,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       }
       r = rn, c0 = n0, c1 = n1;
     }
+    flush_logs();
   }
   // guarded ECs (sell.hpp): a wavefront each, every group visited.  Each group receives its share of the
   // EC's c_j directly -- listed: c e_g x / Z, not listed: c e_g p0 / Z -- and the EC stays out of
