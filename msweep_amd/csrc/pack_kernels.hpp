@@ -126,10 +126,9 @@ __global__ __launch_bounds__(256) void k_pack_long(const uint32_t *rowptr, const
   }
 }
 
-// One wavefront per slice.  Slices of up to 16 cells per EC (the sweeps' register path) get the
-// static LDS-bank scheduling: per step the lanes choose, one after the other in rotating priority,
-// the unplaced cell that is free in most bank sets -- identical to the host packer's loop.  Longer
-// slices (the streaming path) keep the CSR order.
+// One wavefront per slice.  Static LDS-bank scheduling: per step the lanes choose, one after the other in
+// rotating priority, the unplaced cell that is free in most bank sets -- identical to the host packer's loop.
+// Slices of more than 16 rows (the streaming path) are scheduled in windows of 16 rows.
 // Index records (hybrid slot area): the rows [0, nhot) of a slice hold cells of LDS-resident entries only (the
 // greedy scheduling runs over those), the rows [nhot, L) whatever is left in CSR order -- nhot = L - the
 // even-rounded largest number of cold cells of one EC, or 0 when that exceeds kColdRows.
@@ -158,77 +157,82 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
       b = rowptr[j];
       mylen = rowptr[j + 1] - b;
     }
-    if (L > (uint32_t)kPackCells) {
-      for (uint32_t k = 0; k < L; ++k) {
-        if (k < mylen) pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, grp[b + k], pack_entry(pe, lane, idx[b + k]));
-        else pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, pe.n_groups + lane, kPackPad);
-      }
-      if (ENC == kEncIndex && lane == 0) pe.slice_hot[s] = 0;
-      continue;
-    }
-    uint32_t mycold = 0;
-    for (uint32_t c = 0; c < mylen; ++c) {
-      cg[c][lane] = grp[b + c];
-      ce[c][lane] = pack_entry(pe, lane, idx[b + c]);
-      mycold += ce[c][lane] >= pe.n_hot;
-    }
-    uint32_t taken = 0, nhot = L;
-    if constexpr (ENC == kEncIndex) {
-      uint32_t mc = mycold;  // largest cold count of the slice's ECs
-      for (int d = 32; d; d >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, d));
-      const uint32_t ncold = (mc + 1u) & ~1u;
-      nhot = mc > (uint32_t)kColdRows ? 0u : L - ncold;
-      if (lane == 0) pe.slice_hot[s] = (uint8_t)nhot;
-    }
+    // A slice of up to 16 rows is one window; a longer one (the streaming path of the sweeps, which walks it in
+    // chunks of 16 rows) is scheduled chunk by chunk: the cells [k0, k0 + 16) of every EC, in CSR order, go
+    // into the rows [k0, k0 + 16).  (Round 3: such slices used to keep the CSR order.)
+    const bool streaming = L > (uint32_t)kPackCells;
+    if (ENC == kEncIndex && lane == 0) pe.slice_hot[s] = 0;  // streaming and empty slices; a short one overwrites it
     const int R = kRGroupDev[lane], C = lane >> 4, H = lane >> 5;
-    for (uint32_t k = 0; k < nhot; ++k) {
-      for (int t = lane; t < 196; t += 64) reinterpret_cast<uint32_t *>(&bk)[t] = t < 192 ? 0xffffffffu : 0u;
-      uint32_t pick_g = pe.n_groups + lane, pick_e = kPackPad;
-      __syncthreads();
-      for (int li = 0; li < 64; ++li) {
-        const int l = (li + (int)k * 7) & 63;  // rotate the priority
-        if (lane == l) {
-          int best = -1, best_score = -1;
-          for (uint32_t c = 0; c < mylen; ++c) {
-            if (taken >> c & 1) continue;
-            const uint32_t g = cg[c][lane], i = ce[c][lane];
-            if (ENC == kEncIndex && i >= pe.n_hot) continue;  // a cold cell: not in the hot segment
-            int score = 0;
-            if (!(at[C] >> (g & 15) & 1)) score += MSW_W_AT;                              // atomic: bank pair free
-            if (rg[R][g & 15] == 0xffffffffu || rg[R][g & 15] == g) score += MSW_W_EW;   // {e,w} b128
-            if (ENC == kEncValue || rs[R][i & 15] == 0xffffffffu || rs[R][i & 15] == i) score += MSW_W_XT;   // slot entry b128
-            if (hg[H][g & 31] == 0xffffffffu || hg[H][g & 31] == g) score += MSW_W_E;   // e_g b64
-            if (score > best_score) {
-              best_score = score;
-              best = (int)c;
-              if (score == MSW_W_AT + MSW_W_EW + MSW_W_XT + MSW_W_E) break;
+    for (uint32_t k0 = 0; k0 < L; k0 += kPackCells) {
+      const uint32_t nrows = min((uint32_t)kPackCells, L - k0);
+      const uint32_t ncell = mylen > k0 ? min((uint32_t)kPackCells, mylen - k0) : 0u;  // this lane's cells in the window
+      uint32_t mycold = 0;
+      for (uint32_t c = 0; c < ncell; ++c) {
+        cg[c][lane] = grp[b + k0 + c];
+        ce[c][lane] = pack_entry(pe, lane, idx[b + k0 + c]);
+        mycold += ce[c][lane] >= pe.n_hot;
+      }
+      uint32_t taken = 0, nhot = nrows;
+      if constexpr (ENC == kEncIndex) {
+        if (!streaming) {
+          uint32_t mc = mycold;  // largest cold count of the slice's ECs
+          for (int d = 32; d; d >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, d));
+          const uint32_t ncold = (mc + 1u) & ~1u;
+          nhot = mc > (uint32_t)kColdRows ? 0u : L - ncold;
+          if (lane == 0) pe.slice_hot[s] = (uint8_t)nhot;
+        }
+      }
+      for (uint32_t k = 0; k < nhot; ++k) {
+        for (int t = lane; t < 196; t += 64) reinterpret_cast<uint32_t *>(&bk)[t] = t < 192 ? 0xffffffffu : 0u;
+        uint32_t pick_g = pe.n_groups + lane, pick_e = kPackPad;
+        __syncthreads();
+        for (int li = 0; li < 64; ++li) {
+          const int l = (li + (int)(k0 + k) * 7) & 63;  // rotate the priority
+          if (lane == l) {
+            int best = -1, best_score = -1;
+            for (uint32_t c = 0; c < ncell; ++c) {
+              if (taken >> c & 1) continue;
+              const uint32_t g = cg[c][lane], i = ce[c][lane];
+              if (ENC == kEncIndex && !streaming && i >= pe.n_hot) continue;  // a cold cell: not in the hot segment
+              int score = 0;
+              if (!(at[C] >> (g & 15) & 1)) score += MSW_W_AT;                              // atomic: bank pair free
+              if (rg[R][g & 15] == 0xffffffffu || rg[R][g & 15] == g) score += MSW_W_EW;   // {e,w} b128
+              if (ENC == kEncValue || rs[R][i & 15] == 0xffffffffu || rs[R][i & 15] == i) score += MSW_W_XT;   // slot entry b128
+              if (hg[H][g & 31] == 0xffffffffu || hg[H][g & 31] == g) score += MSW_W_E;   // e_g b64
+              if (score > best_score) {
+                best_score = score;
+                best = (int)c;
+                if (score == MSW_W_AT + MSW_W_EW + MSW_W_XT + MSW_W_E) break;
+              }
+            }
+            if (best >= 0) {
+              taken |= 1u << best;
+              const uint32_t g = cg[best][lane], i = ce[best][lane];
+              at[C] |= 1u << (g & 15);
+              if (rg[R][g & 15] == 0xffffffffu) rg[R][g & 15] = g;
+              if (rs[R][i & 15] == 0xffffffffu) rs[R][i & 15] = i;
+              if (hg[H][g & 31] == 0xffffffffu) hg[H][g & 31] = g;
+              pick_g = g;
+              pick_e = i;
             }
           }
-          if (best >= 0) {
-            taken |= 1u << best;
-            const uint32_t g = cg[best][lane], i = ce[best][lane];
-            at[C] |= 1u << (g & 15);
-            if (rg[R][g & 15] == 0xffffffffu) rg[R][g & 15] = g;
-            if (rs[R][i & 15] == 0xffffffffu) rs[R][i & 15] = i;
-            if (hg[H][g & 31] == 0xffffffffu) hg[H][g & 31] = g;
-            pick_g = g;
-            pick_e = i;
-          }
+          __syncthreads();
         }
-        __syncthreads();
+        pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, pick_g, pick_e);
       }
-      pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, pick_g, pick_e);
-    }
-    // the cold segment (index records; nhot = L otherwise): what is left, in CSR order, then the lane's sentinel
-    uint32_t c = 0;
-    for (uint32_t k = nhot; k < L; ++k) {
-      while (c < mylen && (taken >> c & 1)) ++c;
-      if (c < mylen) {
-        pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, cg[c][lane], ce[c][lane]);
-        ++c;
-      } else {
-        pack_put<ENC>(rec, base + (size_t)k * 64 + lane, pe, pe.n_groups + lane, kPackPad);
+      // the cold segment (index records; nhot = the window's rows otherwise): what is left, in CSR order, then
+      // the lane's sentinel
+      uint32_t c = 0;
+      for (uint32_t k = nhot; k < nrows; ++k) {
+        while (c < ncell && (taken >> c & 1)) ++c;
+        if (c < ncell) {
+          pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, cg[c][lane], ce[c][lane]);
+          ++c;
+        } else {
+          pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, pe.n_groups + lane, kPackPad);
+        }
       }
+      __syncthreads();
     }
     __syncthreads();
   }
