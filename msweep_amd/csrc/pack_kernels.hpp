@@ -114,15 +114,53 @@ __device__ __forceinline__ void pack_put(uint32_t *dst, size_t slot, const PackE
   }
 }
 
-// records of the long ECs (plain CSR, any lane reads them: compact slot entries)
+// Records of the long ECs (plain CSR, one wavefront sweeps an EC 64 cells at a time: compact slot entries).
+// The order of an EC's cells is free, so they are laid out for the LDS banks: with r = group mod 32 and j = the
+// cell's rank among the EC's cells of the same r (CSR order), the cells are sorted by (j, r) -- position
+//   pos = sum_r' min(b_r', j) + #{r' < r : b_r' > j}      (b_r' = cells of the EC with residue r').
+// While j is below the smallest b, a row of 32 cells holds the residues 0..31 in order: lane l reads a group
+// congruent to l modulo 32, which is conflict-free for the e_g reads (32 bank pairs per half-wave), the {e, w}
+// reads and the column-sum atomics (16 bank pairs per 16 lanes, in either lane grouping); later rows thin out
+// but keep their residues distinct and ascending.  (Round 3; before, CSR order: the reads of 16 random groups met
+// on a bank 2.9 times.)  One wavefront per EC; identical to the host packer's loop.
+constexpr uint32_t kLongResidues = 32;
+__host__ __device__ inline uint32_t long_cell_pos(const uint32_t *b, uint32_t r, uint32_t j) {
+  uint32_t pos = 0;
+  for (uint32_t q = 0; q < kLongResidues; ++q) pos += (b[q] < j ? b[q] : j) + (q < r && b[q] > j ? 1u : 0u);
+  return pos;
+}
 template <int ENC>
-__global__ __launch_bounds__(256) void k_pack_long(const uint32_t *rowptr, const uint32_t *grp, const uint32_t *idx,
-                                                  const uint32_t *perm, const uint32_t *long_ptr, uint32_t n_long,
-                                                  PackEnc pe, uint32_t *rec_long) {
+__global__ __launch_bounds__(64) void k_pack_long(const uint32_t *rowptr, const uint32_t *grp, const uint32_t *idx,
+                                                 const uint32_t *perm, const uint32_t *long_ptr, uint32_t n_long,
+                                                 PackEnc pe, uint32_t *rec_long) {
+  __shared__ uint32_t cnt[kLongResidues];
+  const uint32_t lane = threadIdx.x;
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;  // lanes below this one
   for (uint32_t p = blockIdx.x; p < n_long; p += gridDim.x) {
     const uint32_t b = rowptr[perm[p]], n = long_ptr[p + 1] - long_ptr[p], o = long_ptr[p];
-    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x)
-      pack_put<ENC>(rec_long, (size_t)o + k, pe, grp[b + k], pack_entry(pe, -1, idx[b + k]));
+    if (lane < kLongResidues) cnt[lane] = 0;
+    __syncthreads();
+    for (uint32_t k = lane; k < n; k += 64) atomicAdd(&cnt[grp[b + k] & (kLongResidues - 1)], 1u);
+    __syncthreads();
+    uint32_t run = 0;  // lane r < 32: cells of residue r in the chunks before this one
+    for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      const bool valid = k < n;
+      const uint32_t g = valid ? grp[b + k] : 0u;
+      const uint32_t r = valid ? (g & (kLongResidues - 1)) : kLongResidues;
+      unsigned long long mine = 0;
+      uint32_t add = 0;
+      for (uint32_t q = 0; q < kLongResidues; ++q) {
+        const unsigned long long m = __ballot(r == q);
+        if (r == q) mine = m;
+        if (lane == q) add = (uint32_t)__popcll(m);
+      }
+      const uint32_t before = (uint32_t)__shfl((int)run, (int)(r & (kLongResidues - 1)));
+      const uint32_t j = before + (uint32_t)__popcll(mine & lt);
+      run += add;
+      if (valid) pack_put<ENC>(rec_long, (size_t)o + long_cell_pos(cnt, r, j), pe, g, pack_entry(pe, -1, idx[b + k]));
+    }
+    __syncthreads();
   }
 }
 
