@@ -493,15 +493,8 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
     auto load_long = [&](uint32_t kb, uint32_t k1, RT(&dst)[LS]) {
 #pragma unroll
       for (int u = 0; u < LS; ++u) {
-        // wave-uniform tests first: a whole row inside the EC is loaded without a per-lane test, whole rows past
-        // its end cost nothing
-        const uint32_t row = kb + 64u * u;
-        if (row + 64u <= k1) {
-          dst[u] = R::load(S.rec_long, row + lane);
-        } else {
-          dst[u] = null_rec;
-          if (row < k1 && row + lane < k1) dst[u] = R::load(S.rec_long, row + lane);
-        }
+        dst[u] = null_rec;  // wave-uniform test first: whole 64-cell groups past the end cost nothing
+        if (kb + 64u * u < k1 && kb + 64u * u + lane < k1) dst[u] = R::load(S.rec_long, kb + 64u * u + lane);
       }
     };
     uint32_t r = stream.s_first, kb = 0, k1 = 0;
@@ -998,13 +991,9 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
     auto load_long = [&](uint32_t kb, uint32_t k1, RT(&dst)[kLongStep]) {
 #pragma unroll
       for (int u = 0; u < kLongStep; ++u) {
-        const uint32_t row = kb + 64u * u;
-        if (row + 64u <= k1) {
-          dst[u] = R::load(S.rec_long, row + lane);
-        } else {
-          dst[u] = null_rec;
-          if (row < k1 && row + lane < k1) dst[u] = R::load(S.rec_long, row + lane);
-        }
+        dst[u] = null_rec;  // (a separate branch for rows that lie wholly inside the EC -- no per-lane test -- was
+                            // measured in round 3: 4-6 % SLOWER on ECs of 300..1000 cells)
+        if (kb + 64u * u < k1 && kb + 64u * u + lane < k1) dst[u] = R::load(S.rec_long, kb + 64u * u + lane);
       }
     };
     RT pre[kLongStep];
