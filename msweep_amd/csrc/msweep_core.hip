@@ -235,6 +235,9 @@ void choose_lds_mode(msw_core *h) {
     if (force && strlen(force) == 2 && (o[0] != (force[0] == '1') || o[1] != (force[1] == '1'))) continue;
     const uint32_t n_tab = o[1] ? h->n_area : 0u;
     const int gmB = passB_mode(h, o[0], n_tab, false);
+    // (too many groups for the group vectors AND a slot table that leaves no room for the column sums: the table
+    // goes to memory -- or into the hybrid area -- rather than the column sums into HBM atomics, 20 x the cost)
+    if (!force && !o[0] && o[1] && gmB == 0 && !getenv("MSWEEP_GLOBAL_ATOMICS")) continue;
     if (gmB >= 0 && pass_lds_bytes(o[0] ? 1 : 0, n_tab, h->G, true, false) <= kLdsMax) {
       h->glds = o[0];
       h->tlds = o[1];

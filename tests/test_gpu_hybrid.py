@@ -121,3 +121,22 @@ def test_hybrid_off_switch_gives_the_same_answer(oracle, monkeypatch):
     assert out[0][1]["index_records"] == 1 and out[1][1]["index_records"] == 0
     assert out[0][0]["iters"] == out[1][0]["iters"]
     assert_theta(out[0][0]["theta"], out[1][0]["theta"], rel=1e-9, abs_=1e-12)
+
+
+@pytest.mark.parametrize("G", [12000, 19500])
+def test_hybrid_with_many_groups(oracle, G):
+    """More groups than the LDS images hold AND more table slots than fit beside what is left: pass B keeps its column
+    sums in LDS (mode 3) or sweeps once per range of groups (mode 4, two runs at 19 500 groups), {e, w} / e_g come
+    from memory, and the room that remains holds the head of the hybrid area."""
+    p = diverse(120_000, G, 29, max_other=10)
+    lut = precalc_lls(p["group_sizes"])
+    with Core(0) as core:
+        res, tr, logc, alpha0 = solve_csr(core, p)
+        li = core.layout_info()
+        print(li)
+        assert li["groups_in_lds"] == 0 and li["passB_mode"] in (3, 4)
+        assert li["index_records"] == 1 and li["record_bytes"] == 4, li
+        ref = oracle.rcg_optl_csr(p["rowptr"], p["grp"], lutidx_of(p, lut), lut, np.log(0.01), G, logc, alpha0, trace=20)
+        lockstep(tr, ref["trace"], 20)
+        assert res["iters"] == ref["iters"]
+        assert_theta(res["theta"], ref["theta"])

@@ -93,3 +93,28 @@ def test_value_records_bootstrap_and_zero_counts(oracle):
             assert abs(int(iters_b[b]) - rb["iters"]) <= 2
             if int(iters_b[b]) == rb["iters"]:
                 assert_theta(theta_b[b], rb["theta"])
+
+
+def test_value_records_with_many_groups(oracle):
+    """Continuous values AND more groups than the LDS images hold (12 000: pass B mode 3, {e, w} / e_g from memory)."""
+    rng = np.random.default_rng(35)
+    G, E = 12000, 6000
+    L = np.full((G, E), np.log(0.01))
+    for j in range(E):
+        g = rng.choice(G, int(rng.integers(1, 30)), replace=False)
+        L[g, j] = np.clip(rng.normal(-2.0, 1.0, len(g)), -12.0, -0.1)
+    logc = np.log(rng.integers(1, 6, E).astype(float))
+    alpha0 = np.ones(G)
+    with Core(0) as core:
+        from_dense(core, L, logc)
+        li = core.layout_info()
+        assert li["record_bytes"] == 12 and li["groups_in_lds"] == 0 and li["passB_mode"] in (3, 4), li
+        core.set_trace_theta(20)
+        res = core.solve(logc, alpha0)
+        tr = core.trace(20, with_theta=True)
+        ref = oracle.rcg_optl_dense_structured(L, logc, alpha0, trace=20)
+        lockstep(tr, ref["trace"], 20)
+        assert abs(res["iters"] - ref["iters"]) <= 1
+        if res["iters"] == ref["iters"]:
+            assert_theta(res["theta"], ref["theta"])
+        np.testing.assert_array_equal(core.get_dense_logl(), L)
