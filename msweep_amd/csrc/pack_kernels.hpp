@@ -46,9 +46,9 @@ __global__ __launch_bounds__(256) void k_pack_keys(const uint32_t *rowptr, uint3
   if (mine) atomicAdd(n_long, mine);
 }
 
-// out[i] = cells of the i-th long EC (i < n_long) / even-rounded cells of slice i's first EC
+// out[i] = cells of the i-th long EC (i < n_long) / cells of slice i's first EC
 __global__ __launch_bounds__(256) void k_pack_lens(const uint32_t *rowptr, const uint32_t *perm, uint32_t n_long,
-                                                  uint32_t nslices, uint32_t *long_len, uint32_t *slice_len) {
+                                                  uint32_t nslices, int even, uint32_t *long_len, uint32_t *slice_len) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_long) {
     const uint32_t j = perm[i];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_pack_lens(const uint32_t *rowptr, const
   if (i < nslices) {
     const uint32_t j = perm[n_long + (size_t)i * 64];
     uint32_t len = rowptr[j + 1] - rowptr[j];  // the first EC of a slice is its longest
-    slice_len[i] = len + (len & 1);              // the sweeps consume two cells per step
+    slice_len[i] = even ? len + (len & 1) : len;  // sell.hpp odd_slices
   }
 }
 
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
         if (!streaming) {
           uint32_t mc = mycold;  // largest cold count of the slice's ECs
           for (int d = 32; d; d >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, d));
-          const uint32_t ncold = (mc + 1u) & ~1u;
+          const uint32_t ncold = (mc + 1u) & ~1u;  // (index records: even slices, even segments)
           nhot = mc > (uint32_t)kColdRows ? 0u : L - ncold;
           if (lane == 0) pe.slice_hot[s] = (uint8_t)nhot;
         }

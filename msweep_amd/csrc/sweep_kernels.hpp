@@ -107,15 +107,23 @@ struct SliceBuf {
   uint32_t c8;  // byte image of the EC's multiplicity (sell.hpp)
 };
 
-// Issue the loads of one slice (<= kRegCells cells per EC, even count) into registers.
+// Issue the loads of one slice (<= kRegCells cells per EC) into registers.  The sweeps work through a slice two
+// rows at a time; a slice of byte-offset records may have an odd number of rows (sell.hpp odd_slices: until round 3
+// every slice was padded in memory -- 5 % of cfg3's record stream, 10 % of cfg5's): its missing last row is the
+// lane's null record, made here instead of being read.
 template <int ENC>
 __device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uint32_t len,
-                                           typename Rec<ENC>::T (&r)[kRegCells]) {
+                                           typename Rec<ENC>::T (&r)[kRegCells], typename Rec<ENC>::T nullr) {
 #pragma unroll
   for (int k = 0; k < kRegCells; k += 2) {
     if ((uint32_t)k < len) {
       r[k] = Rec<ENC>::load(rec, base + (size_t)k * 64);
-      r[k + 1] = Rec<ENC>::load(rec, base + (size_t)(k + 1) * 64);
+      if constexpr (odd_slices(ENC)) {
+        r[k + 1] = nullr;
+        if ((uint32_t)k + 1 < len) r[k + 1] = Rec<ENC>::load(rec, base + (size_t)(k + 1) * 64);
+      } else {
+        r[k + 1] = Rec<ENC>::load(rec, base + (size_t)(k + 1) * 64);
+      }
     }
   }
 }
@@ -125,16 +133,12 @@ __device__ __forceinline__ void load_slice_split(const uint32_t *rec, size_t bas
                                                  uint32_t (&r)[kRegCells], uint32_t (&rc)[kColdRows]) {
   const uint32_t ncold = len - nhot;
   if (ncold <= (uint32_t)kColdRows) {
-    load_slice<kEncIndex>(rec, base, nhot, r);
+    load_slice<kEncIndex>(rec, base, nhot, r, 0u);
 #pragma unroll
-    for (int j = 0; j < kColdRows; j += 2) {
-      if ((uint32_t)j < ncold) {
-        rc[j] = rec[base + (size_t)(nhot + j) * 64];
-        rc[j + 1] = rec[base + (size_t)(nhot + j + 1) * 64];
-      }
-    }
+    for (int j = 0; j < kColdRows; ++j)
+      if ((uint32_t)j < ncold) rc[j] = rec[base + (size_t)(nhot + j) * 64];
   } else {
-    load_slice<kEncIndex>(rec, base, len, r);
+    load_slice<kEncIndex>(rec, base, len, r, 0u);
   }
 }
 
@@ -180,6 +184,7 @@ struct SliceStream {
   const SellDev &S;
   uint32_t s_first, nw, n_mine, lane;
   uint32_t geo;  // LDS byte offset of this wave's 64 (+2 dummy) {slice_off[s], slice_off[s+1]} pairs
+  typename Rec<ENC>::T nullr = {};  // the lane's null record (the missing last row of an odd slice: load_slice)
   uint2 pend = make_uint2(0, 0);
   __device__ __forceinline__ SliceStream(const SellDev &S_, uint32_t first, uint32_t nw_, uint32_t lane_,
                                          uint32_t geo_)
@@ -228,7 +233,7 @@ struct SliceStream {
     } else {
       b.o = uniform(oe.x);
       b.len = uniform(oe.y) - b.o;
-      if (b.len <= (uint32_t)kRegCells) load_slice<ENC>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r);
+      if (b.len <= (uint32_t)kRegCells) load_slice<ENC>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r, nullr);
     }
     issue(b);
   }
@@ -368,11 +373,15 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
+  // (lanes past the end of a long EC, and the missing last row of an odd slice, take a record of the lane's own
+  // sentinel group)
+  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
+  stream.nullr = null_rec;
   auto issue = [&](SliceBuf<ENC> &) {};
   auto process = [&](SliceBuf<ENC> &sb) {
     const uint32_t len = sb.len;
     AccA c = {0.0, 0.0, 0.0};
-    // straight-line code per cell count (wave-uniform and even): all LDS gathers of a batch can be
+    // straight-line code per cell count (wave-uniform): all LDS gathers of a batch can be
     // in flight together instead of one scalar-branched pair at a time
     // (ANY: the cells may refer to any entry of a hybrid slot area -- gathered from memory)
     auto fixed = [&](RT(&b)[kRegCells], auto LEN, auto ANY) {
@@ -395,6 +404,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
       }
     };
     auto cells = [&](RT(&b)[kRegCells], uint32_t n) {
+      n += n & 1;  // an odd slice's missing last row is a null record in the registers (load_slice)
       switch (n) {
         case 0: break;
         case 2: fixed(b, std::integral_constant<int, 2>{}, std::false_type{}); break;
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
     auto pairs_any = [&](RT(&b)[kRegCells], uint32_t n) {
 #pragma unroll
       for (int k = 0; k < kRegCells; k += 2) {
-        if ((uint32_t)k < n) {
+        if ((uint32_t)k < n) {  // (n odd: the pair's second record is the lane's null record, load_slice)
           const double2 a0 = EW_(b[k]), a1 = EW_(b[k + 1]);
           const double2 x0 = XTg_(b[k]), x1 = XTg_(b[k + 1]);
           cellA(c, p0, a0.x, a0.y, x0.x, x0.y);
@@ -426,22 +436,16 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
           // the cold rows' table entries come from memory: issued first, consumed after the hot rows
           double2 cew[kColdRows], cxt[kColdRows];
 #pragma unroll
-          for (int j = 0; j < kColdRows; j += 2) {
+          for (int j = 0; j < kColdRows; ++j) {
             if ((uint32_t)j < ncold) {
               cxt[j] = XTg_(sb.rc[j]);
-              cxt[j + 1] = XTg_(sb.rc[j + 1]);
               cew[j] = EW_(sb.rc[j]);
-              cew[j + 1] = EW_(sb.rc[j + 1]);
             }
           }
           cells(sb.r, nhot);
 #pragma unroll
-          for (int j = 0; j < kColdRows; j += 2) {
-            if ((uint32_t)j < ncold) {
-              cellA(c, p0, cew[j].x, cew[j].y, cxt[j].x, cxt[j].y);
-              cellA(c, p0, cew[j + 1].x, cew[j + 1].y, cxt[j + 1].x, cxt[j + 1].y);
-            }
-          }
+          for (int j = 0; j < kColdRows; ++j)
+            if ((uint32_t)j < ncold) cellA(c, p0, cew[j].x, cew[j].y, cxt[j].x, cxt[j].y);
         } else {
           pairs_any(sb.r, len);
         }
@@ -458,13 +462,13 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
       RT t[kRegCells];
       uint32_t k0 = 0;
       for (; k0 + (uint32_t)kRegCells <= len; k0 += kRegCells) {
-        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, kRegCells, t);
+        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, kRegCells, t, null_rec);
         fixed(t, std::integral_constant<int, kRegCells>{}, std::true_type{});
       }
       if (k0 < len) {  // the last chunk: pair by pair (a second copy of the per-count code costs the
                        // short path 5 % through its sheer size)
         const uint32_t n = len - k0;
-        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t);
+        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t, null_rec);
         pairs_any(t, n);
       }
     }
@@ -484,7 +488,6 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   // distinct, so the gathers of a step never meet on an address, and the three sums are wave
   // reductions (no barrier)
   // (lanes past the end take a record of their own sentinel group)
-  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
   // The wavefront's ECs are one sequence of steps of LS * 64 cells; the records of the NEXT step (of
   // this EC or of the next one) are always in flight while a step is processed -- a step costs a
   // full memory round trip otherwise, and a wavefront walks some sixty of them one after the other.
@@ -726,6 +729,8 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   __syncthreads();
 
   const uint32_t n_sell = S.n_ecs - S.n_long;
+  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
+  stream.nullr = null_rec;
   auto issue = [&](SliceBuf<ENC> &sb) {
     const uint32_t q = sb.sl * 64 + lane;
     const uint32_t cj = S.c8[S.n_long + (q < n_sell ? q : 0u)];
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
     double zs = 0.0, hs = 0.0;
-    // row sums: straight-line code per cell count (wave-uniform, even).  x - p0 of the first KEEPN
+    // row sums: straight-line code per cell count (wave-uniform).  x - p0 of the first KEEPN
     // cells stays in registers for the scatter, any others are gathered a second time (with 16
     // wavefronts per workgroup all 16 would push the kernel into scratch, and a scratch reload
     // drains the record prefetch: hence 12 wavefronts, common.hpp).
@@ -780,6 +785,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       }
     };
     auto cells = [&](RT(&b)[kRegCells], uint32_t n, auto KEEP) {
+      n += n & 1;  // an odd slice's missing last row is a null record in the registers (load_slice)
       switch (n) {
         case 0: break;
         case 2: fixed(b, std::integral_constant<int, 2>{}, KEEP, std::false_type{}); break;
@@ -797,7 +803,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
     auto pairs_any = [&](RT(&b)[kRegCells], uint32_t n) {
 #pragma unroll
       for (int k = 0; k < kRegCells; k += 2) {
-        if ((uint32_t)k < n) {
+        if ((uint32_t)k < n) {  // (n odd: the pair's second record is the lane's null record, load_slice)
           const double e0 = E_(b[k]), e1 = E_(b[k + 1]);
           const double2 t0 = XTg_(b[k]), t1 = XTg_(b[k + 1]);
           zs = fma(e0, t0.x, zs);
@@ -815,7 +821,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       constexpr bool WA = decltype(WIDE_ADD)::value;
 #pragma unroll
       for (int k = 0; k < kRegCells; k += 2) {
-        if ((uint32_t)k < n) {
+        if ((uint32_t)k < n) {  // (n odd: the pair's second record is the lane's null record, load_slice)
           double x0, x1;
           if constexpr (kFx) {
             x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : fx_factor(E_(b[k]), fxe) * XMg_(b[k]);
@@ -851,18 +857,16 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
           double ce[kColdRows];
           double2 cx[kColdRows];
 #pragma unroll
-          for (int j = 0; j < kColdRows; j += 2) {
+          for (int j = 0; j < kColdRows; ++j) {
             if ((uint32_t)j < ncold) {
               cx[j] = XTg_(sb.rc[j]);
-              cx[j + 1] = XTg_(sb.rc[j + 1]);
               ce[j] = E_(sb.rc[j]);
-              ce[j + 1] = E_(sb.rc[j + 1]);
             }
           }
           cells(sb.r, nhot, std::true_type{});
 #pragma unroll
           for (int j = 0; j < kColdRows; ++j) {
-            if ((uint32_t)(j & ~1) < ncold) {
+            if ((uint32_t)j < ncold) {
               zs = fma(ce[j], cx[j].x, zs);
               hs = fma(ce[j], cx[j].y, hs);
               xc[j] = kFx ? fx_factor(ce[j], fxe) * cx[j].x : cx[j].x;
@@ -882,7 +886,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         if constexpr (HYB) {
 #pragma unroll
           for (int j = 0; j < kColdRows; ++j) {
-            if ((uint32_t)(j & ~1) < ncold) {
+            if ((uint32_t)j < ncold) {
               if constexpr (kFx) {
                 if constexpr (decltype(WIDE_ADD)::value) addFXwide(sb.rc[j], rs, xc[j]);
                 else addFX(sb.rc[j], rs, xc[j]);
@@ -949,12 +953,12 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       RT t[kRegCells];
       uint32_t k0 = 0;
       for (; k0 + (uint32_t)kRegCells <= len; k0 += kRegCells) {
-        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, kRegCells, t);
+        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, kRegCells, t, null_rec);
         fixed(t, std::integral_constant<int, kRegCells>{}, std::false_type{}, std::true_type{});
       }
       if (k0 < len) {
         const uint32_t n = len - k0;
-        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t);
+        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t, null_rec);
         pairs_any(t, n);
       }
       if (c != 0.0 && !(zbase + zs >= gthr)) {
@@ -969,7 +973,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         const bool narrow = !kFx || (fma(rj, zbase, c) < fxt1 && rj < fxt2);
         for (k0 = 0; k0 < len; k0 += kRegCells) {
           const uint32_t n = len - k0 < (uint32_t)kRegCells ? len - k0 : (uint32_t)kRegCells;
-          load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t);
+          load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t, null_rec);
           if (narrow) scatter(t, n, rs, std::false_type{}, std::false_type{});
           else scatter(t, n, rs, std::false_type{}, std::true_type{});
         }
@@ -978,7 +982,6 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   };
   stream.run(issue, process, flush_logs);
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step (see pass A)
-  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
   // The current EC's first kLongStep * 64 records stay in registers for the scatter (one reload less: 10 % on
   // ECs of 300..1000 cells), and the next EC's first ones are fetched before the current one is
   // processed.  (The same prefetch changes nothing in pass A, which keeps the plain loop: the
