@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_pack_long(const uint32_t *rowptr, const 
 // Slices of more than 16 rows (the streaming path) are scheduled in windows of 16 rows.
 // Index records (hybrid slot area): the rows [0, nhot) of a slice hold cells of LDS-resident entries only (the
 // greedy scheduling runs over those), the rows [nhot, L) whatever is left in CSR order -- nhot = L - the
-// even-rounded largest number of cold cells of one EC, or 0 when that exceeds kColdRows.
+// largest number of cold cells of one EC, or 0 when that exceeds kColdRows.
 constexpr int kPackCells = 16;
 template <int ENC>
 __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, const uint32_t *grp, const uint32_t *idx,
@@ -215,8 +215,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
         if (!streaming) {
           uint32_t mc = mycold;  // largest cold count of the slice's ECs
           for (int d = 32; d; d >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, d));
-          const uint32_t ncold = (mc + 1u) & ~1u;  // (index records: even slices, even segments)
-          nhot = mc > (uint32_t)kColdRows ? 0u : L - ncold;
+          nhot = mc > (uint32_t)kColdRows ? 0u : L - mc;
           if (lane == 0) pe.slice_hot[s] = (uint8_t)nhot;
         }
       }

@@ -79,13 +79,13 @@ struct RecDec {
   uint32_t shift, mask, bhi, bhiA;
 };
 enum { kEncNarrow = 0, kEncWide = 1, kEncIndex = 2, kEncValue = 3 };
-// Slices of byte-offset records have as many rows as their longest EC has cells; the other encodings round that up
-// to an even number (their sweeps have no code for odd counts: with it the register allocation of their larger
-// kernels falls into scratch -- round 3).  (Until round 3 every slice was rounded: 5 % of cfg3's rows, 10 % of cfg5's.)
+// A slice has as many rows as its longest EC has cells (until round 3 that was rounded up to an even number: 5 % of
+// cfg3's rows, 10 % of cfg5's); the sweeps, which work through a slice two rows at a time, make the missing last row
+// of an odd slice in registers (sweep_kernels.hpp load_slice).  MSW_ODD_SLICES=0: the padded layout, for A/B timing.
 #ifndef MSW_ODD_SLICES
 #define MSW_ODD_SLICES 1
 #endif
-__host__ __device__ constexpr bool odd_slices(int enc) { return MSW_ODD_SLICES && enc == kEncNarrow; }
+__host__ __device__ constexpr bool odd_slices(int) { return MSW_ODD_SLICES != 0; }
 constexpr uint32_t kValRowWords = 192;  // value records: dwords per row of 64 cells (64 hi words + 64 doubles)
 struct ValRec {
   uint32_t hi;  // byte offset of e_g (8 * group: no table in front of the group vectors)

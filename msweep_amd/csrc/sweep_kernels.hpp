@@ -108,7 +108,7 @@ struct SliceBuf {
 };
 
 // Issue the loads of one slice (<= kRegCells cells per EC) into registers.  The sweeps work through a slice two
-// rows at a time; a slice of byte-offset records may have an odd number of rows (sell.hpp odd_slices: until round 3
+// rows at a time; a slice may have an odd number of rows (sell.hpp odd_slices: until round 3
 // every slice was padded in memory -- 5 % of cfg3's record stream, 10 % of cfg5's): its missing last row is the
 // lane's null record, made here instead of being read.
 template <int ENC>
@@ -130,15 +130,15 @@ __device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uin
 // index records: rows [0, nhot) into r, the cold rows [nhot, len) -- at most kColdRows, or the packer has set
 // nhot = 0 and the whole slice is taken from memory -- into rc
 __device__ __forceinline__ void load_slice_split(const uint32_t *rec, size_t base, uint32_t len, uint32_t nhot,
-                                                 uint32_t (&r)[kRegCells], uint32_t (&rc)[kColdRows]) {
+                                                 uint32_t (&r)[kRegCells], uint32_t (&rc)[kColdRows], uint32_t nullr) {
   const uint32_t ncold = len - nhot;
   if (ncold <= (uint32_t)kColdRows) {
-    load_slice<kEncIndex>(rec, base, nhot, r, 0u);
+    load_slice<kEncIndex>(rec, base, nhot, r, nullr);
 #pragma unroll
     for (int j = 0; j < kColdRows; ++j)
       if ((uint32_t)j < ncold) rc[j] = rec[base + (size_t)(nhot + j) * 64];
   } else {
-    load_slice<kEncIndex>(rec, base, len, r, 0u);
+    load_slice<kEncIndex>(rec, base, len, r, nullr);
   }
 }
 
@@ -229,7 +229,7 @@ struct SliceStream {
       b.o = ox & ((1u << kGeoHotShift) - 1u);
       b.nhot = ox >> kGeoHotShift;
       b.len = uniform(oe.y) - b.o;
-      if (b.len <= (uint32_t)kRegCells) load_slice_split(S.rec, (size_t)b.o * 64 + lane, b.len, b.nhot, b.r, b.rc);
+      if (b.len <= (uint32_t)kRegCells) load_slice_split(S.rec, (size_t)b.o * 64 + lane, b.len, b.nhot, b.r, b.rc, nullr);
     } else {
       b.o = uniform(oe.x);
       b.len = uniform(oe.y) - b.o;
