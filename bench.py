@@ -12,7 +12,9 @@ reference would hold (E * G) processed per second, summed over all ranks.
   cfg2  synthetic 1M ECs x 500 groups DENSE likelihood through rcg_optl's own dense boundary
         (msw_core_set_dense_logl; the library re-expresses it as CSR-of-ECs on the device);
   cfg5  sparse 50M reads x 20k groups through msw_core_build_likelihood with --min-hits 1 (build timed
-        separately), one GPU;
+        separately), one GPU -- or, with --gpus N --mode shard, BASELINE's "8 x MI355X": every rank expands and
+        builds its own block of ECs (the --min-hits counts all-reduced inside the build) and the ONE solve
+        all-reduces its column sums every iteration;
   cfg4  cfg3 + bootstrap: a "step" is ONE bootstrap replicate (src/mSWEEP.cpp:496-518) through
         msw_core_bootstrap_dist -- K replicates per rank: stream seek / GF(2) jump-ahead, resampling, solve to
         --tol 1e-6, and the all-gather of the abundances inside the timed region.
@@ -286,12 +288,22 @@ def load_workload(a, core, shard, rank, world):
         p = synth.make_csr_problem(a.reads, G, seed=a.seed, max_other=7, theta_support=max(G // 10, 1), chunk=2_000_000)
         t_gen = time.time() - t0
         t0 = time.time()
-        aln = synth.csr_to_targets(p, shuffle=False)
-        t_aln = time.time() - t0
         E, nnz = len(p["rowptr"]) - 1, len(p["grp"])
+        if shard:
+            # EC-sharded build: every rank expands and builds its own block of ECs; the --min-hits
+            # counts of a group are summed over ALL ECs (one all-reduce of G integers inside the build call)
+            from msweep_amd.parallel import csr_block, shard_ecs
+            b = shard_ecs(p["rowptr"], world)
+            blk = csr_block(p, b[rank], b[rank + 1])
+            aln = synth.csr_to_targets(blk, shuffle=False)
+            ecc = blk["ec_counts"]
+        else:
+            aln = synth.csr_to_targets(p, shuffle=False)
+            ecc = p["ec_counts"]
+        t_aln = time.time() - t0
         t0 = time.time()
         lik = from_alignment(core, aln["ec_tptr"], aln["ec_targets"], aln["target_group"], p["group_sizes"],
-                             p["ec_counts"], min_hits=1)
+                             ecc, min_hits=1)
         t_build = time.time() - t0
         hits = int(len(aln["ec_targets"]))
         del aln
@@ -313,7 +325,7 @@ def load_workload(a, core, shard, rank, world):
             out["cpu_baseline_structured"] = cpu_structured_csr(p["rowptr"], grp2, lutidx, lut, G2, lik.log_counts(), 3,
                                                                 "full cfg5 workload (compacted to the kept groups)")
             return out
-        return dict(E=E, G=G2, nnz=nnz, logc=None, w=None, cpu=cpu, reads=a.reads,
+        return dict(E=E, G=G2, nnz=nnz, logc=lik.log_counts() if shard else None, w=None, cpu=cpu, reads=a.reads,
                     setup_s={"generate": t_gen, "expand_to_targets": t_aln, "build_likelihood": t_build},
                     build={"seconds": t_build, "target_hits": hits, "groups_in": G, "groups_kept": G2,
                            "what": "msw_core_build_likelihood: upload of the pseudoalignment (ec_tptr / ec_targets / "
@@ -390,8 +402,11 @@ def main():
                  f"(plain `python bench.py --gpus {a.gpus}` starts them itself)")
     if a.launch_selftest:
         return launch_selftest(a, rank, world)
-    if a.config in ("cfg2", "cfg5") and (world > 1 or a.mode == "shard"):
-        sys.exit(f"bench.py: --config {a.config} is a single-GPU line; the N > 1 modes run on cfg3 / cfg4")
+    if a.config == "cfg2" and (world > 1 or a.mode == "shard"):
+        sys.exit("bench.py: --config cfg2 is a single-GPU line; the N > 1 modes run on cfg3 / cfg4 / cfg5")
+    if a.config == "cfg5" and world > 1 and a.mode != "shard":
+        sys.exit("bench.py: --config cfg5 over several GPUs is ONE solve with the ECs sharded (BASELINE.json: 8 x MI355X): "
+                 "add --mode shard")
     if a.config == "cfg4" and a.mode == "shard":
         sys.exit("bench.py: --config cfg4 shards whole replicates, not ECs")
     # ONE JSON line on stdout: libraries that print banners there (RCCL's version block at its first
@@ -427,10 +442,10 @@ def main():
         if rccl_ranks != world:
             sys.exit(f"bench.py: RCCL communicator spans {rccl_ranks} ranks, expected {world}")
     boot_comm = comm if comm is not None else Comm.local(1)[0]   # one rank: the in-process communicator
+    if shard:
+        core.set_comm(comm)      # before the likelihood: cfg5's --min-hits counts are all-reduced over the EC shards
     wl = load_workload(a, core, shard, rank, world)
     E, G, nnz = wl["E"], wl["G"], wl["nnz"]
-    if shard:
-        core.set_comm(comm)
     alpha0 = np.ones(G)
     logc = wl["logc"]
     if dist is not None and not shard and a.config == "cfg3":
