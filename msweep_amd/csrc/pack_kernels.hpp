@@ -1,8 +1,8 @@
 // pack_kernels.hpp -- device construction of the SELL-64 layout (sell.hpp) from a CSR-of-ECs that
-// is already in HBM: EC order (long ECs first, then by descending length: a stable radix sort of
-// 9-bit keys), slice geometry, slot statistics, and the records themselves -- one wavefront per
-// slice runs the same greedy LDS-bank scheduling as the host packer (host_likelihood.inc), pick
-// for pick, so both produce the same bytes.  Replaces ~1 s of host re-layout at cfg3 (20 x the
+// is already in HBM: EC order (long ECs first, then by descending length and, with a hybrid slot area, ascending
+// cold class: a stable radix sort of 11-bit keys), slice geometry, slot statistics, and the records themselves --
+// one wavefront per slice runs the same greedy LDS-bank scheduling as the host packer (host_likelihood.inc), pick
+// for pick, and one wavefront per long EC the same bank-aware cell order, so both produce the same bytes.  Replaces ~1 s of host re-layout at cfg3 (20 x the
 // solve it prepares) by a few milliseconds.
 #pragma once
 #include "common.hpp"

@@ -1,17 +1,21 @@
 // sweep_kernels.hpp -- the two HBM-streaming sweeps of one RCG iteration over the SELL-64
 // likelihood: pass A (natural-gradient norm) and pass B (softmax / column sums / ELBO).
 //
-// Both kernels: one persistent 1024-thread workgroup per CU; its 16 wavefronts take slices
-// round-robin.  A slice of up to kRegCells cells per EC is held in registers: while slice s is
-// being processed the records of the wave's next slice are already in flight (the record stream
+// Both kernels: one persistent workgroup per CU (pass A 16 wavefronts, pass B 12; value records 8); its
+// wavefronts take slices round-robin.  A slice of up to kRegCells cells per EC is held in registers: while
+// slice s is being processed the records of the wave's next slice are already in flight (the record stream
 // is the only HBM traffic; everything else is gathered from LDS).  Slice bounds are wave-uniform
 // and kept in SGPRs (readfirstlane) so the cell loops are scalar branches, not exec-mask loops.
 //
-// The sweeps are bound by VALU issue + LDS gathers, not by HBM, so the per-cell
-// instruction count is what is optimised here: records carry ready-made LDS byte offsets
+// Pass A is bound by its record stream, pass B by VALU issue + LDS gathers in balance, so the
+// per-cell instruction count is what is optimised here: records carry ready-made LDS byte offsets
 // (sell.hpp: one shift + one mask per cell), every per-slot quantity that does not depend on the
 // group is tabulated once per pass by prepB_block (state_kernels.hpp), and padding records point
 // at per-lane sentinel groups so that no per-cell test is needed.
+//
+// Template parameter ENC = the record encoding (sell.hpp): byte-offset records (the case above), 8-byte records,
+// index records with the HYBRID slot area (a slice is cut into a hot segment served from LDS and a short cold one
+// whose table entries come from memory), value records (the cell's log-likelihood inline, exp per cell).
 #pragma once
 #include <type_traits>
 
