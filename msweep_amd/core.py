@@ -46,7 +46,8 @@ class LayoutInfo(C.Structure):
     _fields_ = [("record_bytes", C.c_int32), ("index_records", C.c_int32), ("groups_in_lds", C.c_int32),
                 ("table_in_lds", C.c_int32), ("passB_mode", C.c_int32), ("slot_entries", C.c_uint32),
                 ("slot_entries_in_lds", C.c_uint32), ("n_slices", C.c_uint32), ("n_long_ecs", C.c_uint32),
-                ("rows", C.c_uint64), ("rows_from_memory", C.c_uint64)]
+                ("rows", C.c_uint64), ("rows_from_memory", C.c_uint64), ("slices_by_lanes", C.c_uint32 * 5),
+                ("max_rows", C.c_uint32)]
 
 
 class BootstrapTiming(C.Structure):
@@ -264,7 +265,7 @@ class Core:
         """How the resident CSR-of-ECs likelihood is laid out for the sweeps (msw_core_layout_info)."""
         t = LayoutInfo()
         self._check(self._L.msw_core_layout_info(self._h, C.byref(t)))
-        return {k: getattr(t, k) for k, _ in LayoutInfo._fields_}
+        return {k: (list(getattr(t, k)) if k == "slices_by_lanes" else getattr(t, k)) for k, _ in LayoutInfo._fields_}
 
     def layout_hash(self):
         out = C.c_uint64(0)

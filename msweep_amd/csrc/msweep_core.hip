@@ -55,6 +55,7 @@ struct msw_core {
   uint32_t n_area = 0;                                  // 16-byte entries of the slot area
   uint32_t n_tab_lds = 0;                               // ... of which the LDS images hold (all, the hot head, none)
   DevBuf<uint8_t> slice_hot;                            // index records: rows of every slice's hot segment
+  SliceClasses cls = {};                                // slice classes: lanes per EC (sell.hpp)
   bool wide() const { return enc == kEncWide; }
   bool hybrid() const { return enc == kEncIndex; }
   RecDec dec() const { return RecDec{enc_shift, enc_mask, enc_bhi, enc_bhiA}; }
@@ -75,14 +76,14 @@ struct msw_core {
 
   // ---- solve state ---------------------------------------------------------------------
   DevBuf<double> cvec, logc_d, alpha0, u, os_u, step_u, w, e, N, Nc, Acc;
-  DevBuf<uint8_t> c8;  // byte image of cvec (sell.hpp)
+  DevBuf<uint8_t> c8, c8s;  // byte image of cvec by EC position / by slice lane (sell.hpp)
   DevBuf<double> logc_res;  // log counts left on the device by msw_core_build_likelihood
   bool have_logc_res = false;
   DevBuf<double2> ew, tabA, tabB;  // group table of pass A; per-slot tables of both sweeps (TabDev)
   TabDev tabs() const { return TabDev{tabA.p, tabB.p}; }
   DevBuf<double> partA, partS, partAcc, partC, partR, totS;
   // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
-  size_t lds_attr[2][40] = {};  // dynamic-LDS limit already granted per sweep instantiation
+  size_t lds_attr[2][80] = {};  // dynamic-LDS limit already granted per sweep instantiation
   msw_comm *comm = nullptr;
   bool in_collective = false;  // a solve / sharded build is under way: a failure now strands the peers (guarded())
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
@@ -193,6 +194,7 @@ SellDev sell_view(msw_core *h) {
   S.perm = h->perm.p;
   S.cvec = h->cvec.p;
   S.c8 = h->c8.p;
+  S.c8s = h->c8s.p;
   S.nslices = h->nslices;
   S.n_long = h->n_long;
   S.n_ecs = h->E;
@@ -207,6 +209,7 @@ SellDev sell_view(msw_core *h) {
   S.n_tab_lds = h->n_tab_lds;
   S.slice_hot = h->slice_hot.p;
   S.lut_area = h->lut_area.p;
+  S.cls = h->cls;
   return S;
 }
 
@@ -226,6 +229,23 @@ int passB_mode(const msw_core *h, bool glds, uint32_t n_tab, bool index) {
   // ... and beyond that one range of groups at a time does (mode 4), whatever the group count
   if (pass_lds_bytes(4, n_tab, G, false, index) <= kLdsMax) return 4;
   return 0;
+}
+
+// MSWEEP_MULTILANE=0 (developer switch): every EC of up to 256 cells one lane (slices of up to 256 rows on the
+// streaming path of the sweeps), the layout of rounds 1-2
+bool multilane() {
+  const char *e = getenv("MSWEEP_MULTILANE");
+  return !(e && atoi(e) == 0);
+}
+// slice / position boundaries of the classes from the ECs per class (n[c]: class c = 16 >> c lanes per EC)
+SliceClasses make_slice_classes(const uint32_t *n) {
+  SliceClasses C = {};
+  for (int c = 0; c < kSliceClasses; ++c) {
+    const uint32_t per = 64u >> (4 - c);
+    C.p0[c + 1] = C.p0[c] + n[c];
+    C.s0[c + 1] = C.s0[c] + (n[c] + per - 1) / per;
+  }
+  return C;
 }
 
 void choose_lds_mode(msw_core *h) {
@@ -322,6 +342,8 @@ void alloc_solve_state(msw_core *h) {
   h->ew.zero(h->stream);
   h->cvec.alloc(E);
   h->c8.alloc((size_t)E + 64);
+  h->c8s.alloc((size_t)h->nslices * 64 + 64);  // lanes without an EC stay 0: no EC
+  h->c8s.zero(h->stream);
   h->logc_d.alloc(E);
   h->tabA.alloc((size_t)std::max<uint32_t>(h->n_area, 1));
   h->tabB.alloc((size_t)std::max<uint32_t>(h->n_area, 1));
@@ -382,16 +404,20 @@ void prepare_sweep(K k, size_t lds, size_t &lds_set) {
 template <int ENC, bool GL, bool TL>
 void launch_passA_t(msw_core *h) {
   const size_t lds = pass_lds_bytes(GL ? 1 : 0, h->n_tab_lds, h->G, true, ENC == kEncIndex);
-  auto k = k_passA<ENC, GL, TL>;
-  prepare_sweep(k, lds, h->lds_attr[0][ENC * 4 + (GL ? 2 : 0) + (TL ? 1 : 0)]);
+  // ML: some slices hold ECs over several lanes (sell.hpp slice classes) -- an instantiation of its own: the few
+  // scalar operations and branches the classes cost per slice are 2-3 % of a sweep over short slices (cfg3, cfg5)
+  const bool ml = h->cls.s0[kSliceClasses - 1] > 0;
+  auto k = ml ? k_passA<ENC, GL, TL, true> : k_passA<ENC, GL, TL, false>;
+  prepare_sweep(k, lds, h->lds_attr[0][(ml ? 40 : 0) + ENC * 4 + (GL ? 2 : 0) + (TL ? 1 : 0)]);
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(pass_threads_A<ENC>()), lds, h->stream, h->sc.p, sell_view(h),
                      h->ew.p, h->tabA.p, h->partA.p, h->guard_view());
 }
 template <int ENC, int GM, bool TL>
 void launch_passB_t(msw_core *h) {
   const size_t lds = pass_lds_bytes(GM, h->n_tab_lds, h->G, false, ENC == kEncIndex);
-  auto k = k_passB<ENC, GM, TL>;
-  prepare_sweep(k, lds, h->lds_attr[1][ENC * 10 + 2 * GM + (TL ? 1 : 0)]);
+  const bool ml = h->cls.s0[kSliceClasses - 1] > 0;
+  auto k = ml ? k_passB<ENC, GM, TL, true> : k_passB<ENC, GM, TL, false>;
+  prepare_sweep(k, lds, h->lds_attr[1][(ml ? 40 : 0) + ENC * 10 + 2 * GM + (TL ? 1 : 0)]);
   if (GM == 4) {  // one run per range of groups; the first also delivers the ELBO terms
     for (uint32_t g0 = 0; g0 < h->G; g0 += kRangeGroups)
       hipLaunchKernelGGL(k, dim3(h->nblk), dim3(pass_threads_B<ENC>()), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
@@ -589,7 +615,8 @@ void prepare_inputs(msw_core *h, const double *logc_host, const uint32_t *counts
   const uint32_t E = h->E, G = h->G;
   if (counts_dev) {
     hipLaunchKernelGGL(k_cvec_from_counts, dim3(kCvecBlocks), dim3(256), 0, h->stream, counts_dev,
-                       h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->c8.p, h->partC.p);
+                       h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->c8.p, h->partC.p, h->cls, h->n_long,
+                       h->flavor == 0 ? h->c8s.p : nullptr);
   } else {
     const double *src = h->logc_d.p;
     if (logc_host) {
@@ -599,7 +626,8 @@ void prepare_inputs(msw_core *h, const double *logc_host, const uint32_t *counts
       src = h->logc_res.p;
     }
     hipLaunchKernelGGL(k_cvec_from_logc, dim3(kCvecBlocks), dim3(256), 0, h->stream, src,
-                       h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->c8.p, h->partC.p);
+                       h->flavor == 0 ? h->perm.p : nullptr, E, h->cvec.p, h->c8.p, h->partC.p, h->cls, h->n_long,
+                       h->flavor == 0 ? h->c8s.p : nullptr);
   }
   if (alpha0_host)
     MSW_HIP(hipMemcpyAsync(h->alpha0.p, alpha0_host, G * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -881,6 +909,8 @@ int msw_core_layout_info(msw_handle h, msw_layout_info *out) {
     std::vector<uint32_t> off((size_t)h->nslices + 1);
     MSW_HIP(hipMemcpy(off.data(), h->slice_off.p, off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     li.rows = off[h->nslices];
+    for (int c = 0; c < kSliceClasses; ++c) li.slices_by_lanes[c] = h->cls.s0[c + 1] - h->cls.s0[c];
+    for (uint32_t s2 = 0; s2 < h->nslices; ++s2) li.max_rows = std::max(li.max_rows, off[s2 + 1] - off[s2]);
     if (h->hybrid()) {
       std::vector<uint8_t> hot(std::max<uint32_t>(h->nslices, 1));
       MSW_HIP(hipMemcpy(hot.data(), h->slice_hot.p, hot.size(), hipMemcpyDeviceToHost));

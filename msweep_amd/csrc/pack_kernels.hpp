@@ -29,35 +29,43 @@ __host__ __device__ inline uint32_t cold_class(uint32_t n_cold) {
 constexpr uint32_t kPackKeyBits = 11;  // (1 + kLongRow) * 4 + 3 < 2^11
 // sort key of an EC: 0 = long (plain CSR part), else (1 + (kLongRow - cells)) * 4 + cold class: ascending = SELL
 // order.  canon == nullptr: no hybrid area, every cold class 0.
-__global__ __launch_bounds__(256) void k_pack_keys(const uint32_t *rowptr, uint32_t E, uint32_t long_row,
+// counts[0] = long ECs, counts[1 + c] = ECs of slice class c (sell.hpp)
+__global__ __launch_bounds__(256) void k_pack_keys(const uint32_t *rowptr, uint32_t E, uint32_t long_row, int multilane,
                                                   const uint32_t *idx, const uint32_t *canon, uint32_t n_hot,
-                                                  uint32_t *key, uint32_t *val, uint32_t *n_long) {
-  uint32_t mine = 0;
+                                                  uint32_t *key, uint32_t *val, uint32_t *counts) {
+  uint32_t mine[1 + kSliceClasses] = {};
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < E; j += gridDim.x * blockDim.x) {
     const uint32_t b = rowptr[j], len = rowptr[j + 1] - b;
     const bool lg = len > long_row;  // long_row <= kLongRow
     uint32_t cc = 0;
-    if (canon && len <= 16u)  // slices of more rows take every entry from memory anyway
+    if (canon && len <= 16u)  // (ECs of more lanes or rows: class 0 -- their slices find their segments themselves)
       for (uint32_t k = 0; k < len; ++k) cc += canon[idx[b + k]] >= n_hot;
     key[j] = lg ? 0u : (1u + ((uint32_t)kLongRow - len)) * 4u + cold_class(cc);
     val[j] = j;
-    mine += lg;
+    const int c = lg ? 0 : 1 + slice_class_of(len, multilane != 0);
+#pragma unroll
+    for (int i = 0; i <= kSliceClasses; ++i) mine[i] += c == i;
   }
-  if (mine) atomicAdd(n_long, mine);
+#pragma unroll
+  for (int i = 0; i <= kSliceClasses; ++i)
+    if (mine[i]) atomicAdd(&counts[i], mine[i]);
 }
 
 // out[i] = cells of the i-th long EC (i < n_long) / cells of slice i's first EC
 __global__ __launch_bounds__(256) void k_pack_lens(const uint32_t *rowptr, const uint32_t *perm, uint32_t n_long,
-                                                  uint32_t nslices, int even, uint32_t *long_len, uint32_t *slice_len) {
+                                                  uint32_t nslices, int even, SliceClasses cls, uint32_t *long_len,
+                                                  uint32_t *slice_len) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_long) {
     const uint32_t j = perm[i];
     long_len[i] = rowptr[j + 1] - rowptr[j];
   }
   if (i < nslices) {
-    const uint32_t j = perm[n_long + (size_t)i * 64];
-    uint32_t len = rowptr[j + 1] - rowptr[j];  // the first EC of a slice is its longest
-    slice_len[i] = even ? len + (len & 1) : len;  // sell.hpp odd_slices
+    const SliceGeo sg = slice_geo(cls, i);
+    const uint32_t j = perm[n_long + (size_t)sg.ec0];
+    const uint32_t len = rowptr[j + 1] - rowptr[j];  // the first EC of a slice is its longest
+    const uint32_t rows = (len + (1u << sg.lgm) - 1u) >> sg.lgm;  // its cells over its 2^lgm lanes
+    slice_len[i] = even ? rows + (rows & 1) : rows;  // sell.hpp odd_slices
   }
 }
 
@@ -174,7 +182,8 @@ constexpr int kPackCells = 16;
 template <int ENC>
 __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, const uint32_t *grp, const uint32_t *idx,
                                                    const uint32_t *perm, const uint32_t *slice_off, uint32_t n_long,
-                                                   uint32_t n_sell, uint32_t nslices, PackEnc pe, uint32_t *rec) {
+                                                   uint32_t n_sell, uint32_t nslices, SliceClasses cls, PackEnc pe,
+                                                   uint32_t *rec) {
   __shared__ uint32_t cg[kPackCells][64], ce[kPackCells][64];  // the slice's cells: group, slot-area entry
   struct Bank {  // bank state of the current step: address held by each bank (all ones = free)
     uint32_t rg[4][16], rs[4][16], hg[2][32], at[4];
@@ -188,12 +197,15 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
   for (uint32_t s = blockIdx.x; s < nslices; s += gridDim.x) {
     const uint32_t o = slice_off[s], L = slice_off[s + 1] - o;
     const size_t base = (size_t)o * 64;
-    const uint32_t q = s * 64 + lane;
+    // this lane's cells: sub-lane t of the m lanes of its EC takes the EC's cells t, t + m, t + 2 m, ... (sell.hpp)
+    const SliceGeo sg = slice_geo(cls, s);
+    const uint32_t m = 1u << sg.lgm, t = (uint32_t)lane & (m - 1u);
     uint32_t b = 0, mylen = 0;
-    if (q < n_sell) {
-      const uint32_t j = perm[n_long + q];
-      b = rowptr[j];
-      mylen = rowptr[j + 1] - b;
+    if (((uint32_t)lane >> sg.lgm) < sg.nec) {
+      const uint32_t j = perm[n_long + sg.ec0 + ((uint32_t)lane >> sg.lgm)];
+      const uint32_t len = rowptr[j + 1] - rowptr[j];
+      b = rowptr[j] + t;
+      mylen = len > t ? (len - t + m - 1u) >> sg.lgm : 0u;
     }
     // A slice of up to 16 rows is one window; a longer one (the streaming path of the sweeps, which walks it in
     // chunks of 16 rows) is scheduled chunk by chunk: the cells [k0, k0 + 16) of every EC, in CSR order, go
@@ -206,8 +218,8 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
       const uint32_t ncell = mylen > k0 ? min((uint32_t)kPackCells, mylen - k0) : 0u;  // this lane's cells in the window
       uint32_t mycold = 0;
       for (uint32_t c = 0; c < ncell; ++c) {
-        cg[c][lane] = grp[b + k0 + c];
-        ce[c][lane] = pack_entry(pe, lane, idx[b + k0 + c]);
+        cg[c][lane] = grp[b + (size_t)(k0 + c) * m];
+        ce[c][lane] = pack_entry(pe, lane, idx[b + (size_t)(k0 + c) * m]);
         mycold += ce[c][lane] >= pe.n_hot;
       }
       uint32_t taken = 0, nhot = nrows;

@@ -40,6 +40,45 @@ namespace msw {
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kSentinels = 64;  // one sentinel group per lane: padding never shares an address
 
+// ---------------------------------------------------------------------------------------
+// Slice classes (round 3): an EC of up to 16 cells takes ONE lane of its slice; an EC of 17..256 cells takes
+// m = 2, 4, 8 or 16 lanes (the smallest m with cells <= 16 m; cell k of the EC in sub-lane k mod m, row k / m), so
+// that every slice has at most 16 rows and stays on the sweeps' register path: no second walk over the records
+// and no second gathers in pass B (the streaming path such ECs took before ran pass B at half the per-cell
+// rate), the m partial row sums meet in log2 m DPP steps inside a row of 16 lanes, and a slice holds 64 / m
+// ECs -- the chain of a wavefront that has few slices is m times shorter.  The ECs are sorted by descending
+// length, so the classes are contiguous: class c = 0..4 <-> m = 16 >> c.  s0 / p0: first slice / first EC position
+// (within the sliced part of the permuted order) of every class.
+// ---------------------------------------------------------------------------------------
+constexpr int kSliceClasses = 5;
+struct SliceClasses {
+  uint32_t s0[kSliceClasses + 1], p0[kSliceClasses + 1];
+};
+// class of an EC of `len` cells (multilane = false: every EC one lane -- the developer switch MSWEEP_MULTILANE=0)
+__host__ __device__ inline int slice_class_of(uint32_t len, bool multilane) {
+  if (!multilane || len <= 16) return 4;
+  return len <= 32 ? 3 : (len <= 64 ? 2 : (len <= 128 ? 1 : 0));
+}
+struct SliceGeo {
+  uint32_t lgm, ec0, nec;  // log2 lanes per EC; first EC position of the slice; ECs in it
+};
+__host__ __device__ inline SliceGeo slice_geo(const SliceClasses &C, uint32_t s) {
+  const uint32_t c = (s >= C.s0[1]) + (s >= C.s0[2]) + (s >= C.s0[3]) + (s >= C.s0[4]);
+  const uint32_t lgm = 4u - c, per = 64u >> lgm;
+  const uint32_t ec0 = C.p0[c] + (s - C.s0[c]) * per;
+  const uint32_t left = C.p0[c + 1] - ec0;
+  return SliceGeo{lgm, ec0, left < per ? left : per};
+}
+// slice and lane group of the EC at position q of the sliced part
+__host__ __device__ inline void slice_of_position(const SliceClasses &C, uint32_t q, uint32_t &s, uint32_t &lgm,
+                                                  uint32_t &first_lane) {
+  const uint32_t c = (q >= C.p0[1]) + (q >= C.p0[2]) + (q >= C.p0[3]) + (q >= C.p0[4]);
+  lgm = 4u - c;
+  const uint32_t per = 64u >> lgm, d = q - C.p0[c];
+  s = C.s0[c] + d / per;
+  first_lane = (d % per) << lgm;
+}
+
 struct SellDev {
   const uint32_t *rec;        // SELL records
   const uint32_t *slice_off;  // [nslices + 1], in units of 64 records
@@ -48,6 +87,7 @@ struct SellDev {
   const uint32_t *perm;       // [E] permuted position -> original EC index
   const double *cvec;         // [E] EC multiplicities, permuted order
   const uint8_t *c8;          // [E] the same as a byte; kC8Escape = not a small integer, read cvec
+  const uint8_t *c8s;         // [64 * nslices] the byte of the EC every slice lane works for (0: none): pass B's stream
   const uint32_t *area_slot;  // [n_area] LUT slot held by each 16-byte entry of the slot area
   const uint8_t *slice_hot;   // [nslices] index records: rows of the slice's hot segment (0: all from memory)
   uint32_t nslices, n_long, n_ecs, n_groups, n_lut, n_area;
@@ -55,6 +95,7 @@ struct SellDev {
   uint32_t shift, mask, bhi;  // record encoding (narrow: shift / lo mask; all: bhi = LDS byte offset of e_g[0])
   uint32_t bhiA;              // LDS byte offset of pass A's {e, w}[0] (2 * bhi but for index records)
   const double *lut_area;     // table value of every slot-area entry (utility kernels: the value of a cell)
+  SliceClasses cls;           // slice classes: lanes per EC (above)
 };
 
 constexpr uint32_t kC8Escape = 255;
@@ -73,6 +114,8 @@ constexpr int kLongRow = 256;  // ECs with more cells than this take the workgro
 constexpr int kColdRows = MSW_COLD_ROWS;  // index records: rows of a slice's cold segment, 2 or 4 (beyond: the whole slice from memory)
 static_assert(kColdRows == 2 || kColdRows == 4, "cold segments are cut in pairs of rows");
 constexpr uint32_t kGeoHotShift = 27;  // slice geometry in LDS: rows of the hot segment above the slice offset
+// ... and above the slice's rows (<= kLongRow): log2 lanes per EC, ECs in the slice (slice classes)
+constexpr uint32_t kGeoLgmShift = 10, kGeoNecShift = 13;
 
 // what a sweep needs to decode a record (SGPRs)
 struct RecDec {
@@ -182,12 +225,15 @@ __device__ __forceinline__ void for_each_cell(const SellDev &S, uint32_t p, F f)
       f(rec_grp<ENC>(S, r), rec_value<ENC>(S, r));
     }
   } else {
-    const uint32_t q = p - S.n_long, s = q >> 6, lane = q & 63;
+    uint32_t s, lgm, l0;
+    slice_of_position(S.cls, p - S.n_long, s, lgm, l0);
     const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;
     for (uint32_t k = 0; k < len; ++k) {
-      const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + lane);
-      const uint32_t g = rec_grp<ENC>(S, r);
-      if (g < S.n_groups) f(g, rec_value<ENC>(S, r));
+      for (uint32_t t = 0; t < (1u << lgm); ++t) {
+        const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + l0 + t);
+        const uint32_t g = rec_grp<ENC>(S, r);
+        if (g < S.n_groups) f(g, rec_value<ENC>(S, r));
+      }
     }
   }
 }
@@ -204,10 +250,12 @@ __device__ __forceinline__ void wave_cells(const SellDev &S, uint32_t p, uint32_
       f(rec_grp<ENC>(S, r), rec_value<ENC>(S, r));
     }
   } else {
-    const uint32_t q = p - S.n_long, s = q >> 6, le = q & 63;
+    uint32_t s, lgm, l0;
+    slice_of_position(S.cls, p - S.n_long, s, lgm, l0);
     const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;
-    for (uint32_t k = lane; k < len; k += 64) {
-      const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + le);
+    // a lane per (row, sub-lane) of the EC
+    for (uint32_t i = lane; i < (len << lgm); i += 64) {
+      const typename R::T r = R::load(S.rec, ((size_t)o0 + (i >> lgm)) * 64 + l0 + (i & ((1u << lgm) - 1u)));
       const uint32_t g = rec_grp<ENC>(S, r);
       if (g < S.n_groups) f(g, rec_value<ENC>(S, r));
     }

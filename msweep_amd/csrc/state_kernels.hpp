@@ -597,13 +597,24 @@ __device__ __forceinline__ uint8_t c8_of(double &c) {
   return (uint8_t)255;
 }
 
+// c8s: the byte again for every slice lane that works for the EC (sell.hpp slice classes: pass B reads it with the
+// slice, one byte per lane, whatever the class); nullptr: no slices (dense flavour)
+__device__ __forceinline__ void c8_to_lanes(uint8_t *c8s, const SliceClasses &cls, uint32_t n_long, uint32_t j, uint8_t b) {
+  if (!c8s || j < n_long) return;
+  uint32_t s, lgm, l0;
+  slice_of_position(cls, j - n_long, s, lgm, l0);
+  for (uint32_t i = 0; i < (1u << lgm); ++i) c8s[(size_t)s * 64 + l0 + i] = b;
+}
+
 __global__ __launch_bounds__(256) void k_cvec_from_logc(const double *logc, const uint32_t *perm,
-                                                       uint32_t E, double *cvec, uint8_t *c8, double *part) {
+                                                       uint32_t E, double *cvec, uint8_t *c8, double *part,
+                                                       SliceClasses cls, uint32_t n_long, uint8_t *c8s) {
   __shared__ double sh[32];
   double s = 0.0;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < E; j += gridDim.x * blockDim.x) {
     double c = exp(logc[perm ? perm[j] : j]);
     c8[j] = c8_of(c);
+    c8_to_lanes(c8s, cls, n_long, j, c8[j]);
     cvec[j] = c;
     s += c;
   }
@@ -612,12 +623,14 @@ __global__ __launch_bounds__(256) void k_cvec_from_logc(const double *logc, cons
 }
 
 __global__ __launch_bounds__(256) void k_cvec_from_counts(const uint32_t *cnt, const uint32_t *perm,
-                                                         uint32_t E, double *cvec, uint8_t *c8, double *part) {
+                                                         uint32_t E, double *cvec, uint8_t *c8, double *part,
+                                                         SliceClasses cls, uint32_t n_long, uint8_t *c8s) {
   __shared__ double sh[32];
   double s = 0.0;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < E; j += gridDim.x * blockDim.x) {
     double c = (double)cnt[perm ? perm[j] : j];
     c8[j] = c8_of(c);
+    c8_to_lanes(c8s, cls, n_long, j, c8[j]);
     cvec[j] = c;
     s += c;
   }

@@ -108,6 +108,7 @@ struct SliceBuf {
   // index records (sell.hpp): the rows of the slice's cold segment; r then holds the hot rows only
   typename Rec<ENC>::T rc[ENC == kEncIndex ? kColdRows : 1];
   uint32_t sl, o, len, nhot;
+  uint32_t lgm, nec;  // slice class (sell.hpp): log2 lanes per EC, ECs in the slice
   uint32_t c8;  // byte image of the EC's multiplicity (sell.hpp)
 };
 
@@ -209,7 +210,11 @@ struct SliceStream {
     pend = make_uint2(0, 0);  // past the wave's last slice: an empty slice
     if (i < n_mine) {
       const uint32_t sl = slice_at(i);
-      pend = make_uint2(S.slice_off[sl], S.slice_off[sl + 1]);
+      // (the slice's rows, and above them its class: lanes per EC, ECs -- a few vector operations per 64 slices
+      // here instead of scalar ones per slice in fetch())
+      const uint32_t o = S.slice_off[sl];
+      const SliceGeo sg = slice_geo(S.cls, sl);
+      pend = make_uint2(o, (S.slice_off[sl + 1] - o) | sg.lgm << kGeoLgmShift | sg.nec << kGeoNecShift);
       // index records: the rows of the slice's hot segment ride above its offset (< 2^27: checked at upload)
       if constexpr (ENC == kEncIndex) pend.x |= (uint32_t)S.slice_hot[sl] << kGeoHotShift;
     }
@@ -228,15 +233,17 @@ struct SliceStream {
     typedef __attribute__((address_space(3))) const v2u_t lds_cu2_t;
     const v2u_t oe = *(lds_cu2_t *)(size_t)(geo + j * 8);
     b.sl = slice_at(base + j);
+    const uint32_t oy = uniform(oe.y);
+    b.len = oy & ((1u << kGeoLgmShift) - 1u);
+    b.lgm = (oy >> kGeoLgmShift) & 7u;
+    b.nec = oy >> kGeoNecShift;
     if constexpr (ENC == kEncIndex) {
       const uint32_t ox = uniform(oe.x);
       b.o = ox & ((1u << kGeoHotShift) - 1u);
       b.nhot = ox >> kGeoHotShift;
-      b.len = uniform(oe.y) - b.o;
       if (b.len <= (uint32_t)kRegCells) load_slice_split(S.rec, (size_t)b.o * 64 + lane, b.len, b.nhot, b.r, b.rc, nullr);
     } else {
       b.o = uniform(oe.x);
-      b.len = uniform(oe.y) - b.o;
       if (b.len <= (uint32_t)kRegCells) load_slice<ENC>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r, nullr);
     }
     issue(b);
@@ -312,7 +319,7 @@ __device__ __forceinline__ void cellA(AccA &c, const double p0, const double e, 
 
 // ENC = kEncIndex (index records): the hybrid slot area -- TLDS is then false by convention, the LDS image
 // holds the hot head of the area (S.n_tab_lds entries) and the whole area lives in memory (sell.hpp).
-template <int ENC, bool GLDS, bool TLDS>
+template <int ENC, bool GLDS, bool TLDS, bool ML>
 __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *sc, SellDev S,
                                                        const double2 *ew_g, const double2 *tabA_g,
                                                        double *partA, GuardDev GD) {
@@ -376,7 +383,6 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   if (tid == 0) *(lds_u32_t *)(size_t)gcnt_off = 0u;
   __syncthreads();
 
-  const uint32_t n_sell = S.n_ecs - S.n_long;
   // (lanes past the end of a long EC, and the missing last row of an odd slice, take a record of the lane's own
   // sentinel group)
   const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
@@ -476,14 +482,24 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
         pairs_any(t, n);
       }
     }
-    if (sb.sl * 64 + lane < n_sell) {
+    // an EC over several lanes (sell.hpp slice classes): its partial sums meet; its first lane speaks for it
+    // (ML = false: every slice one lane per EC)
+    const uint32_t lgm = ML ? sb.lgm : 0u;
+    bool mine = ((uint32_t)lane >> lgm) < sb.nec;
+    if (ML && lgm != 0u) {
+      c.zs = group_sum(c.zs, lgm);
+      c.t1 = group_sum(c.t1, lgm);
+      c.t2 = group_sum(c.t2, lgm);
+      mine = mine && ((uint32_t)lane & ((1u << lgm) - 1u)) == 0u;
+    }
+    if (mine) {
       const double Zt = zbase + c.zs;
       if (Zt >= gthr) {
         const double iZ = ec_rcp(Zt);
         const double S1 = (b1 + c.t1) * iZ, S2 = (b2 + c.t2) * iZ;
         nn += S2 - S1 * S1;
       } else {
-        defer(S.n_long + sb.sl * 64 + lane);
+        defer(S.n_long + (ML ? slice_geo(S.cls, sb.sl).ec0 + ((uint32_t)lane >> lgm) : sb.sl * 64 + lane));
       }
     }
   };
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
 // 0 = e_g / column sums in global memory; 1 = in LDS, column sums right behind e_g;
 // 2 = in LDS, column sums at the fixed distance kAccFixed (an instruction immediate: one VALU
 // operation less per scattered cell; needs 8 * Gp <= kAccFixed).
-template <int ENC, int GMODE, bool TLDS>
+template <int ENC, int GMODE, bool TLDS, bool ML>
 __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
                                                        const double2 *tabB_g, double *partAcc,
                                                        double *partS, double *accGlobal, RangeB rg, GuardDev GD) {
@@ -732,13 +748,14 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   if (tid == 0) *(lds_u32_t *)(size_t)gcnt_off = 0u;
   __syncthreads();
 
-  const uint32_t n_sell = S.n_ecs - S.n_long;
+  const uint32_t n_lanes = S.nslices * 64u;
   const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
   stream.nullr = null_rec;
   auto issue = [&](SliceBuf<ENC> &sb) {
+    // (a byte per slice lane: the lanes of an EC that takes several hold the same one; lanes without an EC 0)
     const uint32_t q = sb.sl * 64 + lane;
-    const uint32_t cj = S.c8[S.n_long + (q < n_sell ? q : 0u)];
-    sb.c8 = q < n_sell ? cj : 0u;
+    const uint32_t cj = S.c8s[q < n_lanes ? q : 0u];
+    sb.c8 = q < n_lanes ? cj : 0u;
   };
   auto process = [&](SliceBuf<ENC> &sb) {
     const uint32_t o = sb.o, len = sb.len;
@@ -748,7 +765,8 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
     // wait for it at the first use of c (the EC epilogue of EVERY slice, escape or not) is vmcnt(0) and
     // drains the prefetch half-way through the slice
     if (__builtin_amdgcn_ballot_w64(sb.c8 == kC8Escape)) {
-      if (sb.c8 == kC8Escape) c = S.cvec[S.n_long + sb.sl * 64 + lane];
+      if (sb.c8 == kC8Escape)
+        c = S.cvec[S.n_long + (ML ? slice_geo(S.cls, sb.sl).ec0 + ((uint32_t)lane >> sb.lgm) : sb.sl * 64 + lane)];
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
     double zs = 0.0, hs = 0.0;
@@ -901,13 +919,25 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
           }
         }
       };
+      // an EC over several lanes (sell.hpp slice classes): its partial row sums meet in every one of them -- the
+      // same bits, so all take the same branches below -- and its first lane alone adds to the scalar sums
+      // (ML = false: every slice one lane per EC)
+      const uint32_t lgm = ML ? sb.lgm : 0u;
+      bool spoke = true;
+      if (ML && lgm != 0u) {
+        zs = group_sum(zs, lgm);
+        hs = group_sum(hs, lgm);
+        spoke = ((uint32_t)lane & ((1u << lgm) - 1u)) == 0u;
+      }
       if (c != 0.0 && !(zbase + zs >= gthr)) {
-        defer(S.n_long + sb.sl * 64 + lane);
+        if (spoke) defer(S.n_long + (ML ? slice_geo(S.cls, sb.sl).ec0 + ((uint32_t)lane >> lgm) : sb.sl * 64 + lane));
       } else if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
         const double rj = ec_div(c, Z);
-        s_rH += rj * H;
-        s_W += rj;
+        double rja = rj;  // what the scalar sums see of this lane
+        if (ML && lgm != 0u) rja = spoke ? rj : 0.0;
+        s_rH += rja * H;
+        s_W += rja;
         if constexpr (kFx) {
           const double rs = rj * fxs;
           // rs (Z + zbase) = 2^K (c + r_j zbase) and rs fxb against 2^51: two comparisons with per-pass constants
@@ -940,9 +970,11 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
             r *= (sb.c8 & 4u) ? m4 : 1.0;
             r *= (sb.c8 & 8u) ? m8 : 1.0;
           }
+          int ezc = ez * (int)sb.c8;
+          if (ML && lgm != 0u && !spoke) r = 1.0, ezc = 0;
           lp_mant *= r;  // >= 2^-15 per slice: 2^-960 between two flushes
-          lp_exp += ez * (int)sb.c8;
-        } else {
+          lp_exp += ezc;
+        } else if (spoke) {
           s_clogZ += c * log(Z);
         }
       }
@@ -965,8 +997,8 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t, null_rec);
         pairs_any(t, n);
       }
-      if (c != 0.0 && !(zbase + zs >= gthr)) {
-        defer(S.n_long + sb.sl * 64 + lane);
+      if (c != 0.0 && !(zbase + zs >= gthr)) {  // (slices of more than 16 rows hold one lane per EC: lgm = 0)
+        defer(S.n_long + (ML ? slice_geo(S.cls, sb.sl).ec0 : sb.sl * 64) + lane);
       } else if (c != 0.0) {
         const double Z = zbase + zs, H = hbase + hs;
         const double rj = ec_div(c, Z);

@@ -516,9 +516,14 @@ def test_unstructured_dense_matrix_beyond_the_dense_sweeps(gpu_core, oracle):
     np.testing.assert_array_equal(gpu_core.get_dense_logl(), L)
 
 
-def test_mid_length_ecs_streaming_path(gpu_core, oracle):
-    """ECs with 17..256 cells: slices too long for the register buffers take the streaming branch of
-    both sweeps (and odd lengths exercise the padding to an even slice length)."""
+@pytest.mark.parametrize("multilane", ["1", "0"])
+def test_mid_length_ecs_slice_classes_and_streaming_path(oracle, monkeypatch, multilane):
+    """ECs with 17..256 cells.  Default: they take 2, 4, 8 or 16 lanes of their slice (sell.hpp slice classes), every
+    slice stays within the 16 rows of the sweeps' register path and the partial row sums meet by DPP.
+    MSWEEP_MULTILANE=0: one lane per EC as for short ECs -- slices too long for the register buffers take the
+    streaming branch of both sweeps (odd lengths exercise the missing last row).  Both against the oracle, lock-step."""
+    monkeypatch.setenv("MSWEEP_MULTILANE", multilane)
+    gpu_core = Core(0)
     rng = np.random.default_rng(17)
     G = 700
     sizes = (1 + rng.poisson(4, G)).astype(np.uint64)
@@ -533,6 +538,14 @@ def test_mid_length_ecs_streaming_path(gpu_core, oracle):
     logc = np.log(rng.integers(1, 30, E).astype(float))
     alpha0 = rng.uniform(0.5, 2.0, G)
     gpu_core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
+    li = gpu_core.layout_info()
+    if multilane == "1":
+        # ECs of 129..256 / 65..128 / 33..64 / 17..32 / <= 16 cells: 4, 8, 16, 32, 64 to a slice
+        want = [int(np.ceil(np.sum((lens > lo) & (lens <= hi)) / per))
+                for lo, hi, per in ((128, 256, 4), (64, 128, 8), (32, 64, 16), (16, 32, 32), (-1, 16, 64))]
+        assert li["slices_by_lanes"] == want and li["max_rows"] <= 16
+    else:
+        assert li["slices_by_lanes"][:4] == [0, 0, 0, 0] and li["max_rows"] == 256
     gpu_core.set_trace_theta(15)
     res = gpu_core.solve(logc, alpha0)
     tr = gpu_core.trace(15, with_theta=True)
@@ -542,6 +555,24 @@ def test_mid_length_ecs_streaming_path(gpu_core, oracle):
     assert res["iters"] == ref["iters"]
     assert_theta(res["theta"], ref["theta"])
     np.testing.assert_allclose(np.exp(gpu_core.gamma()), np.exp(ref["gamma"]), atol=1e-7)
+    # fractional and large multiplicities (the escape byte: the EC's lanes all read its double) and a bootstrap-like
+    # count vector with zeros
+    logc2 = np.log(np.where(rng.random(E) < 0.3, rng.uniform(0.5, 400.0, E), rng.integers(0, 6, E).astype(float)) + 1e-300)
+    logc2[np.exp(logc2) < 1e-200] = -np.inf
+    res2 = gpu_core.solve(logc2, alpha0)
+    ref2 = oracle.rcg_optl_csr(rowptr, grp, lutidx, lut, np.log(0.01), G, logc2, alpha0)
+    assert abs(res2["iters"] - ref2["iters"]) <= 1
+    assert_theta(res2["theta"], ref2["theta"])
+    # bootstrap replicates: the resampled counts reach every lane of their EC (two replicates in flight share the records)
+    w = rng.integers(1, 30, E).astype(np.uint32)
+    theta, iters = gpu_core.bootstrap(w, 3, int(w.sum()), 0, 3, alpha0)
+    counts = oracle.bootstrap_counts(w, 3, int(w.sum()), 3)
+    for b in range(3):
+        with np.errstate(divide="ignore"):
+            refb = oracle.rcg_optl_csr(rowptr, grp, lutidx, lut, np.log(0.01), G, np.log(counts[b].astype(float)), alpha0)
+        assert abs(int(iters[b]) - refb["iters"]) <= 1
+        assert_theta(theta[b], refb["theta"])
+    gpu_core.close()
 
 
 def test_solves_are_bit_reproducible(gpu_core):
