@@ -809,6 +809,24 @@ void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, dou
 
 }  // namespace
 
+namespace {
+// MSWEEP_BUILD_TIMING=1 (developer switch): wall time of every stage of the build / the packer to stderr (each
+// mark drains the stream first, so the stages are what they say; off: no synchronisation, no output)
+struct StageTimer {
+  hipStream_t st;
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  explicit StageTimer(hipStream_t s) : st(s), on(getenv("MSWEEP_BUILD_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char *what) {
+    if (!on) return;
+    (void)hipStreamSynchronize(st);
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[msweep build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+}  // namespace
+
 #include "host_likelihood.inc"
 #include "host_pack.inc"
 #include "host_em.inc"

@@ -184,7 +184,10 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
                                                    const uint32_t *perm, const uint32_t *slice_off, uint32_t n_long,
                                                    uint32_t n_sell, uint32_t nslices, SliceClasses cls, PackEnc pe,
                                                    uint32_t *rec) {
-  __shared__ uint32_t cg[kPackCells][64], ce[kPackCells][64];  // the slice's cells: group, slot-area entry
+  // the slice's cells: group, slot-area entry -- [lane][cell], rows of 17 words (the 16 candidates of one lane are
+  // read by 16 lanes at once: consecutive banks)
+  constexpr int kRowW = kPackCells + 1;
+  __shared__ uint32_t cg[64 * kRowW], ce[64 * kRowW];
   struct Bank {  // bank state of the current step: address held by each bank (all ones = free)
     uint32_t rg[4][16], rs[4][16], hg[2][32], at[4];
   };
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
   auto &hg = bk.hg;
   auto &at = bk.at;
   const int lane = threadIdx.x;
+  const uint32_t cand = (uint32_t)lane & 15u;  // the candidate cell this lane scores in a turn (lanes 0..15)
   for (uint32_t s = blockIdx.x; s < nslices; s += gridDim.x) {
     const uint32_t o = slice_off[s], L = slice_off[s + 1] - o;
     const size_t base = (size_t)o * 64;
@@ -218,9 +222,10 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
       const uint32_t ncell = mylen > k0 ? min((uint32_t)kPackCells, mylen - k0) : 0u;  // this lane's cells in the window
       uint32_t mycold = 0;
       for (uint32_t c = 0; c < ncell; ++c) {
-        cg[c][lane] = grp[b + (size_t)(k0 + c) * m];
-        ce[c][lane] = pack_entry(pe, lane, idx[b + (size_t)(k0 + c) * m]);
-        mycold += ce[c][lane] >= pe.n_hot;
+        const uint32_t e = pack_entry(pe, lane, idx[b + (size_t)(k0 + c) * m]);
+        cg[lane * kRowW + c] = grp[b + (size_t)(k0 + c) * m];
+        ce[lane * kRowW + c] = e;
+        mycold += e >= pe.n_hot;
       }
       uint32_t taken = 0, nhot = nrows;
       if constexpr (ENC == kEncIndex) {
@@ -231,38 +236,62 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
           if (lane == 0) pe.slice_hot[s] = (uint8_t)nhot;
         }
       }
+      // One step = one row: the lanes take their turns one after the other (rotating priority).  A turn is worked
+      // by the whole wavefront: lane c scores candidate c of the lane whose turn it is (its unplaced cells: at most
+      // 16), a DPP row maximum picks the winner -- the highest score, the first such cell -- and the winner enters
+      // the bank state.  (Until round 3 the lane whose turn it was walked its candidates alone, the other 63 idle:
+      // 230 instructions per turn, 34 ms of packing at cfg3; same choices, bit for bit: the layout-hash tests
+      // against the host packer.)
       for (uint32_t k = 0; k < nhot; ++k) {
-        for (int t = lane; t < 196; t += 64) reinterpret_cast<uint32_t *>(&bk)[t] = t < 192 ? 0xffffffffu : 0u;
+        for (int w = lane; w < 196; w += 64) reinterpret_cast<uint32_t *>(&bk)[w] = w < 192 ? 0xffffffffu : 0u;
         uint32_t pick_g = pe.n_groups + lane, pick_e = kPackPad;
         __syncthreads();
         for (int li = 0; li < 64; ++li) {
           const int l = (li + (int)(k0 + k) * 7) & 63;  // rotate the priority
-          if (lane == l) {
-            int best = -1, best_score = -1;
-            for (uint32_t c = 0; c < ncell; ++c) {
-              if (taken >> c & 1) continue;
-              const uint32_t g = cg[c][lane], i = ce[c][lane];
-              if (ENC == kEncIndex && !streaming && i >= pe.n_hot) continue;  // a cold cell: not in the hot segment
-              int score = 0;
-              if (!(at[C] >> (g & 15) & 1)) score += MSW_W_AT;                              // atomic: bank pair free
-              if (rg[R][g & 15] == 0xffffffffu || rg[R][g & 15] == g) score += MSW_W_EW;   // {e,w} b128
-              if (ENC == kEncValue || rs[R][i & 15] == 0xffffffffu || rs[R][i & 15] == i) score += MSW_W_XT;   // slot entry b128
-              if (hg[H][g & 31] == 0xffffffffu || hg[H][g & 31] == g) score += MSW_W_E;   // e_g b64
-              if (score > best_score) {
-                best_score = score;
-                best = (int)c;
-                if (score == MSW_W_AT + MSW_W_EW + MSW_W_XT + MSW_W_E) break;
-              }
+          const uint32_t n_l = (uint32_t)__builtin_amdgcn_readlane((int)ncell, l);
+          const uint32_t t_l = (uint32_t)__builtin_amdgcn_readlane((int)taken, l);
+          if (n_l == 0 || (t_l & ((1u << n_l) - 1u)) == ((1u << n_l) - 1u)) continue;  // nothing left to place
+          const int R_l = __builtin_amdgcn_readlane(R, l), C_l = l >> 4, H_l = l >> 5;
+          bool valid = lane < 16 && cand < n_l && !(t_l >> cand & 1u);
+          uint32_t g = 0, i = 0, v_at = 0, v_rg = 0, v_rs = 0, v_hg = 0, key = 0;
+          if (valid) {
+            g = cg[l * kRowW + cand];
+            i = ce[l * kRowW + cand];
+            if (ENC == kEncIndex && !streaming && i >= pe.n_hot) valid = false;  // a cold cell: not in the hot segment
+          }
+          if (valid) {
+            v_at = at[C_l];
+            v_rg = rg[R_l][g & 15];
+            v_rs = rs[R_l][i & 15];
+            v_hg = hg[H_l][g & 31];
+            uint32_t score = 0;
+            if (!(v_at >> (g & 15) & 1)) score += MSW_W_AT;                               // atomic: bank pair free
+            if (v_rg == 0xffffffffu || v_rg == g) score += MSW_W_EW;                      // {e,w} b128
+            if (ENC == kEncValue || v_rs == 0xffffffffu || v_rs == i) score += MSW_W_XT;  // slot entry b128
+            if (v_hg == 0xffffffffu || v_hg == g) score += MSW_W_E;                       // e_g b64
+            key = ((score << 4) | (15u - cand)) + 1u;  // the highest score; among equals the first cell
+          }
+          // row maximum of lanes 0..15 -> lane 15 (row_shr 1, 2, 4, 8; lanes shifted in from outside read 0)
+          uint32_t mx = key;
+          mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x111, 0xf, 0xf, false));
+          mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x112, 0xf, 0xf, false));
+          mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x114, 0xf, 0xf, false));
+          mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x118, 0xf, 0xf, false));
+          const uint32_t best = (uint32_t)__builtin_amdgcn_readlane((int)mx, 15);
+          if (best != 0) {
+            const int cb = 15 - (int)((best - 1u) & 15u);
+            const uint32_t g_w = (uint32_t)__builtin_amdgcn_readlane((int)g, cb);
+            const uint32_t i_w = (uint32_t)__builtin_amdgcn_readlane((int)i, cb);
+            if (lane == cb) {  // the winner holds the bank words it has just read
+              at[C_l] = v_at | 1u << (g & 15);
+              if (v_rg == 0xffffffffu) rg[R_l][g & 15] = g;
+              if (v_rs == 0xffffffffu) rs[R_l][i & 15] = i;
+              if (v_hg == 0xffffffffu) hg[H_l][g & 31] = g;
             }
-            if (best >= 0) {
-              taken |= 1u << best;
-              const uint32_t g = cg[best][lane], i = ce[best][lane];
-              at[C] |= 1u << (g & 15);
-              if (rg[R][g & 15] == 0xffffffffu) rg[R][g & 15] = g;
-              if (rs[R][i & 15] == 0xffffffffu) rs[R][i & 15] = i;
-              if (hg[H][g & 31] == 0xffffffffu) hg[H][g & 31] = g;
-              pick_g = g;
-              pick_e = i;
+            if (lane == l) {
+              taken |= 1u << cb;
+              pick_g = g_w;
+              pick_e = i_w;
             }
           }
           __syncthreads();
@@ -275,7 +304,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
       for (uint32_t k = nhot; k < nrows; ++k) {
         while (c < ncell && (taken >> c & 1)) ++c;
         if (c < ncell) {
-          pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, cg[c][lane], ce[c][lane]);
+          pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, cg[lane * kRowW + c], ce[lane * kRowW + c]);
           ++c;
         } else {
           pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, pe.n_groups + lane, kPackPad);

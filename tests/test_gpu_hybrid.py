@@ -140,3 +140,37 @@ def test_hybrid_with_many_groups(oracle, G):
         lockstep(tr, ref["trace"], 20)
         assert res["iters"] == ref["iters"]
         assert_theta(res["theta"], ref["theta"])
+
+
+@pytest.mark.parametrize("multilane", ["1", "0"])
+def test_hybrid_with_mid_length_ecs(oracle, monkeypatch, multilane):
+    """Index records AND ECs of 17..256 cells: slices of 2..16 lanes per EC cut into hot and cold segments like any
+    other (MSWEEP_MULTILANE=0: the streaming branch, every table entry from memory), a few ECs beyond 256 cells."""
+    monkeypatch.setenv("MSWEEP_FORCE_LDS", "10")
+    monkeypatch.setenv("MSWEEP_HYBRID_HOT", "256")
+    monkeypatch.setenv("MSWEEP_MULTILANE", multilane)
+    rng = np.random.default_rng(8)
+    G, E = 600, 4000
+    sizes = np.minimum(1 + rng.lognormal(3.0, 1.2, G).astype(np.int64), 400).astype(np.uint64)
+    lens = rng.integers(0, 17, E)
+    lens[rng.choice(E, 1500, replace=False)] = rng.integers(17, 257, 1500)
+    lens[rng.choice(E, 6, replace=False)] = rng.integers(257, 500, 6)
+    lut = precalc_lls(sizes)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    grp = np.concatenate([np.sort(rng.choice(G, k, replace=False)) for k in lens]).astype(np.uint32)
+    cnt = rng.integers(1, sizes[grp] + 1).astype(np.uint32)
+    logc = np.log(rng.integers(1, 40, E).astype(float))
+    alpha0 = rng.uniform(0.5, 2.0, G)
+    with Core(0) as core:
+        core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
+        li = core.layout_info()
+        assert li["index_records"] == 1 and li["slot_entries_in_lds"] == 256, li
+        assert (sum(li["slices_by_lanes"][:4]) > 0) == (multilane == "1")
+        core.set_trace_theta(15)
+        res = core.solve(logc, alpha0)
+        tr = core.trace(15, with_theta=True)
+        lutidx = (grp * lut.shape[1] + cnt).astype(np.uint32)
+        ref = oracle.rcg_optl_csr(rowptr, grp, lutidx, lut, np.log(0.01), G, logc, alpha0, trace=15)
+        lockstep(tr, ref["trace"], 15)
+        assert res["iters"] == ref["iters"]
+        assert_theta(res["theta"], ref["theta"])
