@@ -110,21 +110,132 @@ __global__ __launch_bounds__(256) void k_lut_build(const uint32_t *class_size, u
 }
 
 // ---- K1: per-EC group counts ------------------------------------------------------------------
-// Short ECs (<= 64 hits): one wavefront per EC, lane l holds the group of hit l.
+// Three paths by the number of hits of an EC:
+//   <= 16 : one THREAD per EC -- the groups of its hits sorted by a 16-key network in registers, runs of equal
+//           groups counted (most ECs of an alignment: 12 hits on average at cfg5; until round 3 these took a
+//           wavefront each with 12 of 64 lanes busy: 30 ms of the build);
+//   17..64: one wavefront per EC, lane l holds the group of hit l;
+//   > 64  : one workgroup per EC, histogram over the groups.
+// The first pass of the thread kernel sorts the ECs into the three paths (id lists appended per wavefront) and checks
+// what the host used to walk the arrays for: ec_tptr monotone, target ids in range.
 //   EMIT = false: nd[i] = number of distinct groups;
 //   EMIT = true : (group, count) pairs written at rowptr[i] in ascending group order.
+constexpr uint32_t kEcThreadMax = 16, kEcWaveMax = 64;
+enum : uint32_t { kCtrBad = 0, kCtrMid = 1, kCtrLong = 2, kBuildCtrs = 4 };
+enum : uint32_t { kBadTptr = 1, kBadTarget = 2 };
+
+// bitonic sorting network, 16 keys in registers, ascending
+__device__ __forceinline__ void sort16(uint32_t (&v)[16]) {
+#pragma unroll
+  for (int k = 2; k <= 16; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const uint32_t lo = min(v[i], v[l]), hi = max(v[i], v[l]);
+          const bool up = (i & k) == 0;
+          v[i] = up ? lo : hi;
+          v[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+}
+
+// append `id` to a list for every lane with `want` set: one atomic per wavefront
+__device__ __forceinline__ void wave_append(bool want, uint32_t id, uint32_t *list, uint32_t *counter) {
+  const unsigned long long m = __ballot(want);
+  if (m == 0) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = id;
+}
+
 template <bool EMIT>
-__global__ __launch_bounds__(256) void k_ec_groups_wave(const uint64_t *tptr, const uint32_t *targets,
-                                                       const uint32_t *tgroup, uint32_t E, uint32_t *nd,
-                                                       const uint32_t *rowptr, uint32_t *out_grp,
-                                                       uint32_t *out_cnt) {
+__global__ __launch_bounds__(256) void k_ec_groups_thread(const uint64_t *tptr, const uint32_t *targets,
+                                                         const uint32_t *tgroup, uint32_t E, uint32_t T, uint64_t ntot,
+                                                         uint32_t *nd, const uint32_t *rowptr, uint32_t *out_grp,
+                                                         uint32_t *out_cnt, uint32_t *mid_ids, uint32_t *long_ids,
+                                                         uint32_t *ctr) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  // (every lane of a wavefront runs the same number of rounds: the list appends are wave operations)
+  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < E; i0 += stride) {
+    const uint32_t i = i0 + threadIdx.x;
+    const bool in = i < E;
+    uint64_t b = 0, e = 0;
+    if (in) b = tptr[i], e = tptr[i + 1];
+    const bool broken = e < b || e > ntot;  // (no EC of a broken ec_tptr is read: every access stays inside ec_targets)
+    const uint64_t n64 = broken ? 0 : e - b;
+    if (!EMIT) {
+      if (broken) atomicOr(&ctr[kCtrBad], kBadTptr);
+      wave_append(in && n64 > kEcThreadMax && n64 <= kEcWaveMax, i, mid_ids, &ctr[kCtrMid]);
+      wave_append(in && n64 > kEcWaveMax, i, long_ids, &ctr[kCtrLong]);
+      if (in && n64 == 0) nd[i] = 0;
+    }
+    if (!in || n64 == 0 || n64 > kEcThreadMax) continue;
+    const uint32_t n = (uint32_t)n64;
+    uint32_t v[16];
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+      v[k] = 0xffffffffu;
+      if (k < n) {
+        uint32_t t = targets[b + k];
+        if (t >= T) {
+          if (!EMIT) atomicOr(&ctr[kCtrBad], kBadTarget);
+          t = 0;
+        }
+        v[k] = tgroup[t];
+      }
+    }
+    sort16(v);
+    if (!EMIT) {
+      uint32_t d = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) d += (uint32_t)k < n && (k == 0 || v[k] != v[k - 1]);
+      nd[i] = d;
+    } else {
+      uint32_t o = rowptr[i], run = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if ((uint32_t)k < n) {
+          ++run;
+          if ((uint32_t)k + 1 == n || v[(k + 1) & 15] != v[k]) {  // the last hit of its group
+            out_grp[o] = v[k];
+            out_cnt[o] = run;
+            ++o;
+            run = 0;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ECs of 17..64 hits (the list the thread kernel made): one wavefront per EC, lane l holds the group of hit l.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_ec_groups_wave(const uint32_t *ids, uint32_t n_ids, const uint64_t *tptr,
+                                                       const uint32_t *targets, const uint32_t *tgroup, uint32_t T,
+                                                       uint32_t *nd, const uint32_t *rowptr, uint32_t *out_grp,
+                                                       uint32_t *out_cnt, uint32_t *ctr) {
   const int lane = threadIdx.x & 63;
   const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-  for (uint32_t i = gw; i < E; i += nw) {
+  for (uint32_t r = gw; r < n_ids; r += nw) {
+    const uint32_t i = ids[r];
     const uint64_t b = tptr[i];
-    const uint32_t n = (uint32_t)(tptr[i + 1] - b);
-    if (n > 64) continue;  // workgroup path
-    const uint32_t g = (uint32_t)lane < n ? tgroup[targets[b + lane]] : 0xffffffffu;
+    const uint32_t n = (uint32_t)(tptr[i + 1] - b);  // 17..64
+    uint32_t g = 0xffffffffu;
+    if ((uint32_t)lane < n) {
+      uint32_t t = targets[b + lane];
+      if (t >= T) {
+        if (!EMIT) atomicOr(&ctr[kCtrBad], kBadTarget);
+        t = 0;
+      }
+      g = tgroup[t];
+    }
     uint32_t cnt = 0;
     bool first = (uint32_t)lane < n;
     for (uint32_t k = 0; k < n; ++k) {
@@ -157,9 +268,9 @@ __global__ __launch_bounds__(256) void k_ec_groups_wave(const uint64_t *tptr, co
 template <bool EMIT>
 __global__ __launch_bounds__(256) void k_ec_groups_long(const uint32_t *long_ids, uint32_t n_long,
                                                        const uint64_t *tptr, const uint32_t *targets,
-                                                       const uint32_t *tgroup, uint32_t G, uint32_t *scratch,
-                                                       uint32_t *nd, const uint32_t *rowptr,
-                                                       uint32_t *out_grp, uint32_t *out_cnt) {
+                                                       const uint32_t *tgroup, uint32_t G, uint32_t T,
+                                                       uint32_t *scratch, uint32_t *nd, const uint32_t *rowptr,
+                                                       uint32_t *out_grp, uint32_t *out_cnt, uint32_t *ctr) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t sh[40];
   uint32_t *H = scratch ? scratch + (size_t)blockIdx.x * G : reinterpret_cast<uint32_t *>(smem);
@@ -168,7 +279,14 @@ __global__ __launch_bounds__(256) void k_ec_groups_long(const uint32_t *long_ids
     const uint64_t b = tptr[i], e = tptr[i + 1];
     for (uint32_t g = threadIdx.x; g < G; g += 256) H[g] = 0;
     __syncthreads();
-    for (uint64_t k = b + threadIdx.x; k < e; k += 256) atomicAdd(&H[tgroup[targets[k]]], 1u);
+    for (uint64_t k = b + threadIdx.x; k < e; k += 256) {
+      uint32_t t = targets[k];
+      if (t >= T) {
+        if (!EMIT) atomicOr(&ctr[kCtrBad], kBadTarget);
+        t = 0;
+      }
+      atomicAdd(&H[tgroup[t]], 1u);
+    }
     __syncthreads();
     uint32_t run = 0;
     for (uint32_t base = 0; base < G; base += 256) {
@@ -190,13 +308,27 @@ __global__ __launch_bounds__(256) void k_ec_groups_long(const uint32_t *long_ids
 }
 
 // ---- K2: --min-hits ---------------------------------------------------------------------------
-// hits_g = sum over ECs hitting g of reads_in_ec (include/Likelihood.hpp:149-154); integer atomics.
-__global__ __launch_bounds__(256) void k_group_hits(const uint32_t *rowptr, const uint32_t *grp, uint32_t E,
-                                                   const uint64_t *ec_counts, unsigned long long *hits) {
+// hits_g = sum over ECs hitting g of reads_in_ec (include/Likelihood.hpp:149-154); integer atomics -- into a
+// histogram in LDS over the groups [g0, g0 + ng) (one workgroup per CU; 64-bit LDS atomics), flushed once per
+// workgroup.  (Until round 3: one global atomic per cell on G addresses, 18 ms at cfg5.)
+constexpr uint32_t kHitsGroups = 16384;  // groups per pass: 128 KB of LDS
+__global__ __launch_bounds__(1024) void k_group_hits(const uint32_t *rowptr, const uint32_t *grp, uint32_t E,
+                                                    const uint64_t *ec_counts, uint32_t g0, uint32_t ng,
+                                                    unsigned long long *hits) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned long long *H = reinterpret_cast<unsigned long long *>(smem);
+  for (uint32_t g = threadIdx.x; g < ng; g += blockDim.x) H[g] = 0ull;
+  __syncthreads();
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x) {
     const unsigned long long c = ec_counts[i];
-    for (uint32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) atomicAdd(&hits[grp[k]], c);
+    for (uint32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      const uint32_t g = grp[k] - g0;
+      if (g < ng) atomicAdd(&H[g], c);
+    }
   }
+  __syncthreads();
+  for (uint32_t g = threadIdx.x; g < ng; g += blockDim.x)
+    if (H[g]) atomicAdd(&hits[g0 + g], H[g]);
 }
 
 // cells of kept groups per EC (count), then compaction with group ids remapped to their position

@@ -88,6 +88,17 @@ def test_build_error_behaviour(gpu_core):
     with pytest.raises(MswError, match="group indicator out of range"):
         gpu_core.build_likelihood(tptr, np.array([0, 1], np.uint32), np.array([0, 5, 1], np.uint32),
                                   np.array([2, 1], np.uint64), np.array([3], np.uint64))
+    # (the pointer and target checks run on the device, in the kernel that reads them: every length class of EC)
+    for n_hits in (20, 70):   # an EC of 17..64 hits (one wavefront), of more than 64 (one workgroup)
+        tg = np.zeros(n_hits, np.uint32)
+        tg[-1] = 9
+        with pytest.raises(MswError, match="target id out of range"):
+            gpu_core.build_likelihood(np.array([0, n_hits], np.uint64), tg, np.array([0, 0, 1], np.uint32),
+                                      np.array([2, 1], np.uint64), np.array([3], np.uint64))
+    with pytest.raises(MswError, match="ec_tptr not monotone"):
+        # the second EC ends before it starts; the first one would reach past the 3 targets there are
+        gpu_core.build_likelihood(np.array([0, 5, 3], np.uint64), np.array([0, 1, 2], np.uint32),
+                                  np.array([0, 0, 1], np.uint32), np.array([2, 1], np.uint64), np.array([3, 1], np.uint64))
     with pytest.raises(MswError, match="more sequences of a group"):
         # the same target listed twice: count 2 for a group of size 1
         gpu_core.build_likelihood(tptr, np.array([2, 2], np.uint32), np.array([0, 0, 1], np.uint32),
