@@ -280,6 +280,10 @@ typedef struct msw_bootstrap_timing {
   uint64_t iterations;  /* summed over them */
 } msw_bootstrap_timing;
 int msw_core_last_bootstrap_timing(msw_handle h, msw_bootstrap_timing *out);
+/* Reporting (tests, diagnostics): how many equivalence classes pass B has evaluated through the cancellation guard
+ * (Z formed over every group instead of background + listed cells) since the likelihood became
+ * resident on this handle, summed over the iterations.  No reference counterpart. */
+int msw_core_guarded_visits(msw_handle h, uint64_t *out);
 /* Measurement only (bench.py's roofline object): the streaming rates this device reaches on n_bytes of HBM --
  * a read-only 16-byte-load sweep (the shape of the sweeps' record stream) and the triad a = b + 3 c -- best of
  * `reps` launches after two warm-up launches, in GB/s (1e9).  SURVEY.md 8(d): the practical ceiling beside the

@@ -28,7 +28,7 @@ EXPORTS = [
     "msw_core_set_fixed_iters", "msw_core_hbm_stream_rates", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
     "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
     "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_core_continue", "msw_core_gamma_block",
-    "msw_core_last_bootstrap_timing", "msw_core_layout_info",
+    "msw_core_last_bootstrap_timing", "msw_core_layout_info", "msw_core_guarded_visits",
 ]
 
 
@@ -129,6 +129,7 @@ def load_library():
     L.msw_core_hbm_stream_rates.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.msw_core_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.msw_core_last_bootstrap_timing.argtypes = [vp, C.POINTER(BootstrapTiming)]
+    L.msw_core_guarded_visits.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.msw_core_layout_info.argtypes = [vp, C.POINTER(LayoutInfo)]
     L.msw_comm_unique_id.argtypes = [vp]
     L.msw_comm_create_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
@@ -412,6 +413,12 @@ class Core:
         t = Timing()
         self._check(self._L.msw_core_last_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def guarded_visits(self):
+        """ECs pass B has taken through the cancellation guard since the likelihood became resident (all iterations)."""
+        out = C.c_uint64(0)
+        self._check(self._L.msw_core_guarded_visits(self._h, C.byref(out)))
+        return int(out.value)
 
     def last_bootstrap_timing(self):
         t = BootstrapTiming()

@@ -91,10 +91,11 @@ struct msw_core {
   DevBuf<uint32_t> guard_list, guard_bits;
   DevBuf<unsigned long long> guard_tail;  // [2 G] the guarded ECs' shares per group, two fixed-point limbs
   DevBuf<int> guard_err;
+  DevBuf<unsigned long long> guard_visits;
   DevBuf<double> trange;  // {max, min} of the table values (bounds x_i = exp(a T_i) per pass: Scalars::xb)
   uint32_t guard_cap = 0, guard_words = 0;
   GuardDev guard_view() const {
-    return GuardDev{guard_list.p, guard_bits.p, guard_tail.p, lut_area.p, guard_err.p, guard_cap, guard_words};
+    return GuardDev{guard_list.p, guard_bits.p, guard_tail.p, lut_area.p, guard_err.p, guard_visits.p, guard_cap, guard_words};
   }
   DevBuf<Scalars> sc;
   Scalars *sc_host = nullptr;  // pinned
@@ -376,6 +377,8 @@ void alloc_solve_state(msw_core *h) {
   }
   h->guard_err.alloc(1);
   h->guard_err.zero(h->stream);
+  h->guard_visits.alloc(1);
+  h->guard_visits.zero(h->stream);
   h->sc.alloc(1);
   h->tr_bound.alloc(kMaxTrace);
   h->tr_newnorm.alloc(kMaxTrace);
@@ -1136,6 +1139,17 @@ int msw_core_last_timing(msw_handle h, msw_timing *out) {
   return guarded(h, [&] {
     if (!out) throw Fail("null out");
     *out = h->timing;
+  });
+}
+
+int msw_core_guarded_visits(msw_handle h, uint64_t *out) {
+  return guarded(h, [&] {
+    if (!out) throw Fail("null out");
+    if (h->flavor != 0) throw Fail("msw_core_guarded_visits: no CSR-of-ECs likelihood resident");
+    unsigned long long v = 0;
+    MSW_HIP(hipStreamSynchronize(h->stream));
+    MSW_HIP(hipMemcpy(&v, h->guard_visits.p, sizeof v, hipMemcpyDeviceToHost));
+    *out = v;
   });
 }
 

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
     // into the rows [k0, k0 + 16).  (Round 3: such slices used to keep the CSR order.)
     const bool streaming = L > (uint32_t)kPackCells;
     if (ENC == kEncIndex && lane == 0) pe.slice_hot[s] = 0;  // streaming and empty slices; a short one overwrites it
-    const int R = kRGroupDev[lane], C = lane >> 4, H = lane >> 5;
+    const int R = kRGroupDev[lane];  // (of the lane whose turn it is: read across; its C and H groups are l >> 4, l >> 5)
     for (uint32_t k0 = 0; k0 < L; k0 += kPackCells) {
       const uint32_t nrows = min((uint32_t)kPackCells, L - k0);
       const uint32_t ncell = mylen > k0 ? min((uint32_t)kPackCells, mylen - k0) : 0u;  // this lane's cells in the window

@@ -281,6 +281,7 @@ struct GuardDev {
   unsigned long long *tail;  // [2 * G] the guarded ECs' shares per group, two fixed-point limbs (pass B)
   const double *lut_area;  // table value of every slot-area entry
   int *err;                // set when an EC has no probability under any group
+  unsigned long long *visits;  // ECs pass B has taken through the guard path so far (reporting: msw_core_guarded_visits)
   uint32_t cap, words;
 };
 

@@ -1150,6 +1150,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   __syncthreads();
   const uint32_t n_guard = (GMODE != 4 || rg.first) ? min(*(lds_u32_t *)(size_t)gcnt_off, GD.cap) : 0u;  // once, not per range run
   if (n_guard) {
+    if (tid == 0) atomicAdd(GD.visits, (unsigned long long)n_guard);
     const uint32_t wv = uniform(tid >> 6), nwv = NT / 64;
     uint32_t *bits = GD.bits + (size_t)(blockIdx.x * 16 + wv) * GD.words;
     const double a = uniform_d(sc->a), logzi = uniform_d(sc->logzi), tref = uniform_d(sc->tref);

@@ -19,13 +19,13 @@ pytestmark = pytest.mark.gpu
 LOGZI = np.log(0.01)
 
 
-def isolate_problem(seed, n_ecs=6000, G=40, deep=-55.0, n_levels=6):
+def isolate_problem(seed, n_ecs=6000, G=40, deep=-55.0, n_levels=6, others=(0, 4), other_values=(-6.0, -0.1)):
     """One dominant group (0) listed in most ECs -- strongly (table value near 0) or weakly (`deep`, far
-    below log(zi) = -4.6) -- plus a few other groups per EC with ordinary values."""
+    below log(zi) = -4.6) -- plus a few other groups per EC (`others`: how many, lo..hi-1) with ordinary values."""
     rng = np.random.default_rng(seed)
     lut = np.empty((G, n_levels + 1))
     lut[:, 0] = LOGZI
-    lut[:, 1:] = rng.uniform(-6.0, -0.1, (G, n_levels))
+    lut[:, 1:] = rng.uniform(*other_values, (G, n_levels))
     lut[0, 1] = deep                  # the dominant group's weak hit
     lut[0, 2] = deep / 2
     lut[0, 3:] = rng.uniform(-1.0, -0.05, n_levels - 2)
@@ -47,7 +47,7 @@ def isolate_problem(seed, n_ecs=6000, G=40, deep=-55.0, n_levels=6):
             counts[j] = 1
         else:                         # a read that does not list the dominant group at all
             counts[j] = rng.integers(1, 3)
-        for g in rng.choice(np.arange(2, G), rng.integers(0, 4), replace=False):
+        for g in rng.choice(np.arange(2, G), rng.integers(*others), replace=False):
             cells[int(g)] = int(rng.integers(1, n_levels + 1))
         if not cells:
             cells[int(rng.integers(2, G))] = 1
@@ -71,7 +71,20 @@ def dense_of(p):
 @pytest.mark.parametrize("alpha,deep,zero_counts", [(1.0, -55.0, False), (0.5, -55.0, True), (0.01, -55.0, False),
                                                     (1e-3, -120.0, True), (0.01, -30.0, False)])
 def test_dominant_group_matches_dense_state_oracle(gpu_core, oracle, alpha, deep, zero_counts):
-    p = isolate_problem(seed=int(-deep) + int(alpha * 1000), deep=deep)
+    _check_dominant(gpu_core, oracle, isolate_problem(seed=int(-deep) + int(alpha * 1000), deep=deep), alpha, deep, zero_counts)
+
+
+@pytest.mark.parametrize("alpha,deep,zero_counts", [(0.5, -55.0, True), (0.01, -55.0, False)])
+def test_dominant_group_with_mid_length_ecs(gpu_core, oracle, alpha, deep, zero_counts):
+    """The guarded ECs of slices that hold several lanes per EC (17..256 cells: sell.hpp slice classes): the EC's
+    first lane hands it to the guard path, which walks the EC's cells over its lanes."""
+    p = isolate_problem(seed=77 + int(alpha * 1000), n_ecs=3000, G=150, deep=deep, others=(18, 120), other_values=(-16.0, -8.0))
+    visits = _check_dominant(gpu_core, oracle, p, alpha, deep, zero_counts)
+    assert sum(gpu_core.layout_info()["slices_by_lanes"][:4]) > 0
+    assert visits > 0          # the guard path of multi-lane slices is what this test is about
+
+
+def _check_dominant(gpu_core, oracle, p, alpha, deep, zero_counts):
     G = p["G"]
     alpha0 = np.full(G, alpha)
     with np.errstate(divide="ignore"):
@@ -82,6 +95,7 @@ def test_dominant_group_matches_dense_state_oracle(gpu_core, oracle, alpha, deep
     gpu_core.set_csr(p["rowptr"], p["grp"], p["cnt"], p["lut"], LOGZI, G)
     gpu_core.set_trace_theta(20)
     res = gpu_core.solve(logc, alpha0)
+    visits = gpu_core.guarded_visits()
     tr = gpu_core.trace(20, with_theta=True)
     gpu_core.set_trace_theta(0)
     lutidx = (p["grp"] * p["lut"].shape[1] + p["cnt"]).astype(np.uint32)
@@ -90,7 +104,7 @@ def test_dominant_group_matches_dense_state_oracle(gpu_core, oracle, alpha, deep
     th_d = oracle.mixture_components(d["gamma"], logc)
     big = th_d >= 1e-4
     worst = np.max(np.abs(res["theta"] - th_d)[big] / th_d[big])
-    print(f"alpha {alpha}, deepest cell {deep}: theta[0] = 1 - {1 - th_d[0]:.3e}; iterations hip {res['iters']} / "
+    print(f"alpha {alpha}, deepest cell {deep}: {visits} guarded EC evaluations; theta[0] = 1 - {1 - th_d[0]:.3e}; iterations hip {res['iters']} / "
           f"structured oracle {s['iters']} / dense-state oracle {d['iters']}; worst rel err vs the dense-state oracle "
           f"{worst:.2e} (weights >= 1e-4), worst abs err below {np.max(np.abs(res['theta'] - th_d)[~big], initial=0):.2e}")
     assert th_d[0] > 0.9
@@ -105,6 +119,7 @@ def test_dominant_group_matches_dense_state_oracle(gpu_core, oracle, alpha, deep
     g = gpu_core.gamma()
     np.testing.assert_allclose(np.exp(g).sum(0), 1.0, rtol=1e-10)
     np.testing.assert_allclose(np.exp(g), np.exp(d["gamma"]), atol=2e-6)
+    return visits
 
 
 def test_isolate_theta_one_minus_1e_9(gpu_core, oracle):
