@@ -108,8 +108,8 @@ typedef struct msw_layout_info {
   uint32_t n_slices, n_long_ecs;
   uint64_t rows;               /* slice rows (64 records each), padding included */
   uint64_t rows_from_memory;   /* ... whose table entries are gathered from memory (cold segments, whole slices) */
-  uint32_t slices_by_lanes[5]; /* slices whose ECs take 16, 8, 4, 2, 1 lanes each (ECs of 129..256, .., 17..32, <= 16
-                                * cells; MSWEEP_MULTILANE=0: all in the last) */
+  uint32_t slices_by_lanes[7]; /* slices whose ECs take 64, 32, 16, 8, 4, 2, 1 lanes each (ECs of 513..1024, 257..512,
+                                * .., 17..32, <= 16 cells; MSWEEP_MULTILANE=0: all in the last) */
   uint32_t max_rows;           /* rows of the longest slice (<= 16: every slice on the register path of the sweeps) */
 } msw_layout_info;
 int msw_core_layout_info(msw_handle h, msw_layout_info *out);

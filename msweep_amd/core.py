@@ -46,7 +46,7 @@ class LayoutInfo(C.Structure):
     _fields_ = [("record_bytes", C.c_int32), ("index_records", C.c_int32), ("groups_in_lds", C.c_int32),
                 ("table_in_lds", C.c_int32), ("passB_mode", C.c_int32), ("slot_entries", C.c_uint32),
                 ("slot_entries_in_lds", C.c_uint32), ("n_slices", C.c_uint32), ("n_long_ecs", C.c_uint32),
-                ("rows", C.c_uint64), ("rows_from_memory", C.c_uint64), ("slices_by_lanes", C.c_uint32 * 5),
+                ("rows", C.c_uint64), ("rows_from_memory", C.c_uint64), ("slices_by_lanes", C.c_uint32 * 7),
                 ("max_rows", C.c_uint32)]
 
 

@@ -42,15 +42,17 @@ __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_move<0x143, 0xc>(v, ninf));
   return bcast_lane63(v);
 }
-// Sum over the 2^lgm lanes of an aligned lane group, lgm <= 4 and wave-uniform (the lanes of one EC in a slice of
+// Sum over the 2^lgm lanes of an aligned lane group, lgm <= 6 and wave-uniform (the lanes of one EC in a slice of
 // more than one lane per EC, sell.hpp): every lane of the group ends with the same bits (each step adds two partial
 // sums in either order: fp addition is commutative).  quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror,
-// row_mirror: all inside a row of 16 lanes.
+// row_mirror: all inside a row of 16 lanes; across rows (32 and 64 lanes per EC) through the LDS crossbar.
 __device__ __forceinline__ double group_sum(double v, uint32_t lgm) {
   if (lgm >= 1) v += dpp_move<0xB1, 0xf>(v, 0.0);
   if (lgm >= 2) v += dpp_move<0x4E, 0xf>(v, 0.0);
   if (lgm >= 3) v += dpp_move<0x141, 0xf>(v, 0.0);
   if (lgm >= 4) v += dpp_move<0x140, 0xf>(v, 0.0);
+  if (lgm >= 5) v += __shfl_xor(v, 16, 64);
+  if (lgm >= 6) v += __shfl_xor(v, 32, 64);
   return v;
 }
 // sh: >= 16 doubles of LDS scratch.  Result valid in every thread.

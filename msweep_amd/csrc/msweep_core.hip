@@ -59,7 +59,7 @@ struct msw_core {
   bool wide() const { return enc == kEncWide; }
   bool hybrid() const { return enc == kEncIndex; }
   RecDec dec() const { return RecDec{enc_shift, enc_mask, enc_bhi, enc_bhiA}; }
-  uint32_t long_row = kLongRow;                         // ECs with more cells go one per wavefront (<= kLongRow)
+  uint32_t long_row = kLongRow;                         // ECs with more cells go one per wavefront (reset_likelihood)
   DevBuf<uint32_t> area_slot;
   DevBuf<double> lut_area;  // lut[area_slot[i]]: what the per-slot tables are built from, in their order
   DevBuf<int> tab_built;    // k_tables bookkeeping
@@ -238,11 +238,11 @@ bool multilane() {
   const char *e = getenv("MSWEEP_MULTILANE");
   return !(e && atoi(e) == 0);
 }
-// slice / position boundaries of the classes from the ECs per class (n[c]: class c = 16 >> c lanes per EC)
+// slice / position boundaries of the classes from the ECs per class (n[c]: class c = 64 >> c lanes per EC)
 SliceClasses make_slice_classes(const uint32_t *n) {
   SliceClasses C = {};
   for (int c = 0; c < kSliceClasses; ++c) {
-    const uint32_t per = 64u >> (4 - c);
+    const uint32_t per = 64u >> (kMaxLgm - c);
     C.p0[c + 1] = C.p0[c] + n[c];
     C.s0[c + 1] = C.s0[c] + (n[c] + per - 1) / per;
   }

@@ -26,7 +26,7 @@ __device__ __constant__ uint8_t kRPosDev[64] = {0,  1,  2,  3,  0,  1,  2,  3,  
 __host__ __device__ inline uint32_t cold_class(uint32_t n_cold) {
   return n_cold == 0 ? 0u : (n_cold <= 2 ? 1u : (n_cold <= (uint32_t)kColdRows ? 2u : 3u));
 }
-constexpr uint32_t kPackKeyBits = 11;  // (1 + kLongRow) * 4 + 3 < 2^11
+constexpr uint32_t kPackKeyBits = 13;  // (1 + kLongRow) * 4 + 3 < 2^13
 // sort key of an EC: 0 = long (plain CSR part), else (1 + (kLongRow - cells)) * 4 + cold class: ascending = SELL
 // order.  canon == nullptr: no hybrid area, every cold class 0.
 // counts[0] = long ECs, counts[1 + c] = ECs of slice class c (sell.hpp)

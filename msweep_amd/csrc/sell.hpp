@@ -41,30 +41,36 @@ namespace msw {
 constexpr uint32_t kSentinels = 64;  // one sentinel group per lane: padding never shares an address
 
 // ---------------------------------------------------------------------------------------
-// Slice classes (round 3): an EC of up to 16 cells takes ONE lane of its slice; an EC of 17..256 cells takes
-// m = 2, 4, 8 or 16 lanes (the smallest m with cells <= 16 m; cell k of the EC in sub-lane k mod m, row k / m), so
+// Slice classes (round 3): an EC of up to 16 cells takes ONE lane of its slice; an EC of 17..1024 cells takes
+// m = 2, 4, ... 64 lanes (the smallest m with cells <= 16 m; cell k of the EC in sub-lane k mod m, row k / m), so
 // that every slice has at most 16 rows and stays on the sweeps' register path: no second walk over the records
 // and no second gathers in pass B (the streaming path such ECs took before ran pass B at half the per-cell
-// rate), the m partial row sums meet in log2 m DPP steps inside a row of 16 lanes, and a slice holds 64 / m
+// rate), the m partial row sums meet in log2 m steps (DPP inside a row of 16 lanes), and a slice holds 64 / m
 // ECs -- the chain of a wavefront that has few slices is m times shorter.  The ECs are sorted by descending
-// length, so the classes are contiguous: class c = 0..4 <-> m = 16 >> c.  s0 / p0: first slice / first EC position
+// length, so the classes are contiguous: class c = 0..6 <-> m = 64 >> c.  s0 / p0: first slice / first EC position
 // (within the sliced part of the permuted order) of every class.
 // ---------------------------------------------------------------------------------------
-constexpr int kSliceClasses = 5;
+constexpr int kSliceClasses = 7;
+constexpr uint32_t kMaxLgm = kSliceClasses - 1;  // class c: 2^(kMaxLgm - c) lanes per EC
 struct SliceClasses {
   uint32_t s0[kSliceClasses + 1], p0[kSliceClasses + 1];
 };
-// class of an EC of `len` cells (multilane = false: every EC one lane -- the developer switch MSWEEP_MULTILANE=0)
+// class of an EC of `len` cells (multilane = false: every EC one lane -- the developer switch MSWEEP_MULTILANE=0):
+// the smallest m = 2^lgm with len <= 16 m
 __host__ __device__ inline int slice_class_of(uint32_t len, bool multilane) {
-  if (!multilane || len <= 16) return 4;
-  return len <= 32 ? 3 : (len <= 64 ? 2 : (len <= 128 ? 1 : 0));
+  if (!multilane) return kSliceClasses - 1;
+  uint32_t lgm = 0;
+  while (lgm < kMaxLgm && len > (16u << lgm)) ++lgm;
+  return (int)(kMaxLgm - lgm);
 }
 struct SliceGeo {
   uint32_t lgm, ec0, nec;  // log2 lanes per EC; first EC position of the slice; ECs in it
 };
 __host__ __device__ inline SliceGeo slice_geo(const SliceClasses &C, uint32_t s) {
-  const uint32_t c = (s >= C.s0[1]) + (s >= C.s0[2]) + (s >= C.s0[3]) + (s >= C.s0[4]);
-  const uint32_t lgm = 4u - c, per = 64u >> lgm;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 1; i < kSliceClasses; ++i) c += s >= C.s0[i];
+  const uint32_t lgm = kMaxLgm - c, per = 64u >> lgm;
   const uint32_t ec0 = C.p0[c] + (s - C.s0[c]) * per;
   const uint32_t left = C.p0[c + 1] - ec0;
   return SliceGeo{lgm, ec0, left < per ? left : per};
@@ -72,8 +78,10 @@ __host__ __device__ inline SliceGeo slice_geo(const SliceClasses &C, uint32_t s)
 // slice and lane group of the EC at position q of the sliced part
 __host__ __device__ inline void slice_of_position(const SliceClasses &C, uint32_t q, uint32_t &s, uint32_t &lgm,
                                                   uint32_t &first_lane) {
-  const uint32_t c = (q >= C.p0[1]) + (q >= C.p0[2]) + (q >= C.p0[3]) + (q >= C.p0[4]);
-  lgm = 4u - c;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 1; i < kSliceClasses; ++i) c += q >= C.p0[i];
+  lgm = kMaxLgm - c;
   const uint32_t per = 64u >> lgm, d = q - C.p0[c];
   s = C.s0[c] + d / per;
   first_lane = (d % per) << lgm;
@@ -107,7 +115,8 @@ constexpr uint32_t kC8Escape = 255;
 #define MSW_W_XT 4
 #define MSW_W_E 2
 #endif
-constexpr int kLongRow = 256;  // ECs with more cells than this take the workgroup path
+constexpr int kLongRow = 1024;      // ECs with more cells than this take the wavefront-per-EC path (64 lanes x 16 rows)
+constexpr int kLongRowOneLane = 256;  // ... when every EC takes one lane (MSWEEP_MULTILANE=0: slices of up to 256 rows)
 #ifndef MSW_COLD_ROWS
 #define MSW_COLD_ROWS 2
 #endif
@@ -115,7 +124,7 @@ constexpr int kColdRows = MSW_COLD_ROWS;  // index records: rows of a slice's co
 static_assert(kColdRows == 2 || kColdRows == 4, "cold segments are cut in pairs of rows");
 constexpr uint32_t kGeoHotShift = 27;  // slice geometry in LDS: rows of the hot segment above the slice offset
 // ... and above the slice's rows (<= kLongRow): log2 lanes per EC, ECs in the slice (slice classes)
-constexpr uint32_t kGeoLgmShift = 10, kGeoNecShift = 13;
+constexpr uint32_t kGeoLgmShift = 11, kGeoNecShift = 14;
 
 // what a sweep needs to decode a record (SGPRs)
 struct RecDec {

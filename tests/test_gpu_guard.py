@@ -80,7 +80,7 @@ def test_dominant_group_with_mid_length_ecs(gpu_core, oracle, alpha, deep, zero_
     first lane hands it to the guard path, which walks the EC's cells over its lanes."""
     p = isolate_problem(seed=77 + int(alpha * 1000), n_ecs=3000, G=150, deep=deep, others=(18, 120), other_values=(-16.0, -8.0))
     visits = _check_dominant(gpu_core, oracle, p, alpha, deep, zero_counts)
-    assert sum(gpu_core.layout_info()["slices_by_lanes"][:4]) > 0
+    assert sum(gpu_core.layout_info()["slices_by_lanes"][:-1]) > 0
     assert visits > 0          # the guard path of multi-lane slices is what this test is about
 
 

@@ -528,7 +528,7 @@ def test_mid_length_ecs_slice_classes_and_streaming_path(oracle, monkeypatch, mu
     G = 700
     sizes = (1 + rng.poisson(4, G)).astype(np.uint64)
     lut = precalc_lls(sizes)
-    lens = np.concatenate([rng.integers(17, 257, 300), rng.integers(0, 17, 500), [255, 256, 17, 33]])
+    lens = np.concatenate([rng.integers(17, 257, 300), rng.integers(0, 17, 500), [255, 256, 17, 33, 257, 512, 513, 699]])
     rng.shuffle(lens)
     cols = [np.sort(rng.choice(G, int(n), replace=False)) for n in lens]
     rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
@@ -540,12 +540,12 @@ def test_mid_length_ecs_slice_classes_and_streaming_path(oracle, monkeypatch, mu
     gpu_core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
     li = gpu_core.layout_info()
     if multilane == "1":
-        # ECs of 129..256 / 65..128 / 33..64 / 17..32 / <= 16 cells: 4, 8, 16, 32, 64 to a slice
+        # ECs of 513..1024 / 257..512 / 129..256 / 65..128 / 33..64 / 17..32 / <= 16 cells: 1, 2, 4, 8, 16, 32, 64 to a slice
         want = [int(np.ceil(np.sum((lens > lo) & (lens <= hi)) / per))
-                for lo, hi, per in ((128, 256, 4), (64, 128, 8), (32, 64, 16), (16, 32, 32), (-1, 16, 64))]
-        assert li["slices_by_lanes"] == want and li["max_rows"] <= 16
+                for lo, hi, per in ((512, 1024, 1), (256, 512, 2), (128, 256, 4), (64, 128, 8), (32, 64, 16), (16, 32, 32), (-1, 16, 64))]
+        assert li["slices_by_lanes"] == want and li["max_rows"] <= 16 and li["n_long_ecs"] == 0
     else:
-        assert li["slices_by_lanes"][:4] == [0, 0, 0, 0] and li["max_rows"] == 256
+        assert li["slices_by_lanes"][:6] == [0] * 6 and li["max_rows"] == 256 and li["n_long_ecs"] == 4
     gpu_core.set_trace_theta(15)
     res = gpu_core.solve(logc, alpha0)
     tr = gpu_core.trace(15, with_theta=True)
