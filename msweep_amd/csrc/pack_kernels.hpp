@@ -250,9 +250,10 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
           const int l = (li + (int)(k0 + k) * 7) & 63;  // rotate the priority
           const uint32_t n_l = (uint32_t)__builtin_amdgcn_readlane((int)ncell, l);
           const uint32_t t_l = (uint32_t)__builtin_amdgcn_readlane((int)taken, l);
-          if (n_l == 0 || (t_l & ((1u << n_l) - 1u)) == ((1u << n_l) - 1u)) continue;  // nothing left to place
+          const uint32_t avail = ((1u << n_l) - 1u) & ~t_l;  // its unplaced cells (wave-uniform)
+          if (avail == 0) continue;                         // nothing left to place
           const int R_l = __builtin_amdgcn_readlane(R, l), C_l = l >> 4, H_l = l >> 5;
-          bool valid = lane < 16 && cand < n_l && !(t_l >> cand & 1u);
+          bool valid = lane < 16 && (avail >> cand & 1u);
           uint32_t g = 0, i = 0, v_at = 0, v_rg = 0, v_rs = 0, v_hg = 0, key = 0;
           if (valid) {
             g = cg[l * kRowW + cand];
@@ -283,10 +284,10 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
             const uint32_t g_w = (uint32_t)__builtin_amdgcn_readlane((int)g, cb);
             const uint32_t i_w = (uint32_t)__builtin_amdgcn_readlane((int)i, cb);
             if (lane == cb) {  // the winner holds the bank words it has just read
-              at[C_l] = v_at | 1u << (g & 15);
-              if (v_rg == 0xffffffffu) rg[R_l][g & 15] = g;
-              if (v_rs == 0xffffffffu) rs[R_l][i & 15] = i;
-              if (v_hg == 0xffffffffu) hg[H_l][g & 31] = g;
+              at[C_l] = v_at | 1u << (g & 15);  // (a bank that is held keeps its address: written back as read)
+              rg[R_l][g & 15] = v_rg == 0xffffffffu ? g : v_rg;
+              rs[R_l][i & 15] = v_rs == 0xffffffffu ? i : v_rs;
+              hg[H_l][g & 31] = v_hg == 0xffffffffu ? g : v_hg;
             }
             if (lane == l) {
               taken |= 1u << cb;
