@@ -111,8 +111,17 @@ typedef struct msw_layout_info {
   uint32_t slices_by_lanes[7]; /* slices whose ECs take 64, 32, 16, 8, 4, 2, 1 lanes each (ECs of 513..1024, 257..512,
                                 * .., 17..32, <= 16 cells; MSWEEP_MULTILANE=0: all in the last) */
   uint32_t max_rows;           /* rows of the longest slice (<= 16: every slice on the register path of the sweeps) */
+  int32_t bank_scheduled;      /* the cells of every slice were ordered for the LDS banks (msw_core_set_pack_schedule) */
 } msw_layout_info;
 int msw_core_layout_info(msw_handle h, msw_layout_info *out);
+/* Whether the NEXT likelihood made resident on the handle (msw_core_set_csr, msw_core_build_likelihood, a dense
+ * matrix re-expressed as CSR-of-ECs) gets its cells ordered for the LDS banks of the sweeps (the order of
+ * the cells inside an EC is free).  enabled = 1 (default): an iteration is 5-6 % faster (cfg3: 0.177 against 0.187 ms)
+ * and the upload 10 ms slower (cfg3; 28 ms at cfg5) -- pays from about the 1 000th iteration on the same likelihood,
+ * i.e. for bootstrap runs (src/mSWEEP.cpp:496-518); enabled = 0: the cells keep their CSR order -- the faster way to
+ * ONE solve.  Same results either way (the order of the additions inside an EC changes: rounding).  The drivers set
+ * it from --iters.  No reference counterpart. */
+int msw_core_set_pack_schedule(msw_handle h, int enabled);
 
 /* ---- solve --------------------------------------------------------------------------
  * Replaces rcgpar::rcg_optl_torch / rcg_optl_omp / em_torch as called from rcg_optl()

@@ -127,6 +127,8 @@ def main(argv=None):
                          "footprint float would halve); results are those of --emprecision double\n")
     try:
         core = Core(a.device)
+        # ordering the cells for the LDS banks pays from about the 1 000th iteration on: bootstrap runs (msw_core_set_pack_schedule)
+        core.set_pack_schedule(a.iters >= 5)
         if a.read_likelihood:
             # --read-likelihood (include/Likelihood.hpp:224-253): "count \t L(0,j) ... L(G-1,j)" per EC
             ec_counts, L = read_likelihood_file(a.read_likelihood, grouping.get_n_groups())

@@ -28,7 +28,7 @@ EXPORTS = [
     "msw_core_set_fixed_iters", "msw_core_hbm_stream_rates", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
     "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
     "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_core_continue", "msw_core_gamma_block",
-    "msw_core_last_bootstrap_timing", "msw_core_layout_info", "msw_core_guarded_visits",
+    "msw_core_last_bootstrap_timing", "msw_core_layout_info", "msw_core_guarded_visits", "msw_core_set_pack_schedule",
 ]
 
 
@@ -47,7 +47,7 @@ class LayoutInfo(C.Structure):
                 ("table_in_lds", C.c_int32), ("passB_mode", C.c_int32), ("slot_entries", C.c_uint32),
                 ("slot_entries_in_lds", C.c_uint32), ("n_slices", C.c_uint32), ("n_long_ecs", C.c_uint32),
                 ("rows", C.c_uint64), ("rows_from_memory", C.c_uint64), ("slices_by_lanes", C.c_uint32 * 7),
-                ("max_rows", C.c_uint32)]
+                ("max_rows", C.c_uint32), ("bank_scheduled", C.c_int32)]
 
 
 class BootstrapTiming(C.Structure):
@@ -126,6 +126,7 @@ def load_library():
     L.msw_comm_allgather.argtypes = [vp, vp, sz, vp]
     L.msw_core_set_profiling.argtypes = [vp, C.c_int]
     L.msw_core_set_fixed_iters.argtypes = [vp, C.c_int]
+    L.msw_core_set_pack_schedule.argtypes = [vp, C.c_int]
     L.msw_core_hbm_stream_rates.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.msw_core_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.msw_core_last_bootstrap_timing.argtypes = [vp, C.POINTER(BootstrapTiming)]
@@ -413,6 +414,11 @@ class Core:
         t = Timing()
         self._check(self._L.msw_core_last_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def set_pack_schedule(self, enabled):
+        """Order the cells of the NEXT likelihood for the LDS banks (default) or keep their CSR order (one solve only:
+        the upload is faster than the iterations are slower).  msw_core_set_pack_schedule."""
+        self._check(self._L.msw_core_set_pack_schedule(self._h, 1 if enabled else 0))
 
     def guarded_visits(self):
         """ECs pass B has taken through the cancellation guard since the likelihood became resident (all iterations)."""

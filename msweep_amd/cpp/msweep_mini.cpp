@@ -167,6 +167,8 @@ int main(int argc, char **argv) {
   try {
     if (msw_core_create(a.gpu, &h) != 0) throw std::runtime_error(msw_last_error(nullptr));
     if (n_ecs == 0) throw std::runtime_error("no read aligned against the reference");
+    // ordering the cells for the LDS banks pays from about the 1 000th iteration on: bootstrap runs
+    check(h, msw_core_set_pack_schedule(h, a.iters >= 5 ? 1 : 0));
     check(h, msw_core_build_likelihood(h, ec_tptr.data(), ec_targets.data(), n_ecs, grouping.indicators.data(),
                                        grouping.indicators.size(), grouping.sizes.data(), G, ec_counts.data(), a.q,
                                        a.e, a.zero_inflation, a.min_hits, &n_kept, mask.data(), nullptr));

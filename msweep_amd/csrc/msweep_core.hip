@@ -56,6 +56,8 @@ struct msw_core {
   uint32_t n_tab_lds = 0;                               // ... of which the LDS images hold (all, the hot head, none)
   DevBuf<uint8_t> slice_hot;                            // index records: rows of every slice's hot segment
   SliceClasses cls = {};                                // slice classes: lanes per EC (sell.hpp)
+  bool pack_schedule = true;                            // LDS-bank scheduling of the cells at upload (msw_core_set_pack_schedule)
+  bool packed_scheduled = false;                        // ... as the resident likelihood was packed
   bool wide() const { return enc == kEncWide; }
   bool hybrid() const { return enc == kEncIndex; }
   RecDec dec() const { return RecDec{enc_shift, enc_mask, enc_bhi, enc_bhiA}; }
@@ -927,6 +929,7 @@ int msw_core_layout_info(msw_handle h, msw_layout_info *out) {
     li.slot_entries_in_lds = h->n_tab_lds;
     li.n_slices = h->nslices;
     li.n_long_ecs = h->n_long;
+    li.bank_scheduled = h->packed_scheduled ? 1 : 0;
     std::vector<uint32_t> off((size_t)h->nslices + 1);
     MSW_HIP(hipMemcpy(off.data(), h->slice_off.p, off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     li.rows = off[h->nslices];
@@ -1134,6 +1137,9 @@ int msw_core_set_profiling(msw_handle h, int enabled) {
 }
 int msw_core_set_fixed_iters(msw_handle h, int enabled) {
   return guarded(h, [&] { h->fixed_iters = enabled != 0; });
+}
+int msw_core_set_pack_schedule(msw_handle h, int enabled) {
+  return guarded(h, [&] { h->pack_schedule = enabled != 0; });
 }
 int msw_core_last_timing(msw_handle h, msw_timing *out) {
   return guarded(h, [&] {

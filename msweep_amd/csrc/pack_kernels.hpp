@@ -183,7 +183,7 @@ template <int ENC>
 __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, const uint32_t *grp, const uint32_t *idx,
                                                    const uint32_t *perm, const uint32_t *slice_off, uint32_t n_long,
                                                    uint32_t n_sell, uint32_t nslices, SliceClasses cls, PackEnc pe,
-                                                   uint32_t *rec) {
+                                                   int schedule, uint32_t *rec) {
   // the slice's cells: group, slot-area entry -- [lane][cell], rows of 17 words (the 16 candidates of one lane are
   // read by 16 lanes at once: consecutive banks)
   constexpr int kRowW = kPackCells + 1;
@@ -220,12 +220,13 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
     for (uint32_t k0 = 0; k0 < L; k0 += kPackCells) {
       const uint32_t nrows = min((uint32_t)kPackCells, L - k0);
       const uint32_t ncell = mylen > k0 ? min((uint32_t)kPackCells, mylen - k0) : 0u;  // this lane's cells in the window
-      uint32_t mycold = 0;
+      uint32_t mycold = 0, coldmask = 0;
       for (uint32_t c = 0; c < ncell; ++c) {
         const uint32_t e = pack_entry(pe, lane, idx[b + (size_t)(k0 + c) * m]);
         cg[lane * kRowW + c] = grp[b + (size_t)(k0 + c) * m];
         ce[lane * kRowW + c] = e;
         mycold += e >= pe.n_hot;
+        coldmask |= (uint32_t)(e >= pe.n_hot) << c;
       }
       uint32_t taken = 0, nhot = nrows;
       if constexpr (ENC == kEncIndex) {
@@ -242,7 +243,21 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
       // the bank state.  (Until round 3 the lane whose turn it was walked its candidates alone, the other 63 idle:
       // 230 instructions per turn, 34 ms of packing at cfg3; same choices, bit for bit: the layout-hash tests
       // against the host packer.)
-      for (uint32_t k = 0; k < nhot; ++k) {
+      // schedule = 0 (msw_core_set_pack_schedule): the cells keep their CSR order -- every lane its first unplaced
+      // (hot) cell, no turns: what the scheduler does when nothing scores
+      for (uint32_t k = 0; !schedule && k < nhot; ++k) {
+        uint32_t avail = ((1u << ncell) - 1u) & ~taken;
+        if (ENC == kEncIndex && !streaming) avail &= ~coldmask;
+        uint32_t pick_g = pe.n_groups + lane, pick_e = kPackPad;
+        if (avail) {
+          const int c = __ffs((int)avail) - 1;
+          taken |= 1u << c;
+          pick_g = cg[lane * kRowW + c];
+          pick_e = ce[lane * kRowW + c];
+        }
+        pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, pick_g, pick_e);
+      }
+      for (uint32_t k = 0; schedule && k < nhot; ++k) {
         for (int w = lane; w < 196; w += 64) reinterpret_cast<uint32_t *>(&bk)[w] = w < 192 ? 0xffffffffu : 0u;
         uint32_t pick_g = pe.n_groups + lane, pick_e = kPackPad;
         __syncthreads();

@@ -399,6 +399,39 @@ def test_device_packer_matches_host_packer(oracle, monkeypatch, case):
     assert hashes[0] == hashes[1]
 
 
+def test_pack_without_bank_scheduling(oracle, monkeypatch):
+    """msw_core_set_pack_schedule(0): the cells keep their CSR order (the faster way to ONE solve) -- device and host
+    packer byte for byte, a layout different from the scheduled one, the same answer; the setting holds for the NEXT
+    likelihood only from the call on."""
+    rng = np.random.default_rng(9)
+    G, E = 500, 4000
+    sizes = rng.integers(2, 40, G).astype(np.uint64)
+    lens = rng.integers(0, 17, E)
+    lens[rng.choice(E, 200, replace=False)] = rng.integers(17, 400, 200)
+    rowptr, grp, cnt, lut = _ragged_problem(rng, E, G, sizes, lens)
+    logc = np.log(rng.integers(1, 20, E).astype(float))
+    lutidx = (grp * lut.shape[1] + cnt).astype(np.uint32)
+    ref = oracle.rcg_optl_csr(rowptr, grp, lutidx, lut, np.log(0.01), G, logc, np.ones(G))
+    hashes = {}
+    for sched in (1, 0):
+        for host in (True, False):
+            if host:
+                monkeypatch.setenv("MSWEEP_HOST_PACK", "1")
+            else:
+                monkeypatch.delenv("MSWEEP_HOST_PACK")
+            with Core(0) as core:
+                core.set_pack_schedule(sched)
+                core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
+                assert core.layout_info()["bank_scheduled"] == sched
+                hashes[sched, host] = core.layout_hash()
+                if not host:
+                    res = core.solve(logc, np.ones(G))
+                    assert res["iters"] == ref["iters"]
+                    assert_theta(res["theta"], ref["theta"])
+    assert hashes[1, True] == hashes[1, False] and hashes[0, True] == hashes[0, False]
+    assert hashes[0, False] != hashes[1, False]
+
+
 @pytest.mark.parametrize("G,global_atomics", [(12000, False), (19500, False), (36000, False), (12000, True)])
 def test_many_groups_modes(gpu_core, oracle, monkeypatch, G, global_atomics):
     """More groups than the LDS images of the sweeps hold: {e, w} / e_g gathered from memory, the
