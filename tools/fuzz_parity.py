@@ -31,8 +31,11 @@ for case in range(n_cases):
     lut[:, 1:] = rng.uniform(-8.0, -0.05, (G, nlev))
     if deep:
         lut[rng.integers(0, G, max(1, G // 10)), rng.integers(1, nlev + 1, max(1, G // 10))] = rng.uniform(-90, -20)
-    maxlen = int(rng.choice([1, 3, 8, 16, 17, 40, 300])) if G > 300 else int(rng.choice([1, 3, 8, 16, 17]))
+    # (every slice class of sell.hpp: up to 16 cells one lane, .. up to 1024 cells 64 lanes; beyond: a wavefront per EC)
+    maxlen = int(rng.choice([1, 3, 8, 16, 17, 40, 300, 700, 1500])) if G > 300 else int(rng.choice([1, 3, 8, 16, 17]))
     maxlen = min(maxlen, G)
+    if maxlen > 300:
+        E = min(E, 20000)     # (the oracle's time)
     lens = rng.integers(1, maxlen + 1, E)
     if rng.random() < 0.3:
         lens[rng.integers(0, E, max(1, E // 50))] = maxlen
