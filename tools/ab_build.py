@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer A/B tool: build library variants build_ab/lib_<name>.so with extra compiler flags (the build macros of
-README.md: MSW_FX, MSW_PASS_THREADS_A/B, MSW_B_KEEPN, MSW_COLD_ROWS, MSW_ODD_SLICES, MSW_FAST_DIV, MSW_LONG_KEEP ...)
+README.md: MSW_FX, MSW_PASS_THREADS_A/B, MSW_B_KEEPN, MSW_COLD_ROWS, MSW_ODD_SLICES, MSW_FAST_DIV, MSW_LONG_KEEP, the four
+scheduler weights MSW_W_AT / MSW_W_EW / MSW_W_XT / MSW_W_E -- all four together ...)
 that tools/ab_bench.sh -- or any script through MSWEEP_CORE_LIB -- times in one GPU job next to the default build.
 (Rounds 1-2 also patched instrumentation hooks into the sweeps here -- conflict-free LDS addresses, stream only, no
 atomics ...: DESIGN.md 5 quotes their results; the hooks did not survive the round-3 record refactor.)
