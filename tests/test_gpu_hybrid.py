@@ -76,8 +76,8 @@ def _dense(p, lut):
     return dense_from_csr(p, lut)
 
 
-@pytest.mark.parametrize("hot", [0, 32, 4096])
-def test_hybrid_device_packer_matches_host_packer(monkeypatch, hot):
+@pytest.mark.parametrize("hot,sched", [(0, 1), (32, 1), (4096, 1), (32, 0)])
+def test_hybrid_device_packer_matches_host_packer(monkeypatch, hot, sched):
     """Hot / cold segments, cold classes in the EC order, rows per hot segment: the device packer
     (pack_kernels.hpp) against the host reference implementation, byte for byte; ragged lengths incl. empty ECs,
     streaming (17..256 cells) and long (> 256) ECs."""
@@ -100,10 +100,11 @@ def test_hybrid_device_packer_matches_host_packer(monkeypatch, hot):
         else:
             monkeypatch.delenv("MSWEEP_HOST_PACK")
         with Core(0) as core:
+            core.set_pack_schedule(sched)     # (0: the cells keep their CSR order, hot ones first -- msw_core_set_pack_schedule)
             core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
             hashes.append(core.layout_hash())
             infos.append(core.layout_info())
-    assert infos[0] == infos[1] and infos[0]["index_records"] == 1
+    assert infos[0] == infos[1] and infos[0]["index_records"] == 1 and infos[0]["bank_scheduled"] == sched
     assert hashes[0] == hashes[1]
 
 

@@ -53,6 +53,21 @@ def test_value_records_lockstep(oracle, E, G, support):
             assert_theta(em["theta"], em_ref["theta"])
 
 
+def test_value_records_without_bank_scheduling(oracle):
+    """msw_core_set_pack_schedule(0) on value records: the same solve from cells in CSR order."""
+    p = continuous_problem(30000, 90, 36, max_support=40)
+    with Core(0) as core:
+        core.set_pack_schedule(0)
+        res, tr, logc, alpha0 = solve_dense(core, p)
+        li = core.layout_info()
+        assert li["record_bytes"] == 12 and li["bank_scheduled"] == 0, li
+        ref = oracle.rcg_optl_dense_structured(p["logl"], logc, alpha0, trace=20)
+        lockstep(tr, ref["trace"], 20)
+        assert res["iters"] == ref["iters"]
+        assert_theta(res["theta"], ref["theta"])
+        np.testing.assert_array_equal(core.get_dense_logl(), p["logl"])
+
+
 def test_value_records_equal_the_slot_per_cell_layout(monkeypatch):
     """MSWEEP_VALUE_RECORDS=0: the previous layout (one table slot per listed cell, tables in memory).  Same
     exponentials of the same values: same iteration count, abundances equal to rounding."""
