@@ -368,6 +368,16 @@ __global__ __launch_bounds__(256) void k_cell_lutidx(const uint32_t *grp, const 
   }
 }
 
+// msw_core_set_csr: the caller's 64-bit row pointers as 32-bit ones, checked on the way (bad |= 4: a row ends before
+// it starts, or beyond the nnz the last pointer promises)
+__global__ __launch_bounds__(256) void k_rowptr_narrow(const uint64_t *rp, uint64_t n, uint64_t nnz, uint32_t *out, int *bad) {
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t v = rp[j];
+    if (v > nnz || (j + 1 < n && rp[j + 1] < v)) atomicOr(bad, 4);
+    out[j] = (uint32_t)(v > nnz ? nnz : v);
+  }
+}
+
 // msw_core_set_csr: LUT slot of every cell from the caller's (group, count) pairs, idx = lut_off[group] +
 // count, with the range checks of the upload (bad: 1 = group id out of range, 2 = count beyond the table)
 __global__ __launch_bounds__(256) void k_csr_lutidx(const uint32_t *grp, const uint32_t *cnt, uint64_t nnz,
