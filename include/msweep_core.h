@@ -123,6 +123,26 @@ int msw_core_layout_info(msw_handle h, msw_layout_info *out);
  * it from --iters.  No reference counterpart. */
 int msw_core_set_pack_schedule(msw_handle h, int enabled);
 
+/* ---- solver options ------------------------------------------------------------------
+ * The knobs of the optimiser loops that are restated from memory of rcgpar v1.2.1 (the library is an un-vendored
+ * FetchContent dependency of the reference, CMakeLists.txt:274-311).  The defaults are the
+ * restatement; every alternative reading is selectable, here and in the oracle (oracle/msweep_oracle.h
+ * orc_rcg_opts / orc_em_opts), so that a result from a real mSWEEP run can decide between them
+ * (tests/golden/external/README.md).  Options persist on the handle and apply to every later solve and bootstrap.
+ *   MSW_OPT_CHECK_EVERY n  the stop rule `bound - oldbound < tol && !didreset` (and EM's) is tested after iterations
+ *                          n, 2n, ... only.  Default 1.  (Every iteration count the reference publishes is a multiple
+ *                          of 5, docs/gpubenchmarks.md:15-25: rcgpar logs every 5th iteration -- the default's
+ *                          reading -- or tests on that grid, n = 5.)
+ *   MSW_OPT_INIT_BOUND  b  the value `bound` holds before the first iteration; default -100000 (a first bound below
+ *                          it sends iteration 0 through the steepest-descent retry).
+ *   MSW_OPT_EM_PRIOR 0|1   em_torch's M-step: 0 = MAP, the Dirichlet prior as pseudo-counts alpha0 - 1 (default);
+ *                          1 = ML, theta_g = sum_j c_j q_gj / sum_j c_j (alpha0 ignored).
+ *   MSW_OPT_EM_STOP  0|1   em_torch's stop: 0 = gain of the count-weighted log-likelihood < tol (default);
+ *                          1 = largest move of a mixture weight in the M-step < tol. */
+enum { MSW_OPT_CHECK_EVERY = 0, MSW_OPT_INIT_BOUND = 1, MSW_OPT_EM_PRIOR = 2, MSW_OPT_EM_STOP = 3 };
+int msw_core_set_option(msw_handle h, int option, double value);
+int msw_core_get_option(msw_handle h, int option, double *value);
+
 /* ---- solve --------------------------------------------------------------------------
  * Replaces rcgpar::rcg_optl_torch / rcg_optl_omp / em_torch as called from rcg_optl()
  * (src/mSWEEP.cpp:176-205) followed by rcgpar::mixture_components[_torch]

@@ -143,8 +143,9 @@ def main(argv=None):
         sys.stderr.write(f"Building the log-likelihood array failed:\n  {ex}\nexiting\n")
         return 1
     if a.write_likelihood:
-        # --write-likelihood (include/Likelihood.hpp:255-273), default ostream precision
-        with open(f"{a.prefix}_likelihoods.txt" if a.prefix else "likelihoods.txt", "w") as f:
+        # --write-likelihood (include/Likelihood.hpp:255-273), default ostream precision; the file is
+        # <prefix>_likelihoods.tsv (src/OutfileDesignator.cpp:67-74; the flag's help text says .txt)
+        with open(f"{a.prefix}_likelihoods.tsv" if a.prefix else "likelihoods.tsv", "w") as f:
             write_likelihood_file(f, ec_counts, lik.log_mat())
     if a.no_fit_model:
         core.close()

@@ -15,6 +15,9 @@ LIB_PATH = os.environ.get("MSWEEP_CORE_LIB") or os.path.join(_HERE, "libmsweep_c
 
 ALGO_RCG, ALGO_EM = 0, 1
 PREC_DOUBLE, PREC_FLOAT = 0, 1
+# msw_core_set_option ids (include/msweep_core.h): the knobs of rcgpar's loops that are restated from memory
+OPT_CHECK_EVERY, OPT_INIT_BOUND, OPT_EM_PRIOR, OPT_EM_STOP = 0, 1, 2, 3
+_OPTS = {"check_every": OPT_CHECK_EVERY, "init_bound": OPT_INIT_BOUND, "em_prior": OPT_EM_PRIOR, "em_stop": OPT_EM_STOP}
 
 # every symbol include/msweep_core.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -29,6 +32,7 @@ EXPORTS = [
     "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
     "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_core_continue", "msw_core_gamma_block",
     "msw_core_last_bootstrap_timing", "msw_core_layout_info", "msw_core_guarded_visits", "msw_core_set_pack_schedule",
+    "msw_core_set_option", "msw_core_get_option",
 ]
 
 
@@ -127,6 +131,8 @@ def load_library():
     L.msw_core_set_profiling.argtypes = [vp, C.c_int]
     L.msw_core_set_fixed_iters.argtypes = [vp, C.c_int]
     L.msw_core_set_pack_schedule.argtypes = [vp, C.c_int]
+    L.msw_core_set_option.argtypes = [vp, C.c_int, C.c_double]
+    L.msw_core_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.msw_core_hbm_stream_rates.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.msw_core_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.msw_core_last_bootstrap_timing.argtypes = [vp, C.POINTER(BootstrapTiming)]
@@ -419,6 +425,20 @@ class Core:
         """Order the cells of the NEXT likelihood for the LDS banks (default) or keep their CSR order (one solve only:
         the upload is faster than the iterations are slower).  msw_core_set_pack_schedule."""
         self._check(self._L.msw_core_set_pack_schedule(self._h, 1 if enabled else 0))
+
+    def set_option(self, name, value):
+        """msw_core_set_option: "check_every" n | "init_bound" b | "em_prior" 0 (MAP) / 1 (ML) | "em_stop" 0 (gain) /
+        1 (largest move of a weight).  Persists on the handle."""
+        if name not in _OPTS:
+            raise MswError(f"set_option: unknown option `{name}`")
+        self._check(self._L.msw_core_set_option(self._h, _OPTS[name], float(value)))
+
+    def get_option(self, name):
+        if name not in _OPTS:
+            raise MswError(f"get_option: unknown option `{name}`")
+        v = C.c_double()
+        self._check(self._L.msw_core_get_option(self._h, _OPTS[name], C.byref(v)))
+        return v.value
 
     def guarded_visits(self):
         """ECs pass B has taken through the cancellation guard since the likelihood became resident (all iterations)."""

@@ -83,6 +83,15 @@ struct DevBuf {
   }
 };
 
+// Solver options of a handle (include/msweep_core.h MSW_OPT_*): the knobs of rcgpar's loop that are restated from
+// memory; the defaults are the restatement itself.
+struct SolveOpts {
+  int32_t check_every = 1;     // stop rule tested after every iteration (n: after iterations n, 2n, ... only)
+  double init_bound = -100000.0;  // rcgpar: `long double bound = -100000.0`
+  int32_t em_prior = 0;        // 0 MAP (alpha0 - 1 pseudo-counts), 1 ML
+  int32_t em_stop = 0;         // 0 log-likelihood gain < tol, 1 largest move of a weight < tol
+};
+
 // Per-pass slot tables (n_lut 16-byte entries each), rebuilt by prepB_block whenever `a` moves:
 //   A[i] = {x_i, D_i}            x_i = exp(a*T_i), D_i = (1-a)*(T_i - logzi)      (pass A)
 //   B[i] = {x_i - p0, x_i*T_i - p0*logzi}              p0 = exp(a*logzi)           (pass B)
@@ -109,6 +118,8 @@ struct Scalars {
   double tref;
   int32_t didreset, reset_pending, done, iter;
   int32_t max_iters, fixed_iters, trace_theta, flavor;  // flavor: 0 csr, 1 dense
+  // solver options (msw_core_set_option): the stop rule is tested after iterations n, 2n, ... only; EM variants
+  int32_t check_every, em_prior, em_stop, opt_pad;
   int32_t tab_ver, fx_shift;  // fx_shift: device_util.hpp fx_factor, set with p0 / xb  // bumped whenever (a) changes the per-slot tables: k_tables (large slot areas) follows
 };
 

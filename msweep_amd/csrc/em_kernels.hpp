@@ -57,17 +57,20 @@ __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, 
   if (s0.done) return;
   const int flavor = s0.flavor;
   const double csum = s0.csum, oldll = s0.bound, tol = s0.tol;
+  // variants (msw_core_set_option): ML instead of MAP -- the prior's pseudo-counts dropped; stop on the largest
+  // move of a weight instead of the log-likelihood gain; the rule tested on a grid of iterations
+  const bool ml = s0.em_prior == 1, stop_theta = s0.em_stop == 1;
   if (inreg) {
 #pragma unroll
     for (int k = 0; k < kStepRegs; ++k) {
       if (tid + k * nt < G) {
-        q[2] += alv[k] - 1.0;
+        if (!ml) q[2] += alv[k] - 1.0;
         if (flavor != 0 && ncv[k] != 0.0) q[3] += uv[k] * ncv[k];
       }
     }
   } else {
     for (int g = tid; g < G; g += nt) {
-      q[2] += alpha0[g] - 1.0;
+      if (!ml) q[2] += alpha0[g] - 1.0;
       const double nc = Nc[g];
       if (flavor != 0 && nc != 0.0) q[3] += u[g] * nc;
     }
@@ -78,17 +81,20 @@ __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, 
   const double denom = csum + sa;
   const int it = s0.iter;
   int done = 0;
-  if (!s0.fixed_iters && it > 0 && (ll - oldll < tol)) done = 1;
+  const bool grid = s0.check_every <= 1 || (it + 1) % s0.check_every == 0;
+  if (!s0.fixed_iters && it > 0 && !stop_theta && (ll - oldll < tol) && grid) done = 1;
   if (it + 1 >= s0.max_iters) done = 1;
   const bool trace = it < s0.trace_theta && tr.theta;
-  double m = -INFINITY;
+  double m = -INFINITY, dmax = 0.0;
+  const double t_first = 1.0 / (double)G;  // the weights before the first M-step
   if (inreg) {
 #pragma unroll
     for (int k = 0; k < kStepRegs; ++k) {
       const int g = tid + k * nt;
       if (g < G) {
-        double t = (ncv[k] + alv[k] - 1.0) / denom;
+        double t = (ml ? ncv[k] : ncv[k] + alv[k] - 1.0) / denom;
         t = t > 0.0 ? t : 0.0;
+        if (stop_theta) dmax = fmax(dmax, fabs(t - (it > 0 ? theta[g] : t_first)));
         theta[g] = t;
         if (trace) tr.theta[(size_t)it * G + g] = t;
         uv[k] = log(t);
@@ -98,12 +104,17 @@ __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, 
     }
   } else {
     for (int g = tid; g < G; g += nt) {
-      double t = (Nc[g] + alpha0[g] - 1.0) / denom;
+      double t = (ml ? Nc[g] : Nc[g] + alpha0[g] - 1.0) / denom;
       t = t > 0.0 ? t : 0.0;
+      if (stop_theta) dmax = fmax(dmax, fabs(t - (it > 0 ? theta[g] : t_first)));
       theta[g] = t;
       if (trace) tr.theta[(size_t)it * G + g] = t;
       u[g] = log(t);
     }
+  }
+  if (stop_theta) {  // wave-uniform: the largest move of a weight decides
+    dmax = block_max(dmax, sh);
+    if (!s0.fixed_iters && it > 0 && dmax < tol && grid) done = 1;
   }
   if (tid == 0) {
     sc->oldbound = oldll;

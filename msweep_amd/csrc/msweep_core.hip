@@ -35,7 +35,6 @@ namespace {
 thread_local std::string g_create_error;
 constexpr size_t kLdsMax = 160 * 1024;
 constexpr int kIterBatch = 16;
-constexpr double kInitBound = -100000.0;  // rcgpar: `long double bound = -100000.0`
 }  // namespace
 
 struct msw_core {
@@ -56,6 +55,7 @@ struct msw_core {
   uint32_t n_tab_lds = 0;                               // ... of which the LDS images hold (all, the hot head, none)
   DevBuf<uint8_t> slice_hot;                            // index records: rows of every slice's hot segment
   SliceClasses cls = {};                                // slice classes: lanes per EC (sell.hpp)
+  bool no_hybrid = false;                               // re-planning without the hybrid area (host_pack.inc: slice geometry beyond 2^27 rows)
   bool pack_schedule = true;                            // LDS-bank scheduling of the cells at upload (msw_core_set_pack_schedule)
   bool packed_scheduled = false;                        // ... as the resident likelihood was packed
   bool wide() const { return enc == kEncWide; }
@@ -107,6 +107,7 @@ struct msw_core {
   bool have_solution = false;
   bool prepared = false;
   int last_algo = MSW_ALGO_RCG;
+  SolveOpts opts;  // msw_core_set_option
   // EM state
   DevBuf<double> logth;
 
@@ -150,6 +151,11 @@ namespace {
 
 struct Fail : std::runtime_error {
   using std::runtime_error::runtime_error;
+};
+// a solve that failed NUMERICALLY (likelihood underflow, non-finite bound: where the reference returns NaN weights).
+// The bootstrap driver turns exactly these into a row of NaN; every other failure fails the call.
+struct NumericFail : Fail {
+  using Fail::Fail;
 };
 
 // marks the stretch of a call in which this rank's peers wait for it in collectives
@@ -301,7 +307,7 @@ void choose_layout(msw_core *h) {
 // choose_lds_mode put them, and as many of the most-used entries in LDS as both sweeps' images leave room for.
 // Returns false (layout untouched) when it does not apply.
 bool choose_hybrid_layout(msw_core *h) {
-  if (h->tlds) return false;
+  if (h->tlds || h->no_hybrid) return false;
   if (const char *e = getenv("MSWEEP_HYBRID"))  // developer switch: 0 = the all-memory tables (and wide records)
     if (atoi(e) == 0) return false;
   const char *force = getenv("MSWEEP_RECORD_BYTES");
@@ -642,10 +648,15 @@ void prepare_inputs(msw_core *h, const double *logc_host, const uint32_t *counts
   h->prepared = true;
 }
 
-void begin_solve(msw_core *h, double tol, size_t max_iters) {
-  if (!h->prepared) throw Fail("msw_core_run: inputs not prepared (call msw_core_prepare)");
+// argument / state errors of a solve: thrown BEFORE anything that a peer of a sharded solve could wait for
+void validate_solve(const msw_core *, size_t max_iters, int algo, int prec) {
+  if (algo != MSW_ALGO_RCG && algo != MSW_ALGO_EM) throw Fail("unknown algorithm id");
+  if (prec != MSW_PREC_DOUBLE && prec != MSW_PREC_FLOAT) throw Fail("unknown precision id");
   if (max_iters == 0 || max_iters > (size_t)std::numeric_limits<int32_t>::max())
     throw Fail("max_iters out of range");
+}
+
+void begin_solve(msw_core *h, double tol, size_t max_iters) {
   const uint32_t G = h->G;
   if (h->trace_theta) h->tr_theta.alloc(h->trace_theta * G);
   const double *cpart = h->partC.p;
@@ -659,7 +670,7 @@ void begin_solve(msw_core *h, double tol, size_t max_iters) {
   }
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1024), 0, h->stream, h->sc.p, (int)G, ncpart,
                      cpart, h->alpha0.p, h->u.p, h->os_u.p, h->step_u.p, tol, (int)max_iters,
-                     h->fixed_iters ? 1 : 0, (int)h->trace_theta, h->flavor, h->logzi, kInitBound, h->tab_built.p,
+                     h->fixed_iters ? 1 : 0, (int)h->trace_theta, h->flavor, h->logzi, h->opts, h->tab_built.p,
                      h->trange.p);
   MSW_HIP(hipGetLastError());
 }
@@ -718,12 +729,12 @@ void finish_solve(msw_core *h, double *theta_out, size_t *iters_out, double *bou
   if (gerr) {
     MSW_HIP(hipMemset(h->guard_err.p, 0, sizeof gerr));
     if (gerr == 2) throw Fail("internal: a workgroup's list of guarded equivalence classes overflowed");
-    throw Fail("likelihood underflow: an equivalence class has zero probability under every group "
-               "(exp(a * log-likelihood) and the group weights underflow fp64 together)");
+    throw NumericFail("likelihood underflow: an equivalence class has zero probability under every group "
+                      "(exp(a * log-likelihood) and the group weights underflow fp64 together)");
   }
   // (an EM run that was asked for no iteration leaves its initial bound, -inf: nothing is wrong)
   if (h->sc_host->iter > 0 && !std::isfinite(h->sc_host->bound))
-    throw Fail("the evidence lower bound is not finite: the likelihood or the prior counts are out of range");
+    throw NumericFail("the evidence lower bound is not finite: the likelihood or the prior counts are out of range");
   if (theta_out) {
     if (h->last_algo == MSW_ALGO_EM) {
       MSW_HIP(hipMemcpy(theta_out, h->logth.p, G * sizeof(double), hipMemcpyDeviceToHost));  // theta of the last M-step
@@ -796,11 +807,11 @@ void continue_impl(msw_core *h, size_t n_iters, double *theta_out, size_t *iters
 
 void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, double *theta_out,
               size_t *iters_out, double *bound_out) {
-  if (algo != MSW_ALGO_RCG && algo != MSW_ALGO_EM) throw Fail("unknown algorithm id");
-  if (prec != MSW_PREC_DOUBLE && prec != MSW_PREC_FLOAT) throw Fail("unknown precision id");
+  validate_solve(h, max_iters, algo, prec);
+  if (!h->prepared) throw Fail("msw_core_run: inputs not prepared (call msw_core_prepare)");
   h->timing = {};
   h->evA_used = h->evB_used = 0;
-  CollectiveScope cs(h);
+  CollectiveScope cs(h);  // from here on a failure strands the peers of a sharded solve (guarded())
   begin_solve(h, tol, max_iters);
   MSW_HIP(hipEventRecord(h->ev0, h->stream));
   if (algo == MSW_ALGO_RCG) run_rcg(h, max_iters);
@@ -1140,6 +1151,41 @@ int msw_core_set_fixed_iters(msw_handle h, int enabled) {
 }
 int msw_core_set_pack_schedule(msw_handle h, int enabled) {
   return guarded(h, [&] { h->pack_schedule = enabled != 0; });
+}
+int msw_core_set_option(msw_handle h, int option, double value) {
+  return guarded(h, [&] {
+    switch (option) {
+      case MSW_OPT_CHECK_EVERY:
+        if (!(value >= 1.0 && value <= 65536.0) || value != std::floor(value)) throw Fail("MSW_OPT_CHECK_EVERY: an integer in [1, 65536]");
+        h->opts.check_every = (int32_t)value;
+        break;
+      case MSW_OPT_INIT_BOUND:
+        if (std::isnan(value) || value == INFINITY) throw Fail("MSW_OPT_INIT_BOUND: a number below +inf");
+        h->opts.init_bound = value;
+        break;
+      case MSW_OPT_EM_PRIOR:
+        if (value != 0.0 && value != 1.0) throw Fail("MSW_OPT_EM_PRIOR: 0 (MAP) or 1 (ML)");
+        h->opts.em_prior = (int32_t)value;
+        break;
+      case MSW_OPT_EM_STOP:
+        if (value != 0.0 && value != 1.0) throw Fail("MSW_OPT_EM_STOP: 0 (log-likelihood gain) or 1 (largest move of a weight)");
+        h->opts.em_stop = (int32_t)value;
+        break;
+      default: throw Fail("msw_core_set_option: unknown option id");
+    }
+  });
+}
+int msw_core_get_option(msw_handle h, int option, double *value) {
+  return guarded(h, [&] {
+    if (!value) throw Fail("null out");
+    switch (option) {
+      case MSW_OPT_CHECK_EVERY: *value = h->opts.check_every; break;
+      case MSW_OPT_INIT_BOUND: *value = h->opts.init_bound; break;
+      case MSW_OPT_EM_PRIOR: *value = h->opts.em_prior; break;
+      case MSW_OPT_EM_STOP: *value = h->opts.em_stop; break;
+      default: throw Fail("msw_core_get_option: unknown option id");
+    }
+  });
 }
 int msw_core_last_timing(msw_handle h, msw_timing *out) {
   return guarded(h, [&] {

@@ -78,19 +78,29 @@ __global__ __launch_bounds__(256) void k_tables(const Scalars *sc, int n_tab, co
   }
 }
 
-// {max, min} of the table values in the slot area (one workgroup; at upload)
-__global__ __launch_bounds__(1024) void k_minmax(const double *v, uint32_t n, double *out) {
+// {max, min} of n values (at upload: the table values of the slot area, or -- value records -- every listed cell's
+// value, up to 5e8 of them: any number of workgroups, each leaving its pair in out[2 b], out[2 b + 1]; a second
+// launch with stride2 = 1 over the pairs -- one workgroup -- leaves the result in out[0], out[1])
+__global__ __launch_bounds__(1024) void k_minmax(const double *v, uint64_t n, int pairs, double *out) {
   __shared__ double sh[32];
   double mx = -INFINITY, mn = INFINITY;
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    mx = fmax(mx, v[i]);
-    mn = fmin(mn, v[i]);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  if (pairs) {  // v holds n {max, min} pairs
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      mx = fmax(mx, v[2 * i]);
+      mn = fmin(mn, v[2 * i + 1]);
+    }
+  } else {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      mx = fmax(mx, v[i]);
+      mn = fmin(mn, v[i]);
+    }
   }
   mx = block_max(mx, sh);
   mn = -block_max(-mn, sh);
   if (threadIdx.x == 0) {
-    out[0] = mx;
-    out[1] = mn;
+    out[2 * blockIdx.x] = mx;
+    out[2 * blockIdx.x + 1] = mn;
   }
 }
 
@@ -472,7 +482,9 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
     for (int g = tid; g < G; g += nt) tr.theta[(size_t)it * G + g] = Nc[g] / csum;
   }
   int done = 0;
-  if (!s0.fixed_iters && (bound - oldbound < tol) && !didreset) done = 1;
+  // (check_every > 1: the rule is tested after iterations n, 2n, ... only -- msw_core_set_option)
+  if (!s0.fixed_iters && (bound - oldbound < tol) && !didreset && (s0.check_every <= 1 || (it + 1) % s0.check_every == 0))
+    done = 1;
   if (it + 1 >= s0.max_iters) done = 1;
   __syncthreads();
   if (tid == 0) {
@@ -648,8 +660,9 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
                                                     const double *alpha0, double *u, double *os_u,
                                                     double *step_u, double tol, int max_iters,
                                                     int fixed_iters, int trace_theta, int flavor,
-                                                    double logzi, double init_bound, int *tab_built,
+                                                    double logzi, SolveOpts so, int *tab_built,
                                                     const double *trange) {
+  const double init_bound = so.init_bound;
   __shared__ double sh[32];
   const int tid = threadIdx.x, nt = blockDim.x;
   double s = 0.0;
@@ -697,6 +710,9 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
     z.xb = 1.0;
     z.tref = 0.0;
     z.fx_shift = 9;
+    z.check_every = so.check_every < 1 ? 1 : so.check_every;
+    z.em_prior = so.em_prior;
+    z.em_stop = so.em_stop;
     *sc = z;
     tab_built[0] = -1;  // no tables yet
     tab_built[1] = 0;

@@ -37,7 +37,18 @@ typedef struct orc_rcg_opts {
   double init_bound;      /* rcgpar: long double bound = -100000.0 before the loop      */
   int    weight_newnorm;  /* 0 = rcgpar (newnorm not weighted by EC counts)             */
   int    max_trace;       /* number of iterations to record in trace arrays             */
+  int    check_every;     /* 1 = rcgpar as restated (stop rule tested after every iteration);
+                           * n > 1: tested only after iterations n, 2n, ... (every published
+                           * iteration count is a multiple of 5, docs/gpubenchmarks.md:15-25 -- the verbose log
+                           * prints every 5th iteration, and "checked on a 5-grid" is the other reading)  */
 } orc_rcg_opts;
+
+/* EM variants (rcgpar::em_torch is absent: [UPSTREAM-UNVERIFIED]; the alternatives are explicit) */
+typedef struct orc_em_opts {
+  int prior_mode;   /* 0 = MAP: Dirichlet(alpha0) as pseudo-counts alpha0 - 1 (default); 1 = ML: alpha0 ignored */
+  int stop_rule;    /* 0 = gain of the weighted log-likelihood < tol (default); 1 = max_g |theta_new - theta_old| < tol */
+  int check_every;  /* as orc_rcg_opts.check_every */
+} orc_em_opts;
 
 /* per-iteration trace (arrays of length opts.max_trace, may be NULL) */
 typedef struct orc_rcg_trace {
@@ -108,6 +119,10 @@ void orc_mixture_components(const double *gamma, size_t G, size_t E, const doubl
 size_t orc_em_dense(const double *logl, size_t G, size_t E, const double *logc,
                     const double *alpha0, double tol, size_t max_iters, double *gamma_out,
                     double *theta_out, double *bound_out);
+/* the same with the variant switches (opts == NULL: the defaults = orc_em_dense) */
+size_t orc_em_dense_opts(const double *logl, size_t G, size_t E, const double *logc,
+                         const double *alpha0, double tol, size_t max_iters, const orc_em_opts *opts,
+                         double *gamma_out, double *theta_out, double *bound_out);
 
 /* ---- bootstrap (src/BootstrapSample.cpp:33-73) --------------------------------------- */
 /* libstdc++ types, exactly as the reference instantiates them.  One call = `n_reps`

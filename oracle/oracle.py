@@ -24,7 +24,12 @@ def build(force=False):
 
 
 class _Opts(C.Structure):
-    _fields_ = [("init_bound", C.c_double), ("weight_newnorm", C.c_int), ("max_trace", C.c_int)]
+    _fields_ = [("init_bound", C.c_double), ("weight_newnorm", C.c_int), ("max_trace", C.c_int),
+                ("check_every", C.c_int)]
+
+
+class _EmOpts(C.Structure):
+    _fields_ = [("prior_mode", C.c_int), ("stop_rule", C.c_int), ("check_every", C.c_int)]
 
 
 class _Trace(C.Structure):
@@ -71,6 +76,9 @@ class Oracle:
         L.orc_em_dense.restype = C.c_size_t
         L.orc_em_dense.argtypes = [_dp, C.c_size_t, C.c_size_t, _dp, _dp, C.c_double, C.c_size_t,
                                    C.c_void_p, _dp, C.POINTER(C.c_double)]
+        L.orc_em_dense_opts.restype = C.c_size_t
+        L.orc_em_dense_opts.argtypes = [_dp, C.c_size_t, C.c_size_t, _dp, _dp, C.c_double, C.c_size_t,
+                                        C.POINTER(_EmOpts), C.c_void_p, _dp, C.POINTER(C.c_double)]
         L.orc_bootstrap_counts_stdlib.argtypes = [_u32p, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, _u32p]
         L.orc_bootstrap_counts_restated.argtypes = [_u32p, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, _u32p]
         L.orc_discrete_cp.argtypes = [_u32p, C.c_size_t, _dp]
@@ -123,8 +131,8 @@ class Oracle:
         return out
 
     # ---- optimiser -----------------------------------------------------------------
-    def _opts_trace(self, G, trace, init_bound, weight_newnorm):
-        o = _Opts(init_bound, int(weight_newnorm), int(trace))
+    def _opts_trace(self, G, trace, init_bound, weight_newnorm, check_every=1):
+        o = _Opts(init_bound, int(weight_newnorm), int(trace), int(check_every))
         t = None
         arrs = None
         if trace:
@@ -135,12 +143,12 @@ class Oracle:
         return o, t, arrs
 
     def rcg_optl_dense(self, logl, logc, alpha0, tol=1e-6, max_iters=5000, trace=0,
-                       init_bound=-100000.0, weight_newnorm=0):
+                       init_bound=-100000.0, weight_newnorm=0, check_every=1):
         """rcgpar::rcg_optl_omp restated; logl is G x E (rows = groups)."""
         logl = np.ascontiguousarray(logl, np.float64)
         G, E = logl.shape
         gamma = np.empty((G, E))
-        o, t, arrs = self._opts_trace(G, trace, init_bound, weight_newnorm)
+        o, t, arrs = self._opts_trace(G, trace, init_bound, weight_newnorm, check_every)
         b = C.c_double()
         it = self.lib.orc_rcg_optl_dense(logl, G, E, np.ascontiguousarray(logc, np.float64),
                                          np.ascontiguousarray(alpha0, np.float64), tol, max_iters,
@@ -148,12 +156,13 @@ class Oracle:
         return dict(gamma=gamma, iters=it, bound=b.value, trace=arrs)
 
     def rcg_optl_csr(self, rowptr, grp, lutidx, lut, logzi, G, logc, alpha0, tol=1e-6,
-                     max_iters=5000, trace=0, want_gamma=False, init_bound=-100000.0, weight_newnorm=0):
+                     max_iters=5000, trace=0, want_gamma=False, init_bound=-100000.0, weight_newnorm=0,
+                     check_every=1):
         rowptr = np.ascontiguousarray(rowptr, np.uint64)
         E = len(rowptr) - 1
         theta = np.empty(G)
         gamma = np.empty((G, E)) if want_gamma else None
-        o, t, arrs = self._opts_trace(G, trace, init_bound, weight_newnorm)
+        o, t, arrs = self._opts_trace(G, trace, init_bound, weight_newnorm, check_every)
         b = C.c_double()
         lut = np.ascontiguousarray(lut, np.float64).ravel()
         it = self.lib.orc_rcg_optl_csr(rowptr, np.ascontiguousarray(grp, np.uint32),
@@ -165,12 +174,12 @@ class Oracle:
         return dict(theta=theta, gamma=gamma, iters=it, bound=b.value, trace=arrs)
 
     def rcg_optl_dense_structured(self, logl, logc, alpha0, tol=1e-6, max_iters=5000, trace=0,
-                                  want_gamma=False, init_bound=-100000.0, weight_newnorm=0):
+                                  want_gamma=False, init_bound=-100000.0, weight_newnorm=0, check_every=1):
         logl = np.ascontiguousarray(logl, np.float64)
         G, E = logl.shape
         theta = np.empty(G)
         gamma = np.empty((G, E)) if want_gamma else None
-        o, t, arrs = self._opts_trace(G, trace, init_bound, weight_newnorm)
+        o, t, arrs = self._opts_trace(G, trace, init_bound, weight_newnorm, check_every)
         b = C.c_double()
         it = self.lib.orc_rcg_optl_dense_structured(logl, G, E, np.ascontiguousarray(logc, np.float64),
                                                     np.ascontiguousarray(alpha0, np.float64), tol, max_iters,
@@ -186,15 +195,19 @@ class Oracle:
         self.lib.orc_mixture_components(gamma, G, E, np.ascontiguousarray(logc, np.float64), theta)
         return theta
 
-    def em_dense(self, logl, logc, alpha0, tol=1e-6, max_iters=5000, want_gamma=False):
+    def em_dense(self, logl, logc, alpha0, tol=1e-6, max_iters=5000, want_gamma=False, prior="map",
+                 stop="gain", check_every=1):
+        """rcgpar::em_torch restated [UPSTREAM-UNVERIFIED]; prior: "map" (alpha0 - 1 pseudo-counts) | "ml";
+        stop: "gain" (log-likelihood gain < tol) | "theta" (largest move of a weight < tol)."""
         logl = np.ascontiguousarray(logl, np.float64)
         G, E = logl.shape
         theta = np.empty(G)
         gamma = np.empty((G, E)) if want_gamma else None
         b = C.c_double()
-        it = self.lib.orc_em_dense(logl, G, E, np.ascontiguousarray(logc, np.float64),
-                                   np.ascontiguousarray(alpha0, np.float64), tol, max_iters,
-                                   gamma.ctypes.data if want_gamma else None, theta, C.byref(b))
+        eo = _EmOpts({"map": 0, "ml": 1}[prior], {"gain": 0, "theta": 1}[stop], int(check_every))
+        it = self.lib.orc_em_dense_opts(logl, G, E, np.ascontiguousarray(logc, np.float64),
+                                        np.ascontiguousarray(alpha0, np.float64), tol, max_iters, C.byref(eo),
+                                        gamma.ctypes.data if want_gamma else None, theta, C.byref(b))
         return dict(theta=theta, gamma=gamma, iters=it, bound=b.value)
 
     # ---- bootstrap -----------------------------------------------------------------

@@ -38,6 +38,13 @@ void orc_default_opts(orc_rcg_opts *o) {
   o->init_bound = -100000.0;
   o->weight_newnorm = 0;
   o->max_trace = 0;
+  o->check_every = 1;
+}
+namespace {
+// the stop rule is tested after iteration k (0-based) only on the grid of check_every (msweep_oracle.h)
+inline bool on_check_grid(const orc_rcg_opts &o, size_t k) {
+  return o.check_every <= 1 || (k + 1) % (size_t)o.check_every == 0;
+}
 }
 
 // src/Sample.cpp:87-97 (rcgpar carries the same series)
@@ -272,7 +279,7 @@ size_t orc_rcg_optl_dense(const double *logl, size_t G, size_t E, const double *
       std::memcpy(oldstep.data(), step.data(), n * sizeof(double));
     }
     record(trace, &opts, k, (double)bound, newnorm, beta_FR, didreset, N.data(), alpha0, G, csum);
-    if (bound - oldbound < tol && !didreset) {
+    if (bound - oldbound < tol && !didreset && on_check_grid(opts, k)) {
       D.logsumexp(gamma, oldm.data());
       ++k;
       break;
@@ -685,7 +692,7 @@ size_t structured_loop(size_t G, size_t E, const double *logc, const double *alp
       os.u = step_u;
     }
     record(trace, &opts, k, (double)bound, newnorm, beta_FR, didreset, N.data(), alpha0, G, csum);
-    if (bound - oldbound < tol && !didreset) { ++k; break; }
+    if (bound - oldbound < tol && !didreset && on_check_grid(opts, k)) { ++k; break; }
   }
   if (theta_out) for (size_t g = 0; g < G; ++g) theta_out[g] = Nc[g] / csum;
   if (bound_out) *bound_out = (double)bound;
@@ -757,13 +764,18 @@ size_t orc_rcg_optl_dense_structured(const double *logl, size_t G, size_t E,
 //   E: gamma_gj = log theta_g + L_gj - logsumexp_g(.)
 //   M: theta_g  = (sum_j c_j exp(gamma_gj) + alpha0_g - 1) / (sum_j c_j + sum_g (alpha0_g - 1))
 //   stop when the weighted log-likelihood gain drops below tol.
-size_t orc_em_dense(const double *L, size_t G, size_t E, const double *logc,
-                    const double *alpha0, double tol, size_t max_iters, double *gamma_out,
-                    double *theta_out, double *bound_out) {
+// Variants behind orc_em_opts (msweep_oracle.h): ML instead of MAP (theta_g = sum_j c_j exp(gamma_gj) / sum_j c_j),
+// stop on the largest move of a weight instead of the gain, stop rule on a grid of iterations.
+size_t orc_em_dense_opts(const double *L, size_t G, size_t E, const double *logc,
+                         const double *alpha0, double tol, size_t max_iters, const orc_em_opts *opts_in,
+                         double *gamma_out, double *theta_out, double *bound_out) {
+  orc_em_opts eo = {0, 0, 1};
+  if (opts_in) eo = *opts_in;
+  const bool ml = eo.prior_mode == 1;
   std::vector<double> theta(G, 1.0 / (double)G), logth(G), acc(G), c(E);
   double csum = 0.0, asum = 0.0;
   for (size_t j = 0; j < E; ++j) { c[j] = std::exp(logc[j]); csum += c[j]; }
-  for (size_t g = 0; g < G; ++g) asum += alpha0[g] - 1.0;
+  if (!ml) for (size_t g = 0; g < G; ++g) asum += alpha0[g] - 1.0;
   long double ll = -std::numeric_limits<double>::infinity();
   size_t k = 0;
   std::vector<double> y(G);
@@ -779,13 +791,18 @@ size_t orc_em_dense(const double *L, size_t G, size_t E, const double *logc,
       const double r = c[j] / Z;
       for (size_t g = 0; g < G; ++g) acc[g] += r * y[g];
     }
+    double dmax = 0.0;  // largest move of a weight in this M-step (stop_rule 1)
     for (size_t g = 0; g < G; ++g) {
-      double t = (acc[g] + alpha0[g] - 1.0) / (csum + asum);
-      theta[g] = t > 0.0 ? t : 0.0;
+      double t = ml ? acc[g] / csum : (acc[g] + alpha0[g] - 1.0) / (csum + asum);
+      t = t > 0.0 ? t : 0.0;
+      dmax = std::max(dmax, std::fabs(t - theta[g]));
+      theta[g] = t;
     }
     const long double gain = newll - ll;
     ll = newll;
-    if (k > 0 && gain < tol) { ++k; break; }
+    const bool grid = eo.check_every <= 1 || (k + 1) % (size_t)eo.check_every == 0;
+    const bool small = eo.stop_rule == 1 ? dmax < tol : gain < tol;
+    if (k > 0 && small && grid) { ++k; break; }
   }
   if (theta_out) for (size_t g = 0; g < G; ++g) theta_out[g] = theta[g];
   if (bound_out) *bound_out = (double)ll;
@@ -800,6 +817,12 @@ size_t orc_em_dense(const double *L, size_t G, size_t E, const double *logc,
     }
   }
   return k;
+}
+
+size_t orc_em_dense(const double *L, size_t G, size_t E, const double *logc,
+                    const double *alpha0, double tol, size_t max_iters, double *gamma_out,
+                    double *theta_out, double *bound_out) {
+  return orc_em_dense_opts(L, G, E, logc, alpha0, tol, max_iters, nullptr, gamma_out, theta_out, bound_out);
 }
 
 }  // extern "C"

@@ -128,12 +128,12 @@ def test_cli_likelihood_roundtrip_probs_and_rate(tmp_path, oracle, capsys):
     assert main(base + ["--write-likelihood", "--no-fit-model"]) == 0
     assert not os.path.exists(pre + "_abundances.txt")
     grouping, aln, L, mask, logc = _oracle_pipeline(oracle, tmp_path)
-    rows = [ln.split("\t") for ln in open(pre + "_likelihoods.txt").read().splitlines()]
+    rows = [ln.split("\t") for ln in open(pre + "_likelihoods.tsv").read().splitlines()]
     assert len(rows) == aln.n_ecs() and [int(r[0]) for r in rows] == aln.ec_counts.tolist()
     np.testing.assert_allclose(np.array([[float(x) for x in r[1:]] for r in rows]).T, L, rtol=1e-5)
     # estimate from the written (6-digit) likelihood through the dense path
     pre2 = str(tmp_path / "rt2")
-    assert main(["--read-likelihood", pre + "_likelihoods.txt", "-i", str(tmp_path / "clustering.txt"), "-o", pre2,
+    assert main(["--read-likelihood", pre + "_likelihoods.tsv", "-i", str(tmp_path / "clustering.txt"), "-o", pre2,
                  "--write-probs", "--run-rate"]) == 0
     assert main(base) == 0
     _, rows_direct = _parse(pre + "_abundances.txt")

@@ -20,15 +20,20 @@ OpenMP) runs the same number of iterations as the HIP path with a theta snapshot
         iterations.  Which of those iterations stops is decided by that noise on either side (the reference's own
         count moves by ten with -t, docs/gpubenchmarks.md:15-17).  The gate is therefore what the cause allows
         and no more: with NOISE = 5e-7, the HIP path must not stop while the oracle's gain is still above
-        tol + NOISE, and must have stopped once it has fallen below tol - NOISE; when both stop together the
-        converged theta is compared once more.
+        tol + NOISE, and must have stopped once it has fallen below tol - NOISE.
+  (iv)  the ANSWERS: the theta the HIP path returns at ITS stop against the theta the oracle returns at ITS OWN stop
+        (rcgpar's rule on the oracle's own bounds) -- the north star is worded on the result, and a differing stop
+        is harmless only if this holds.  Always compared, worst component printed.
+  (v)   the bench's own layout (5000 groups: group vectors + slot table + replicas in LDS, pass-B mode 2) against the
+        reference-SHAPED algorithm -- the dense-state oracle with rcgpar's four G x E matrices -- to convergence, on
+        as many of cfg3's ECs as 16 GB of dense state hold; once more on a bootstrap replicate (-inf log counts).
 """
 import time
 
 import numpy as np
 import pytest
 
-from conftest import lutidx_of
+from conftest import dense_from_csr, lutidx_of
 from msweep_amd import synth
 from msweep_amd.likelihood import from_alignment, from_dense, from_grouped_counts, precalc_lls
 from test_gpu_rcg import FLOOR, REL, ABS, lockstep
@@ -92,10 +97,18 @@ def check_against_oracle(tag, res, tr, ref_tr):
           f"{abs(tr['bound'][n - 1] - ref_tr['bound'][n - 1]) / abs(ref_tr['bound'][n - 1]):.1e}")
     assert w_rel <= REL and w_abs <= ABS
     assert_stop_within_noise(k_gpu, ref_tr, tag)
-    if k_gpu == k_orc:
-        r, g, a = worst(res["theta"], ref_tr["theta"][k_orc - 1])
-        assert r <= REL and a <= ABS
+    assert_returned_theta(tag, res["theta"], k_gpu, ref_tr)
     assert res["theta"].sum() == pytest.approx(1.0, abs=1e-11)
+
+
+def assert_returned_theta(tag, theta_gpu, k_gpu, ref_tr):
+    """(iv): what each side RETURNS -- hip's theta after its k_gpu iterations against the oracle's after ITS OWN stop."""
+    k_orc = oracle_stop(ref_tr)
+    assert k_orc is not None, f"{tag}: the oracle's own stop lies beyond its trace ({len(ref_tr['bound'])} iterations)"
+    r, g, a = worst(theta_gpu, ref_tr["theta"][k_orc - 1])
+    print(f"{tag}: RETURNED theta, hip at its stop ({k_gpu}) vs oracle at its own ({k_orc}): worst rel err {r:.2e} "
+          f"(group {g}, theta {ref_tr['theta'][k_orc - 1][g]:.3e}), worst abs err below the floor {a:.2e}")
+    assert r <= REL and a <= ABS, (tag, k_gpu, k_orc, r, a)
 
 
 @pytest.fixture(scope="module")
@@ -134,7 +147,7 @@ def test_cfg3_csr_10M_x_5k_lockstep(gpu_core, oracle_mt, cfg3):
     tr = gpu_core.trace(res["iters"], with_theta=True)
     gpu_core.set_trace_theta(0)
     t0 = time.time()
-    ref_tr = oracle_csr_trace(oracle_mt, p, lik.log_counts(), alpha0, res["iters"] + 8)
+    ref_tr = oracle_csr_trace(oracle_mt, p, lik.log_counts(), alpha0, res["iters"] + 16)
     print(f"oracle: {res['iters'] + 2} iterations in {time.time() - t0:.0f} s")
     check_against_oracle("cfg3", res, tr, ref_tr)
     ok = tr["didreset"] == 0
@@ -167,7 +180,7 @@ def test_diverse_group_sizes_10M_x_5k_lockstep(gpu_core, oracle_mt):
     assert res["iters"] < 1000
     tr = gpu_core.trace(res["iters"], with_theta=True)
     gpu_core.set_trace_theta(0)
-    ref_tr = oracle_csr_trace(oracle_mt, p, lik.log_counts(), alpha0, res["iters"] + 8)
+    ref_tr = oracle_csr_trace(oracle_mt, p, lik.log_counts(), alpha0, res["iters"] + 16)
     check_against_oracle("diverse sizes", res, tr, ref_tr)
     again = gpu_core.solve(lik.log_counts(), alpha0)
     assert again["iters"] == res["iters"] and again["bound"] == res["bound"]
@@ -201,13 +214,14 @@ def test_cfg4_bootstrap_10M_x_5k(gpu_core, oracle_mt, cfg3):
         with np.errstate(divide="ignore"):
             logc = np.log(counts[b].astype(float))                   # -inf for ECs drawn zero times (:70)
         k = int(iters[b])
-        ref_tr = oracle_csr_trace(oracle_mt, p, logc, alpha0, k + 8)
+        ref_tr = oracle_csr_trace(oracle_mt, p, logc, alpha0, k + 16)
         k_orc = oracle_stop(ref_tr)
         r, g, a = worst(theta[b], ref_tr["theta"][k - 1])
         print(f"cfg4 replicate {b}: iterations hip {k} / oracle {k_orc}; theta after {k} iterations: worst rel err "
               f"{r:.2e} (group {g}, theta {ref_tr['theta'][k - 1][g]:.3e}), worst abs err below the floor {a:.2e}")
         assert r <= REL and a <= ABS
         assert_stop_within_noise(k, ref_tr, f"cfg4 replicate {b}")      # see the module docstring, (iii)
+        assert_returned_theta(f"cfg4 replicate {b}", theta[b], k, ref_tr)  # (iv)
         assert theta[b].sum() == pytest.approx(1.0, abs=1e-11)       # normalised by the resampled total (:513)
 
 
@@ -227,7 +241,7 @@ def test_cfg2_dense_1M_x_500_lockstep(gpu_core, oracle_mt):
     gpu_core.set_trace_theta(0)
     assert res["iters"] < 1000
     t0 = time.time()
-    n = res["iters"] + 2
+    n = res["iters"] + 16
     ref_tr = oracle_mt.rcg_optl_dense_structured(p["logl"], p["logc"], alpha0, tol=-1.0, max_iters=n, trace=n)["trace"]
     print(f"structured oracle: {n} iterations in {time.time() - t0:.0f} s")
     check_against_oracle("cfg2", res, tr, ref_tr)
@@ -236,6 +250,57 @@ def test_cfg2_dense_1M_x_500_lockstep(gpu_core, oracle_mt):
     d = oracle_mt.rcg_optl_dense(p["logl"], p["logc"], alpha0, tol=-1.0, max_iters=8, trace=8)
     print(f"dense-state oracle: 8 iterations in {time.time() - t0:.0f} s")
     lockstep(tr, d["trace"], 8, rel=1e-8)
+
+
+def theta_gates(tag, got, ref):
+    r, g, a = worst(got, ref)
+    print(f"{tag}: worst rel err {r:.2e} (group {g}, theta {ref[g]:.3e}), worst abs err below the floor {a:.2e}")
+    assert r <= REL and a <= ABS, (tag, r, a)
+
+
+def test_cfg3_layout_vs_dense_state_oracle_to_convergence(gpu_core, oracle_mt, cfg3):
+    """(v) of the module docstring.  The first N_DENSE ECs of cfg3 with all 5000 groups: the HIP CSR path in the layout
+    the bench runs (asserted) against rcgpar's algorithm AS THE REFERENCE STRUCTURES IT (oracle.rcg_optl_dense: gamma,
+    step, oldstep and L as G x E fp64 matrices, log domain throughout, no background trick, no guard) --
+    lock-step over the first 20 iterations, the converged abundances each side returns, and the same once more for a
+    bootstrap replicate of those ECs (a third of the log counts -inf, src/BootstrapSample.cpp:70)."""
+    N_DENSE, G = 100_000, 5000
+    p = cfg3
+    nz = int(p["rowptr"][N_DENSE])
+    q = dict(rowptr=np.ascontiguousarray(p["rowptr"][:N_DENSE + 1]), grp=np.ascontiguousarray(p["grp"][:nz]),
+             cnt=np.ascontiguousarray(p["cnt"][:nz]), ec_counts=np.ascontiguousarray(p["ec_counts"][:N_DENSE]),
+             group_sizes=p["group_sizes"])
+    alpha0 = np.ones(G)
+    lik = from_grouped_counts(gpu_core, q["rowptr"], q["grp"], q["cnt"], q["ec_counts"], q["group_sizes"])
+    li = gpu_core.layout_info()
+    print(li)
+    assert li["record_bytes"] == 4 and li["index_records"] == 0 and li["groups_in_lds"] == 1
+    assert li["table_in_lds"] == 1 and li["passB_mode"] == 2          # the bench's layout (BENCH_r03 "layout")
+    L = dense_from_csr(q, p["lut"])                                   # 4 GB
+    w = q["ec_counts"].astype(np.uint32)
+    counts = gpu_core.resample_counts(w, 42, int(w.sum()), 0, 1)[0]
+    np.testing.assert_array_equal(counts, oracle_mt.bootstrap_counts(w, 42, int(w.sum()), 1)[0])
+    with np.errstate(divide="ignore"):
+        cases = [("cfg3 slice", lik.log_counts()), ("cfg3 slice, bootstrap replicate", np.log(counts.astype(float)))]
+    for tag, logc in cases:
+        gpu_core.set_trace_theta(32)
+        res = gpu_core.solve(logc, alpha0)
+        tr = gpu_core.trace(min(res["iters"], 32), with_theta=True)
+        gpu_core.set_trace_theta(0)
+        t0 = time.time()
+        d = oracle_mt.rcg_optl_dense(L, logc, alpha0, trace=32)
+        th_d = oracle_mt.mixture_components(d["gamma"], logc)
+        print(f"{tag}: {N_DENSE} ECs x {G} groups, iterations hip {res['iters']} / dense-state oracle {d['iters']} "
+              f"({time.time() - t0:.0f} s); zero-count ECs: {int(np.sum(np.isinf(logc)))}")
+        k = min(20, res["iters"], d["iters"])
+        assert tr["didreset"][:k].tolist() == d["trace"]["didreset"][:k].tolist()
+        np.testing.assert_allclose(tr["bound"][:k], d["trace"]["bound"][:k], rtol=1e-9)
+        for i in range(k):
+            r, g, a = worst(tr["theta"][i], d["trace"]["theta"][i])
+            assert r <= REL and a <= ABS, (tag, i, r, a)
+        assert abs(res["iters"] - d["iters"]) <= 3
+        theta_gates(f"{tag}: RETURNED theta, hip at its stop vs the dense-state oracle at its own", res["theta"], th_d)
+        del d
 
 
 def test_cfg5_sparse_50M_x_20k_min_hits(gpu_core, oracle_mt):

@@ -124,6 +124,24 @@ def test_hybrid_off_switch_gives_the_same_answer(oracle, monkeypatch):
     assert_theta(out[0][0]["theta"], out[1][0]["theta"], rel=1e-9, abs_=1e-12)
 
 
+def test_hybrid_replanned_when_the_slice_geometry_does_not_fit(oracle, monkeypatch):
+    """The hot-segment split of a slice rides above its 27-bit row offset: a likelihood of 2^27 rows or more (34 GB of
+    records) is planned again WITHOUT the hybrid area -- all-memory tables -- instead of being refused
+    (host_pack.inc).  The limit is lowered by a developer switch to reach the branch at test size."""
+    p = diverse(80_000, 3000, 23, max_other=10)
+    monkeypatch.setenv("MSWEEP_FORCE_LDS", "10")
+    with Core(0) as core:
+        ref, _, logc, alpha0 = solve_csr(core, p)
+        assert core.layout_info()["index_records"] == 1
+    monkeypatch.setenv("MSWEEP_HYBRID_MAX_ROWS", "100")
+    with Core(0) as core:
+        res, _, _, _ = solve_csr(core, p)
+        li = core.layout_info()
+        assert li["index_records"] == 0 and li["rows"] > 100, li
+    assert res["iters"] == ref["iters"]
+    assert_theta(res["theta"], ref["theta"], rel=1e-9, abs_=1e-12)
+
+
 @pytest.mark.parametrize("G", [12000, 19500])
 def test_hybrid_with_many_groups(oracle, G):
     """More groups than the LDS images hold AND more table slots than fit beside what is left: pass B keeps its column

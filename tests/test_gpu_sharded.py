@@ -284,3 +284,82 @@ def test_sharded_build_with_min_hits_equals_single_handle(gpu_core, n_ranks):
         assert res["iters"] == single["iters"]
         assert_theta(res["theta"], single["theta"])
         np.testing.assert_array_equal(res["theta"], out[0][2]["theta"])
+
+
+@pytest.mark.parametrize("min_hits,bad", [(0, "target"), (2200, "target"), (2200, "tptr"), (0, "count")])
+def test_sharded_build_failing_rank_fails_every_rank_and_nobody_waits(gpu_core, min_hits, bad):
+    """A rank whose OWN block of the pseudoalignment is bad (a target id out of range / ec_tptr not monotone: found on
+    the device after K1; an EC that hits more sequences of a group than the group holds: found after the --min-hits
+    all-reduce) fails TOGETHER with its peers through the build's status word -- nobody waits in the all-reduce of the
+    group hits or in the first collective of a solve -- and the communicator is good for a second, clean build."""
+    from msweep_amd.likelihood import from_alignment
+    p = synth.make_csr_problem(40000, 400, seed=46, max_other=5, theta_support=60)
+    aln = synth.csr_to_targets(p)
+    n_ranks = 3
+    bounds = shard_ecs(p["rowptr"], n_ranks)
+    tptr = aln["ec_tptr"].astype(np.int64)
+    comms = Comm.local(n_ranks)
+    first, second = [None] * n_ranks, [None] * n_ranks
+
+    def block(r, spoil):
+        e0, e1 = bounds[r], bounds[r + 1]
+        tp = (tptr[e0:e1 + 1] - tptr[e0]).astype(np.uint64)
+        tg = aln["ec_targets"][tptr[e0]:tptr[e1]].copy()
+        sizes = p["group_sizes"].copy()
+        if spoil and bad == "target":
+            tg[len(tg) // 2] = len(aln["target_group"]) + 7
+        if spoil and bad == "tptr":
+            tp[len(tp) // 2] = tp[len(tp) // 2 + 1] + 3
+        if spoil and bad == "count":          # the rank believes group 0 holds one sequence: some EC hits it more often
+            g = int(np.bincount(p["grp"][p["cnt"] > 1]).argmax())
+            sizes[g] = 1
+        return tp, tg, sizes, p["ec_counts"][e0:e1]
+
+    def work(r):
+        core = Core(0)
+        try:
+            core.set_comm(comms[r])
+            tp, tg, sizes, ecc = block(r, spoil=(r == 1))
+            try:
+                from_alignment(core, tp, tg, aln["target_group"], sizes, ecc, min_hits=min_hits)
+                first[r] = "ok"
+            except RuntimeError as ex:
+                first[r] = str(ex)
+            tp, tg, sizes, ecc = block(r, spoil=False)
+            lk = from_alignment(core, tp, tg, aln["target_group"], sizes, ecc, min_hits=min_hits)
+            second[r] = core.solve(None, np.ones(lk.n_groups))
+            core.set_comm(None)
+        except Exception as ex:
+            second[r] = ex
+        finally:
+            core.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+        assert not t.is_alive(), "a rank is still waiting in a collective of the sharded build"
+    want = {"target": "target id out of range", "tptr": "ec_tptr not monotone", "count": "more sequences of a group"}[bad]
+    assert want in first[1], first
+    assert "another rank of the sharded build failed" in first[0] and "another rank" in first[2], first
+    for r in range(n_ranks):
+        assert not isinstance(second[r], Exception), second[r]
+        np.testing.assert_array_equal(second[r]["theta"], second[0]["theta"])
+
+
+def test_bootstrap_bad_arguments_fail_the_call_not_a_table_of_nan(gpu_core):
+    """msw_core_bootstrap / _dist: an unknown algorithm id or max_iters = 0 is an ERROR (include/msweep_core.h: "bad
+    arguments fail the whole call"); only a numerically failed replicate becomes a row of NaN."""
+    p = synth.make_csr_problem(5000, 20, seed=48, max_other=4)
+    from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    w = p["ec_counts"].astype(np.uint32)
+    with pytest.raises(RuntimeError, match="unknown algorithm"):
+        gpu_core.bootstrap(w, 1, int(w.sum()), 0, 2, np.ones(20), algo=7)
+    with pytest.raises(RuntimeError, match="max_iters"):
+        gpu_core.bootstrap(w, 1, int(w.sum()), 0, 2, np.ones(20), max_iters=0)
+    comm = Comm.local(1)[0]
+    with pytest.raises(RuntimeError):
+        gpu_core.bootstrap_dist(comm, w, 1, int(w.sum()), 2, np.ones(20), prec=9)
+    theta, _ = gpu_core.bootstrap_dist(comm, w, 1, int(w.sum()), 2, np.ones(20))   # and the communicator still works
+    assert np.all(np.isfinite(theta))

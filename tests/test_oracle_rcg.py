@@ -115,3 +115,45 @@ def test_em_oracle_converges_to_same_optimum_region(oracle):
     em = oracle.em_dense(L, logc, alpha0, tol=1e-10, max_iters=20000)
     assert em["theta"].sum() == pytest.approx(1.0, abs=1e-12)
     np.testing.assert_allclose(em["theta"], c["expect"]["theta"], atol=2e-3)
+
+
+def test_check_every_knob_same_trajectory_stop_on_the_grid(oracle):
+    """orc_rcg_opts.check_every (every published iteration count is a multiple of 5): the
+    trajectory is the default's, only the stop moves to the next iteration on the grid -- in all three loops."""
+    p = synth.make_csr_problem(4000, 40, seed=9, max_other=5)
+    lut = precalc_lls(p["group_sizes"])
+    L = dense_from_csr(p, lut)
+    logc = np.log(p["ec_counts"].astype(float))
+    alpha0 = np.ones(40)
+    runs = [lambda **kw: oracle.rcg_optl_dense(L, logc, alpha0, trace=200, **kw),
+            lambda **kw: oracle.rcg_optl_dense_structured(L, logc, alpha0, trace=200, **kw),
+            lambda **kw: oracle.rcg_optl_csr(p["rowptr"], p["grp"], lutidx_of(p, lut), lut, np.log(0.01), 40, logc,
+                                             alpha0, trace=200, **kw)]
+    for run in runs:
+        d, g = run(), run(check_every=5)
+        # (not necessarily the NEXT grid point: past convergence the gains hover around zero, and a negative one
+        # is a reset iteration, which never stops)
+        assert g["iters"] % 5 == 0 and d["iters"] <= g["iters"]
+        np.testing.assert_array_equal(g["trace"]["bound"][:d["iters"]], d["trace"]["bound"][:d["iters"]])
+        # every gain between the default's stop and the grid's was below tol or a reset: nothing else delays it
+        assert run(check_every=1)["iters"] == d["iters"]
+
+
+def test_em_variant_knobs(oracle):
+    """orc_em_opts: ML drops the prior's pseudo-counts (equal to MAP at alpha0 = 1); the theta-change stop rule
+    ends at a fixed point of the same map."""
+    p = synth.make_csr_problem(3000, 30, seed=10, max_other=5)
+    lut = precalc_lls(p["group_sizes"])
+    L = dense_from_csr(p, lut)
+    logc = np.log(p["ec_counts"].astype(float))
+    one, prior = np.ones(30), np.full(30, 3.0)
+    m1, l1 = oracle.em_dense(L, logc, one, tol=1e-9), oracle.em_dense(L, logc, one, tol=1e-9, prior="ml")
+    assert m1["iters"] == l1["iters"]
+    np.testing.assert_allclose(m1["theta"], l1["theta"], rtol=1e-12, atol=1e-15)   # (x + 1) - 1 drops what is below 1e-16
+    m3, l3 = oracle.em_dense(L, logc, prior, tol=1e-9), oracle.em_dense(L, logc, prior, tol=1e-9, prior="ml")
+    np.testing.assert_allclose(l3["theta"], l1["theta"], rtol=1e-12)          # ML ignores alpha0
+    assert np.max(np.abs(m3["theta"] - l3["theta"])) > 1e-4                  # MAP does not
+    t = oracle.em_dense(L, logc, one, tol=1e-10, stop="theta")
+    np.testing.assert_allclose(t["theta"], m1["theta"], atol=1e-6)
+    g5 = oracle.em_dense(L, logc, one, tol=1e-9, check_every=5)
+    assert g5["iters"] % 5 == 0 and m1["iters"] <= g5["iters"] < m1["iters"] + 5
