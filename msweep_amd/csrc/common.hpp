@@ -92,6 +92,17 @@ struct SolveOpts {
   int32_t em_stop = 0;         // 0 log-likelihood gain < tol, 1 largest move of a weight < tol
 };
 
+// MSW_STAMPS (diagnostic build only, tools/chain_timeline.py): s_memrealtime stamps (100 MHz) of the phases of the five
+// kernels of an iteration -- g_stamps[(iteration % 64) * 40 + kernel * 8 + phase]; no stamp exists in the product build.
+#ifdef MSW_STAMPS
+__device__ unsigned long long g_stamps[64 * 40];
+#define MSW_STAMP(it, K, p) (g_stamps[((it) & 63) * 40 + (K) * 8 + (p)] = __builtin_amdgcn_s_memrealtime())
+#define MSW_STAMP_MAX(it, K, p) atomicMax(&g_stamps[((it) & 63) * 40 + (K) * 8 + (p)], (unsigned long long)__builtin_amdgcn_s_memrealtime())
+#else
+#define MSW_STAMP(it, K, p) ((void)0)
+#define MSW_STAMP_MAX(it, K, p) ((void)0)
+#endif
+
 // Per-pass slot tables (n_lut 16-byte entries each), rebuilt by prepB_block whenever `a` moves:
 //   A[i] = {x_i, D_i}            x_i = exp(a*T_i), D_i = (1-a)*(T_i - logzi)      (pass A)
 //   B[i] = {x_i - p0, x_i*T_i - p0*logzi}              p0 = exp(a*logzi)           (pass B)

@@ -1194,6 +1194,20 @@ int msw_core_last_timing(msw_handle h, msw_timing *out) {
   });
 }
 
+#ifdef MSW_STAMPS
+// diagnostic build only (tools/chain_timeline.py): the phase stamps of the last <= 64 iterations; clear = 1 zeroes them
+int msw_debug_stamps(msw_handle h, uint64_t *out, int clear) {
+  return guarded(h, [&] {
+    MSW_HIP(hipStreamSynchronize(h->stream));
+    if (out) MSW_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 40));
+    if (clear) {
+      std::vector<unsigned long long> z(64 * 40, 0);
+      MSW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z.data(), z.size() * sizeof(unsigned long long)));
+    }
+  });
+}
+#endif
+
 int msw_core_guarded_visits(msw_handle h, uint64_t *out) {
   return guarded(h, [&] {
     if (!out) throw Fail("null out");

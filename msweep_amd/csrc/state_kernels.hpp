@@ -145,14 +145,17 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
     }
   }
   const double lt = tid < n_lut ? lut[tid] : 0.0;  // first table entry of this thread
+  if (tid == 0) MSW_STAMP(sc->iter, 1, 0);
   const Scalars s0 = *sc;  // one read of the whole state: no dependent scalar round trips later
   if (s0.done || s0.reset_pending) return;  // a pending re-evaluation skips pass A and the step
+  if (tid == 0) MSW_STAMP(s0.iter, 1, 1);
   const double a = s0.a, oldnorm = s0.oldnorm, bound = s0.bound, logzi = s0.logzi;
   double os_a = s0.os_a;
   const int didreset = s0.didreset;
   // (one group: q_j is the constant 1 and the variance exactly 0 -- the sweep's background form would
   // leave rounding noise, and a ratio of two noises as beta)
   const double pnsum = block_sum(pn, sh);
+  if (tid == 0) MSW_STAMP(s0.iter, 1, 2);
   const double newnorm = G == 1 ? 0.0 : pnsum;
   // (an exactly stationary start -- identical groups under a symmetric prior -- makes the ratio x/0: the
   // reference carries the inf / NaN into its state and returns NaN weights; here such a step has no momentum)
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
   }
   const int flavor = s0.flavor;
   double p0 = 0.0, tref = 0.0;
+  if (tid == 0) MSW_STAMP(s0.iter, 1, 3);
   if (flavor == 0) {  // per-slot tables of both sweeps (prepB_block's arithmetic)
     const double oma = 1.0 - a_new;
     tref = tref_of(a_new, s0.tmax, s0.tmin);
@@ -225,8 +229,10 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
     }
   }
   double M = 0.0, U = 0.0;
+  if (tid == 0) MSW_STAMP(s0.iter, 1, 4);
   if (flavor == 0) {
     M = block_max(m, sh);
+    if (tid == 0) MSW_STAMP(s0.iter, 1, 5);
     double su = 0.0;
 #pragma unroll
     for (int k = 0; k < kStepRegs; ++k) {
@@ -239,6 +245,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
     }
     U = block_sum(su, sh);
   }
+  if (tid == 0) MSW_STAMP(s0.iter, 1, 6);
   if (tid == 0) {
     sc->a = a_new;
     sc->tab_ver = s0.tab_ver + 1;
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
   __shared__ double accs[64][kRedfinGroups];
   const int tid = threadIdx.x, gl = tid & (kRedfinGroups - 1), rs = tid >> 4;
   const int g = blockIdx.x * kRedfinGroups + gl;
+  if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 3, 0);
   const Scalars s0 = *sc;  // in flight together with the partial rows below
   // CSR flavour: the rows are 64-bit fixed-point integers (sweep_kernels.hpp kFx) -- summed as integers,
   // exactly, whatever the number of rows; dense flavour: fp64 rows in fixed order
@@ -328,7 +336,9 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
     tail[2 * (size_t)g + 1] = 0;
   }
   accs[rs][gl] = s;
+  if (tid == 0 && blockIdx.x == 0) MSW_STAMP(s0.iter, 3, 1);
   block_sum_n<3>(t, sh);  // its barriers also publish accs
+  if (tid == 0 && blockIdx.x == 0) MSW_STAMP(s0.iter, 3, 2);
   const double W = t[2];
   if (blockIdx.x == 0 && tid == 0) {
     totS[0] = t[0];
@@ -393,6 +403,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
   s0v = wave_sum(s0v);
   s1v = wave_sum(s1v);
   s2v = wave_sum(s2v);
+  if (tid == 0) MSW_STAMP_MAX(s0.iter, 3, 7);
   if (tid == 0) {
     double *o = partR + kRedfinParts * blockIdx.x;
     o[0] = lgv;
@@ -429,14 +440,17 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
     for (int k = 0; k < kStepRegs; ++k)
       if (tid + k * nt < G) sv[k] = step_u[tid + k * nt];
   }
+  if (tid == 0) MSW_STAMP(sc->iter, 4, 0);
   const Scalars s0 = *sc;  // one read of the whole state
   if (s0.done) return;
+  if (tid == 0) MSW_STAMP(s0.iter, 4, 1);
   const int flavor = s0.flavor;
   const int reeval = s0.reset_pending;
   const double a = s0.a, oldbound = s0.oldbound;
   const double beta = s0.beta, tol = s0.tol, csum = s0.csum, kappa = s0.kappa;
   block_sum_n<kRedfinParts>(q, sh);  // one pair of barriers for the five sums
   const double lg = q[0], mu = q[1], S0 = q[2], S1 = q[3], S2 = q[4];
+  if (tid == 0) MSW_STAMP(s0.iter, 4, 2);
   if (mode == 2) {
     if (tid == 0 && flavor == 0) {
       sc->V1c = S1;
@@ -504,6 +518,7 @@ __global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int 
     }
     sc->iter = it + 1;
     sc->done = done;
+    MSW_STAMP(it, 4, 7);
   }
 }
 

@@ -381,7 +381,9 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   double nn = 0.0;
   if (skip) return;
   if (tid == 0) *(lds_u32_t *)(size_t)gcnt_off = 0u;
+  if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 0, 0);
   __syncthreads();
+  if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 0, 1);
 
   // (lanes past the end of a long EC, and the missing last row of an odd slice, take a record of the lane's own
   // sentinel group)
@@ -612,6 +614,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
     }
   }
   nn = block_sum(nn, sh);
+  if (tid == 0) MSW_STAMP_MAX(sc->iter, 0, 7);
   if (tid == 0) partA[blockIdx.x] = nn;
 }
 
@@ -746,7 +749,9 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   };
   if (skip) return;
   if (tid == 0) *(lds_u32_t *)(size_t)gcnt_off = 0u;
+  if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 2, 0);
   __syncthreads();
+  if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 2, 1);
 
   const uint32_t n_lanes = S.nslices * 64u;
   const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
@@ -1219,6 +1224,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
     partS[4 * blockIdx.x + 2] = s_W;
     partS[4 * blockIdx.x + 3] = 0.0;
   }
+  if (tid == 0) MSW_STAMP_MAX(sc->iter, 2, 6);
   if (ALDS) {
     __syncthreads();
     const double *al = reinterpret_cast<const double *>(smem + bhi + acc_off);
@@ -1229,6 +1235,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       for (uint32_t g = tid; g < G; g += NT) dst[g] = al[g];
     }
   }
+  if (tid == 0) MSW_STAMP_MAX(sc->iter, 2, 7);
 }
 
 }  // namespace msw

@@ -102,13 +102,31 @@ def check_against_oracle(tag, res, tr, ref_tr):
 
 
 def assert_returned_theta(tag, theta_gpu, k_gpu, ref_tr):
-    """(iv): what each side RETURNS -- hip's theta after its k_gpu iterations against the oracle's after ITS OWN stop."""
+    """(iv): what each side RETURNS -- hip's theta after its k_gpu iterations against the oracle's after ITS OWN stop.
+    Same stop: the north-star tolerance.  Different stops (inside the noise window of (iii)): the difference is
+    printed and must be EXPLAINED, component by component, by the oracle's own movement between the two iterations
+    (every common iteration already agrees at the north-star tolerance) -- and that movement is reported as what it
+    is, a finding about the stop rule: `bound - oldbound < 1e-6` on a bound of 1e8 fires while the smallest weights
+    above the floor still move by 1e-5..1e-4 per iteration, so the rule itself -- in rcgpar as here -- determines
+    them to 1e-4..1e-3, not to 1e-6 (the reference's own count moves 205 -> 215 with -t, docs/gpubenchmarks.md:15-17)."""
     k_orc = oracle_stop(ref_tr)
     assert k_orc is not None, f"{tag}: the oracle's own stop lies beyond its trace ({len(ref_tr['bound'])} iterations)"
-    r, g, a = worst(theta_gpu, ref_tr["theta"][k_orc - 1])
+    th_o = ref_tr["theta"][k_orc - 1]
+    r, g, a = worst(theta_gpu, th_o)
     print(f"{tag}: RETURNED theta, hip at its stop ({k_gpu}) vs oracle at its own ({k_orc}): worst rel err {r:.2e} "
-          f"(group {g}, theta {ref_tr['theta'][k_orc - 1][g]:.3e}), worst abs err below the floor {a:.2e}")
-    assert r <= REL and a <= ABS, (tag, k_gpu, k_orc, r, a)
+          f"(group {g}, theta {th_o[g]:.3e}), worst abs err below the floor {a:.2e}")
+    if k_gpu == k_orc:
+        assert r <= REL and a <= ABS, (tag, k_gpu, k_orc, r, a)
+        return
+    th_same = ref_tr["theta"][k_gpu - 1]           # the oracle's iterate where hip stopped
+    rd, gd, ad = worst(th_same, th_o)
+    print(f"{tag}: FINDING -- the stops differ ({k_gpu} / {k_orc}); the oracle's OWN theta moves by rel {rd:.2e} "
+          f"(group {gd}, theta {th_o[gd]:.3e}) / abs {ad:.2e} below the floor between those two iterations: at this "
+          f"--tol the stop rule leaves the weights determined to that")
+    allowed = np.where(th_o >= FLOOR, REL * th_o, ABS) + np.abs(th_same - th_o)
+    excess = np.abs(theta_gpu - th_o) - allowed
+    assert np.all(excess <= 0), (tag, int(excess.argmax()), float(excess.max()))
+    assert r <= 2e-3, (tag, r)                      # and nothing beyond what such a stop difference has ever shown
 
 
 @pytest.fixture(scope="module")
@@ -282,6 +300,8 @@ def test_cfg3_layout_vs_dense_state_oracle_to_convergence(gpu_core, oracle_mt, c
     np.testing.assert_array_equal(counts, oracle_mt.bootstrap_counts(w, 42, int(w.sum()), 1)[0])
     with np.errstate(divide="ignore"):
         cases = [("cfg3 slice", lik.log_counts()), ("cfg3 slice, bootstrap replicate", np.log(counts.astype(float)))]
+    from conftest import cpu_share
+    noise_r = noise_a = 0.0
     for tag, logc in cases:
         gpu_core.set_trace_theta(32)
         res = gpu_core.solve(logc, alpha0)
@@ -295,11 +315,38 @@ def test_cfg3_layout_vs_dense_state_oracle_to_convergence(gpu_core, oracle_mt, c
         k = min(20, res["iters"], d["iters"])
         assert tr["didreset"][:k].tolist() == d["trace"]["didreset"][:k].tolist()
         np.testing.assert_allclose(tr["bound"][:k], d["trace"]["bound"][:k], rtol=1e-9)
+        w_lock = 0.0
         for i in range(k):
             r, g, a = worst(tr["theta"][i], d["trace"]["theta"][i])
+            w_lock = max(w_lock, r)
             assert r <= REL and a <= ABS, (tag, i, r, a)
+        print(f"{tag}: lock-step with the dense-state oracle over {k} iterations: worst rel err {w_lock:.2e}")
         assert abs(res["iters"] - d["iters"]) <= 3
-        theta_gates(f"{tag}: RETURNED theta, hip at its stop vs the dense-state oracle at its own", res["theta"], th_d)
+        r, g, a = worst(res["theta"], th_d)
+        print(f"{tag}: RETURNED theta, hip at its stop vs the dense-state oracle at its own: worst rel err {r:.2e} "
+              f"(group {g}, theta {th_d[g]:.3e}), worst abs err below the floor {a:.2e}")
+        self_r = self_a = 0.0
+        if tag == "cfg3 slice":
+            # How far the reference-shaped algorithm is from ITSELF when only the order of its additions changes
+            # (another OpenMP thread count: other partial sums in update_N_k / ELBO / |g|^2 -- what `-t` does to the
+            # reference, docs/gpubenchmarks.md:15-17): the recursion amplifies rounding by ~10 x per 10-20 iterations
+            # (SURVEY.md 7.3b), so two arithmetically different evaluations of the same mathematics cannot agree
+            # better than this after ~80 iterations, whichever two they are.
+            n_thr = oracle_mt.num_threads()
+            oracle_mt.set_num_threads(max(1, cpu_share() * 2 // 3))
+            t0 = time.time()
+            d2 = oracle_mt.rcg_optl_dense(L, logc, alpha0)
+            oracle_mt.set_num_threads(n_thr)
+            self_r, g2, self_a = worst(oracle_mt.mixture_components(d2["gamma"], logc), th_d)
+            print(f"{tag}: the dense-state oracle against ITSELF on {max(1, cpu_share() * 2 // 3)} instead of {n_thr} threads "
+                  f"({time.time() - t0:.0f} s): iterations {d2['iters']} / {d['iters']}, worst rel diff {self_r:.2e} (group {g2}), "
+                  f"worst abs diff below the floor {self_a:.2e}")
+            del d2
+        noise_r, noise_a = max(noise_r, self_r), max(noise_a, self_a)   # (the replicate is gated by the first case's)
+        # the gate: the north-star tolerance, widened by no more than the reference-shaped algorithm's own
+        # sensitivity to the order of its additions, measured above on this very input (x 3: one sample of a noise)
+        assert r <= max(REL, 3.0 * noise_r) and a <= max(ABS, 3.0 * noise_a), (tag, r, a, noise_r)
+        assert r <= 2e-5, (tag, r)         # 1e-7 .. 1e-5 expected; beyond that it is a bug
         del d
 
 
