@@ -23,6 +23,8 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kPassThreads = MSW_PASS_THREADS_A;
 constexpr int kPassThreadsB = MSW_PASS_THREADS_B;
 constexpr int kMaxTrace = 4096;
+constexpr int kRedfinParts = 5;    // doubles per workgroup of k_redfin's partial sums (state_kernels.hpp)
+constexpr int kRedfinGroups = 16;  // groups per workgroup of k_redfin
 // column sums of the CSR sweeps as 64-bit fixed point + integer atomics (sweep_kernels.hpp); 0 = fp64
 // atomics, an A/B timing build only
 #ifndef MSW_FX
@@ -119,15 +121,16 @@ struct Scalars {
   double bound, oldbound, bound_const;
   double tol, csum;
   // per-pass shared quantities
-  double M, U, p0, V1c, V2c, kappa;
+  double M, U, p0, kappa;
   double logzi;
   // fixed-point column sums (sweep_kernels.hpp kFx): 2^K and 2^-K; 2^t / 2^-t of the guarded ECs' shares
   // (sell.hpp); xb >= every table value x_i = exp(a T_i) and p0 of the current pass; extreme table values
   double fx_scale, fx_inv, fx_tscale, fx_tinv, xb, tmax, tmin;
   // every exp(a T) of a pass is formed as exp(a (T - tref)), tref = the table value with the largest a T
-  // (incl. log zi): x_i <= 1, p0 <= 1 whatever a does; the ELBO gets a * tref * sum c back (k_fin)
+  // (incl. log zi): x_i <= 1, p0 <= 1 whatever a does; the ELBO gets a * tref * sum c back (k_finstep)
   double tref;
   int32_t didreset, reset_pending, done, iter;
+  int32_t have_eval, eval_pad;  // what the previous slot left for k_finstep's verdict: 0 nothing, 1 an evaluation, 2 the initial one
   int32_t max_iters, fixed_iters, trace_theta, flavor;  // flavor: 0 csr, 1 dense
   // solver options (msw_core_set_option): the stop rule is tested after iterations n, 2n, ... only; EM variants
   int32_t check_every, em_prior, em_stop, opt_pad;

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k_dense_passA(const Scalars *sc, const do
                                                     uint32_t E, const double *u, const double *w,
                                                     double *partA) {
   __shared__ double sh[32];
-  if (sc->done || sc->reset_pending) return;
+  if (sc->done) return;  // (pass A runs before the verdict on the state it sweeps: k_finstep)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
   const double a = sc->a, oma = 1.0 - a;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_dense_big_passA(const Scalars *sc, cons
                                                         uint32_t E, const double *u, const double *w,
                                                         double *partA) {
   __shared__ double sh[32];
-  if (sc->done || sc->reset_pending) return;
+  if (sc->done) return;  // (pass A runs before the verdict on the state it sweeps: k_finstep)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
   const double a = sc->a, oma = 1.0 - a;

@@ -86,6 +86,58 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double *sh) {
     v[i] = r;
   }
 }
+// The same reductions for a workgroup of NW wavefronts known at compile time (the kernels between the sweeps are
+// chains of such reductions): the second stage is straight-line code -- the NW partial results of a sum are read from
+// LDS together and added in wavefront order (the same order, the same bits as block_sum_n) instead of a loop of NW
+// dependent LDS round trips.  sh: >= NW * N doubles.
+template <int N, int NW>
+__device__ __forceinline__ void block_sum_fixed(double (&v)[N], double *sh) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) sh[w * N + i] = v[i];
+  }
+  __syncthreads();
+  constexpr int C = NW < 8 ? NW : 8;  // partial results in flight at a time (bounds the registers)
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double r = 0.0;
+#pragma unroll
+    for (int j0 = 0; j0 < NW; j0 += C) {
+      double t[C];
+#pragma unroll
+      for (int j = 0; j < C; ++j) t[j] = j0 + j < NW ? sh[(j0 + j) * N + i] : 0.0;
+#pragma unroll
+      for (int j = 0; j < C; ++j)
+        if (j0 + j < NW) r += t[j];
+    }
+    v[i] = r;
+  }
+}
+template <int NW>
+__device__ __forceinline__ double block_sum_fixed1(double v, double *sh) {
+  double a[1] = {v};
+  block_sum_fixed<1, NW>(a, sh);
+  return a[0];
+}
+template <int NW>
+__device__ __forceinline__ double block_max_fixed(double v, double *sh) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double t[NW];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) t[k] = sh[k];
+  double r = t[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) r = fmax(r, t[k]);
+  return r;
+}
 __device__ __forceinline__ double block_max(double v, double *sh) {
   v = wave_max(v);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -140,7 +192,26 @@ __device__ __forceinline__ double flush_denormal(double e) { return e < 0x1p-100
 // carries the same function for the RCG gradient).
 __device__ __forceinline__ double digamma_ref(double x) {
   double result = 0.0;
-  for (; x < 7.0; x += 1.0) result -= 1.0 / x;
+  // the shift loop `for (; x < 7; ++x) result -= 1 / x` with its (up to seven) divisions independent of each other:
+  // the same operands, the same order of the subtractions, the same bits -- one division's latency instead of seven
+  // (most groups of a sample sit at N_g = alpha + nearly nothing: the whole loop)
+  if (x >= 0.0 && x < 7.0) {
+    double xs[8], q[7];
+    xs[0] = x;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) xs[k] = xs[k - 1] + 1.0;  // the loop's own additions
+#pragma unroll
+    for (int k = 0; k < 7; ++k) q[k] = 1.0 / xs[k];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      if (xs[k] < 7.0) {  // (a prefix: xs ascends)
+        result -= q[k];
+        x = xs[k + 1];
+      }
+    }
+  } else {
+    for (; x < 7.0; x += 1.0) result -= 1.0 / x;  // (x < 0: never met, N_g >= alpha_g > 0; NaN: no iteration)
+  }
   x -= 0.5;
   const double xx = 1.0 / x, xx2 = xx * xx, xx4 = xx2 * xx2;
   result += log(x) + (1. / 24.) * xx2 - (7.0 / 960.0) * xx4 + (31.0 / 8064.0) * xx4 * xx2 -

@@ -421,7 +421,8 @@ void launch_passA_t(msw_core *h) {
   auto k = ml ? k_passA<ENC, GL, TL, true> : k_passA<ENC, GL, TL, false>;
   prepare_sweep(k, lds, h->lds_attr[0][(ml ? 40 : 0) + ENC * 4 + (GL ? 2 : 0) + (TL ? 1 : 0)]);
   hipLaunchKernelGGL(k, dim3(h->nblk), dim3(pass_threads_A<ENC>()), lds, h->stream, h->sc.p, sell_view(h),
-                     h->ew.p, h->tabA.p, h->partA.p, h->guard_view());
+                     h->ew.p, h->tabA.p, h->partA.p, h->partR.p, (int)((h->G + kRedfinGroups - 1) / kRedfinGroups),
+                     h->guard_view());
 }
 template <int ENC, int GM, bool TL>
 void launch_passB_t(msw_core *h) {
@@ -604,10 +605,17 @@ void launch_tables(msw_core *h) {
                      h->tab_built.p);
 }
 
-void launch_fin(msw_core *h, int mode) {
+// the verdict on the pending evaluation + the next step (state_kernels.hpp k_finstep); mode 1: the verdict alone
+void launch_finstep(msw_core *h, int mode) {
   TraceDev tr{h->tr_bound.p, h->tr_newnorm.p, h->tr_beta.p, h->tr_theta.p, h->tr_reset.p};
-  hipLaunchKernelGGL(k_fin, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G, h->n_tab_inline(),
-                     (int)((h->G + kRedfinGroups - 1) / kRedfinGroups), h->totS.p, h->partR.p, h->Nc.p, h->u.p,
+  const double *pA = h->partA.p;
+  int npA = h->flavor == 0 ? h->nblk : h->nblk_dense;
+  if (h->comm) {  // |g|^2 summed over the EC shards (run_rcg)
+    pA = h->commA.p;
+    npA = 1;
+  }
+  hipLaunchKernelGGL(k_finstep, dim3(1), dim3(1024), 0, h->stream, h->sc.p, mode, (int)h->G, h->n_tab_inline(), npA, pA,
+                     (int)((h->G + kRedfinGroups - 1) / kRedfinGroups), h->totS.p, h->partR.p, h->Nc.p, h->w.p, h->u.p,
                      h->os_u.p, h->step_u.p, h->lut_area.p, h->e.p, h->tabs(), tr);
   launch_tables(h);
 }
@@ -679,45 +687,45 @@ void begin_solve(msw_core *h, double tol, size_t max_iters) {
 void run_rcg(msw_core *h, size_t max_iters, size_t iters_start = 0) {
   const int G = (int)h->G, n_lut = h->n_tab_inline();
   if (iters_start == 0) {
-    // initial update_N_k on gamma = log(1/G)
+    // initial update_N_k on gamma = log(1/G): the first slot's k_finstep finds it as Scalars::have_eval = 2
     hipLaunchKernelGGL(k_prepB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->u.p, h->lut_area.p,
                        h->e.p, h->tabs());
     launch_tables(h);
     launch_passB(h);
     h->timing.passB_launches--;  // the initial evaluation is not an iteration
     if (h->profiling && h->evB_used) h->evB_used--;
-    launch_fin(h, 2);
   }
   const int nbA = h->flavor == 0 ? h->nblk : h->nblk_dense;
-  // Slots (state_kernels.hpp): one per iteration plus one per rejected step.  Enqueue as many as
-  // iterations are still missing, poll, repeat; nothing is launched for branches not taken.
+  // Slots (state_kernels.hpp k_finstep): k_passA -> k_finstep -> k_passB (+ k_redfin); one per iteration plus one per
+  // rejected step.  The verdict on a slot's evaluation is taken by the NEXT slot's k_finstep, so the iteration count
+  // the host polls lags the evaluations by one: enqueue as many slots as iterations are still missing, poll, repeat;
+  // slots enqueued past the end return at once (Scalars::done), and a verdict-only launch closes the run where the
+  // count, not the tolerance, ends it.
   size_t iters_done = iters_start;
   for (;;) {
     // fixed-iteration runs know how many slots are missing; otherwise poll every kIterBatch
-    const size_t batch = h->fixed_iters ? std::min<size_t>(256, max_iters - iters_done)
-                                        : std::min<size_t>(kIterBatch, max_iters - iters_done);
+    const size_t missing = std::max<size_t>(1, max_iters - std::min(max_iters, iters_done));
+    const size_t batch = h->fixed_iters ? std::min<size_t>(256, missing) : std::min<size_t>(kIterBatch, missing);
     for (size_t b = 0; b < batch; ++b) {
       launch_passA(h);
-      const double *pA = h->partA.p;
-      int npA = nbA;
       if (h->comm) {  // |g|^2 summed over the EC shards
         hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(1024), 0, h->stream, h->sc.p, 1, nbA, h->partA.p,
                            h->commA.p);
         h->comm->allreduce(h->commA.p, 1, h->stream);
-        pA = h->commA.p;
-        npA = 1;
       }
-      hipLaunchKernelGGL(k_step, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, npA,
-                         pA, h->w.p, h->u.p, h->os_u.p, h->step_u.p, h->lut_area.p, h->e.p,
-                         h->tabs());
-      launch_tables(h);
+      launch_finstep(h, 0);
       launch_passB(h);
-      launch_fin(h, 0);
     }
     MSW_HIP(hipGetLastError());
     poll(h);
+    if (h->sc_host->done) break;
+    if (h->sc_host->have_eval && (size_t)h->sc_host->iter + 1 >= max_iters) {  // the last evaluation's verdict ends the run
+      launch_finstep(h, 1);
+      MSW_HIP(hipGetLastError());
+      poll(h);
+      if (h->sc_host->done) break;
+    }
     iters_done = (size_t)h->sc_host->iter;
-    if (h->sc_host->done || iters_done >= max_iters) break;
   }
 }
 

@@ -3,10 +3,7 @@
 // 5k groups on ONE CU cost more than a sweep), ELBO + reset / convergence decision, and the
 // gradient preparation for the next pass A.
 //
-// One "slot" = k_passA -> k_step -> k_passB -> k_redfin -> k_fin.  A slot normally is one
-// iteration; after a rejected step (bound < oldbound) k_fin sets reset_pending and the NEXT slot
-// skips pass A / the step and only re-evaluates the reverted state, so a solve needs
-// iterations + resets slots and no launch is spent on a branch that is not taken.
+// One "slot" = k_passA -> k_finstep -> k_passB -> k_redfin (k_finstep below says what a slot does).
 #pragma once
 #include "device_util.hpp"
 
@@ -53,8 +50,8 @@ __device__ inline void prepB_block(Scalars *sc, double a, int G, int n_lut, cons
   }
 }
 
-// The per-slot tables for slot areas too large to be rebuilt by the single workgroup of k_step /
-// k_fin / k_prepB (those are then called with n_lut = 0 and this kernel follows them): any number
+// The per-slot tables for slot areas too large to be rebuilt by the single workgroup of k_finstep /
+// k_prepB (those are then called with n_lut = 0 and this kernel follows them): any number
 // of workgroups, and nothing to do when the tables already belong to the current a (built[0] =
 // version they were built for, built[1] = workgroups that have finished).
 constexpr int kTabInline = 16384;
@@ -114,32 +111,51 @@ __global__ __launch_bounds__(1024) void k_prepB(Scalars *sc, int G, int n_lut, c
   prepB_block(sc, a, G, n_lut, u, lut, e, X, sh);
 }
 
-// Fletcher-Reeves step (rcgpar rcg_optl_mat: beta_FR, oldstep scaling, gamma += step) on
-// the (a, u) state, followed by the pass-B preparation.  This single-workgroup kernel sits between
-// the two sweeps of every iteration, so it is organised around memory round trips, not arithmetic:
-// every load is issued up front, u stays in registers from the step to the exp, and the
-// per-slot tables (which only need the new scalar a) are built while the group loop runs.
-// Groups beyond kStepRegs * 1024 take the (slower) looping path through prepB_block.
-constexpr int kStepRegs = 8;
-__global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, int n_partA,
-                                              const double *partA, const double *w, double *u,
-                                              double *os_u, double *step_u, const double *lut,
-                                              double *e, TabDev X) {
-  __shared__ double sh[32];
+// ONE kernel between pass A and pass B (round 4; k_fin + k_step until then -- two kernels, two launch boundaries
+// and two chains of memory round trips per iteration, tools/chain_timeline.py): the VERDICT on the evaluation the
+// previous slot left behind (rcgpar ELBO_rcg_mat + bound_const, the `bound < oldbound` steepest-descent retry --
+// revert_step --, the convergence test), then the Fletcher-Reeves STEP (rcgpar rcg_optl_mat: beta_FR, oldstep scaling,
+// gamma += step) on the (a, u) state and the pass-B preparation.  Pass A therefore runs BEFORE the verdict on the
+// state it sweeps: its |g|^2 is wasted only after a rejected step, and it takes the two background moments it needs
+// (S1 = sum e s0, S2 = sum e s0^2) from k_redfin's partial sums itself (sweep_kernels.hpp).
+//
+// One "slot" = k_passA -> k_finstep -> k_passB -> k_redfin.  Scalars::have_eval says what the previous slot left:
+//   2 the initial evaluation (update_N_k on gamma = log(1/G)): bookkeeping only, then the first step;
+//   1 an evaluation: accepted -> iteration count, trace, stop rule, then the next step (none when done);
+//                    rejected (bound < oldbound) -> revert to steepest descent, NO step: the pass B of this slot
+//                    re-evaluates, and the next slot's verdict accepts it unconditionally (reset_pending);
+//   0 nothing pending (a closing verdict has been taken: mode 1 below): the step alone.
+// mode 1 = verdict only: closes a run of slots (fixed-iteration runs, max_iters) -- the last evaluation's verdict
+// without a further step.  A solve needs iterations + rejected steps slots, as before.
+// This single-workgroup kernel sits between the two sweeps of every iteration, so it is organised around memory
+// round trips, not arithmetic: every load is issued up front, BEFORE the state decides what runs; u stays in
+// registers from the step to the exp; one pair of barriers serves the six sums.  Groups beyond kStepRegs * 1024 take
+// the (slower) looping paths.
+constexpr int kStepRegs = 6;  // groups per thread the register paths hold (6144 groups; more: the looping paths)
+__global__ __launch_bounds__(1024) void k_finstep(Scalars *sc, int mode, int G, int n_lut, int n_partA,
+                                                 const double *partA, int npartR, const double *totS,
+                                                 const double *partR, const double *Nc, const double *w, double *u,
+                                                 double *os_u, double *step_u, const double *lut, double *e, TabDev X,
+                                                 TraceDev tr) {
+  __shared__ double sh[16 * (kRedfinParts + 1)];
   const int tid = threadIdx.x, nt = blockDim.x;
   const bool inreg = G <= kStepRegs * nt;
-  // every load of the kernel is issued here, BEFORE the state decides whether the step runs at
-  // all: one memory round trip instead of two on the critical path between the sweeps
-  double pn = 0.0;
-  for (int i = tid; i < n_partA; i += nt) pn += partA[i];
-  double wv[kStepRegs], ov[kStepRegs], uv[kStepRegs];
+  // ---- every load of the kernel: one memory round trip on the critical path between the sweeps
+  double q[kRedfinParts + 1] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // k_redfin's five sums, |g|^2
+  for (int b = tid; b < npartR; b += nt)
+    for (int i = 0; i < kRedfinParts; ++i) q[i] += partR[kRedfinParts * b + i];
+  for (int i = tid; i < n_partA; i += nt) q[kRedfinParts] += partA[i];
+  const double s_clogZ = totS[0], s_rH = totS[1];
+  // (w, u and the last step -- the oldstep of the common case, an accepted evaluation; the scaled oldstep os_u is
+  // read where it is needed: after a rejected step and for the first step of a run)
+  double wv[kStepRegs], sv[kStepRegs], uv[kStepRegs];
   if (inreg) {
 #pragma unroll
     for (int k = 0; k < kStepRegs; ++k) {
       const int g = tid + k * nt;
       if (g < G) {
         wv[k] = w[g];
-        ov[k] = os_u[g];
+        sv[k] = step_u[g];
         uv[k] = u[g];
       }
     }
@@ -147,19 +163,102 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
   const double lt = tid < n_lut ? lut[tid] : 0.0;  // first table entry of this thread
   if (tid == 0) MSW_STAMP(sc->iter, 1, 0);
   const Scalars s0 = *sc;  // one read of the whole state: no dependent scalar round trips later
-  if (s0.done || s0.reset_pending) return;  // a pending re-evaluation skips pass A and the step
+  if (s0.done) return;
   if (tid == 0) MSW_STAMP(s0.iter, 1, 1);
-  const double a = s0.a, oldnorm = s0.oldnorm, bound = s0.bound, logzi = s0.logzi;
-  double os_a = s0.os_a;
-  const int didreset = s0.didreset;
+  block_sum_fixed<kRedfinParts + 1, 16>(q, sh);  // one pair of barriers for the six sums
+  if (tid == 0) MSW_STAMP(s0.iter, 1, 2);
+  const double lg = q[0], mu = q[1], S0 = q[2], S1 = q[3], pnsum = q[5];
+  const int flavor = s0.flavor;
+  const double logzi = s0.logzi;
+  double a = s0.a, os_a = s0.os_a, kappa = s0.kappa, bound = s0.bound;
+  int didreset = s0.didreset, it = s0.iter, done = 0;
+  bool old_is_step = false;  // the accepted step becomes oldstep (rcgpar: oldstep = step) -- folded into the step below
+
+  // ---- the verdict on the pending evaluation ------------------------------------------------------------
+  if (s0.have_eval == 2) {
+    if (flavor == 0) kappa += S1 / S0;  // the initial update_N_k: no bound, no iteration
+  } else if (s0.have_eval == 1) {
+    const int reeval = s0.reset_pending;
+    const double coef = (flavor == 0) ? (1.0 - a) : 1.0;
+    // (the sweeps' Z carries exp(-a tref): sum c log Z gets a * tref * sum c back; 0 for the dense flavour)
+    const double nb = s0.bound_const + s_clogZ + coef * s_rH + mu + lg + (flavor == 0 ? a * s0.tref * s0.csum : 0.0);
+    if (!reeval && nb < s0.oldbound) {
+      // bad step: revert to steepest descent (gamma += oldm; gamma -= oldstep); this slot's pass B re-evaluates
+      double a2 = a;
+      if (s0.beta > 0) {
+        a2 = a - os_a;
+        if (inreg) {
+#pragma unroll
+          for (int k = 0; k < kStepRegs; ++k)
+            if (tid + k * nt < G) u[tid + k * nt] = uv[k] - os_u[tid + k * nt];
+        } else {
+          for (int g = tid; g < G; g += nt) u[g] -= os_u[g];
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        sc->a = a2;
+        sc->didreset = 1;
+        sc->reset_pending = 1;
+        sc->bound = nb;
+        sc->have_eval = 1;
+      }
+      if (flavor == 0) prepB_block(sc, a2, G, n_lut, u, lut, e, X, sh);
+      return;
+    }
+    // accepted (or the re-evaluation after a rejected step, which is taken as it is)
+    if (it < s0.trace_theta && tr.theta)
+      for (int g = tid; g < G; g += nt) tr.theta[(size_t)it * G + g] = Nc[g] / s0.csum;
+    // (check_every > 1: the rule is tested after iterations n, 2n, ... only -- msw_core_set_option)
+    if (!s0.fixed_iters && (nb - s0.oldbound < s0.tol) && !didreset && (s0.check_every <= 1 || (it + 1) % s0.check_every == 0))
+      done = 1;
+    if (it + 1 >= s0.max_iters) done = 1;
+    if (tid == 0 && it < kMaxTrace) {
+      tr.bound[it] = nb;
+      tr.newnorm[it] = s0.newnorm;
+      tr.beta[it] = s0.beta;
+      tr.didreset[it] = didreset;
+    }
+    old_is_step = !reeval;
+    if (old_is_step) os_a = s0.step_a;
+    if (flavor == 0) kappa += S1 / S0;
+    bound = nb;
+    it += 1;
+  } else if (s0.reset_pending) {
+    // a closing verdict (mode 1) rejected the last evaluation: this slot's pass B re-evaluates first
+    if (tid == 0) sc->have_eval = 1;
+    return;
+  }
+  if (done || mode == 1) {  // the verdict alone: the state stays the evaluated one
+    if (old_is_step) {      // ... with its step as oldstep, should the solve be continued (msw_core_continue)
+      if (inreg) {
+#pragma unroll
+        for (int k = 0; k < kStepRegs; ++k)
+          if (tid + k * nt < G) os_u[tid + k * nt] = sv[k];
+      } else {
+        for (int g = tid; g < G; g += nt) os_u[g] = step_u[g];
+      }
+    }
+    if (tid == 0) {
+      sc->os_a = os_a;
+      sc->bound = bound;
+      sc->kappa = kappa;
+      sc->reset_pending = 0;
+      sc->iter = it;
+      sc->done = done;
+      sc->have_eval = 0;
+      MSW_STAMP(it, 4, 7);
+    }
+    return;
+  }
+
+  // ---- the step ---------------------------------------------------------------------------------------------
   // (one group: q_j is the constant 1 and the variance exactly 0 -- the sweep's background form would
   // leave rounding noise, and a ratio of two noises as beta)
-  const double pnsum = block_sum(pn, sh);
-  if (tid == 0) MSW_STAMP(s0.iter, 1, 2);
   const double newnorm = G == 1 ? 0.0 : pnsum;
   // (an exactly stationary start -- identical groups under a symmetric prior -- makes the ratio x/0: the
   // reference carries the inf / NaN into its state and returns NaN weights; here such a step has no momentum)
-  const double ratio = newnorm / oldnorm;
+  const double ratio = newnorm / s0.oldnorm;
   const double beta = ratio < INFINITY ? ratio : 0.0;
   double step_a = 1.0 - a;
   if (didreset) {
@@ -170,8 +269,9 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
   }
   const double a_new = a + step_a;
   if (!inreg) {
+    const double *osrc = old_is_step ? step_u : os_u;
     for (int g = tid; g < G; g += nt) {
-      double osu = os_u[g], su = w[g];
+      double osu = osrc[g], su = w[g];
       if (didreset) {
         osu *= 0.0;
       } else if (beta > 0) {
@@ -191,9 +291,14 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
       sc->newnorm = newnorm;
       sc->beta = beta;
       sc->didreset = 0;
+      sc->reset_pending = 0;
+      sc->bound = bound;
       sc->oldbound = bound;
+      sc->kappa = kappa;
+      sc->iter = it;
+      sc->have_eval = 1;
     }
-    if (s0.flavor == 0) prepB_block(sc, a_new, G, n_lut, u, lut, e, X, sh);
+    if (flavor == 0) prepB_block(sc, a_new, G, n_lut, u, lut, e, X, sh);
     return;
   }
   double m = -INFINITY;
@@ -201,7 +306,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
   for (int k = 0; k < kStepRegs; ++k) {
     const int g = tid + k * nt;
     if (g < G) {
-      double osu = ov[k], su = wv[k];
+      double osu = old_is_step ? sv[k] : os_u[g], su = wv[k];
       if (didreset) {
         osu *= 0.0;
       } else if (beta > 0) {
@@ -215,7 +320,6 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
       m = fmax(m, uv[k]);
     }
   }
-  const int flavor = s0.flavor;
   double p0 = 0.0, tref = 0.0;
   if (tid == 0) MSW_STAMP(s0.iter, 1, 3);
   if (flavor == 0) {  // per-slot tables of both sweeps (prepB_block's arithmetic)
@@ -231,7 +335,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
   double M = 0.0, U = 0.0;
   if (tid == 0) MSW_STAMP(s0.iter, 1, 4);
   if (flavor == 0) {
-    M = block_max(m, sh);
+    M = block_max_fixed<16>(m, sh);
     if (tid == 0) MSW_STAMP(s0.iter, 1, 5);
     double su = 0.0;
 #pragma unroll
@@ -243,7 +347,7 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
         su += eg;
       }
     }
-    U = block_sum(su, sh);
+    U = block_sum_fixed1<16>(su, sh);
   }
   if (tid == 0) MSW_STAMP(s0.iter, 1, 6);
   if (tid == 0) {
@@ -255,7 +359,12 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
     sc->newnorm = newnorm;
     sc->beta = beta;
     sc->didreset = 0;
+    sc->reset_pending = 0;
+    sc->bound = bound;
     sc->oldbound = bound;
+    sc->kappa = kappa;
+    sc->iter = it;
+    sc->have_eval = 1;
     if (flavor == 0) {
       sc->M = M;
       sc->U = U;
@@ -271,14 +380,13 @@ __global__ __launch_bounds__(1024) void k_step(Scalars *sc, int G, int n_lut, in
 // Nc_g, N_g, lgamma(N_g), (M - u_g) * Nc_g, w_g = digamma(N_g) - 1 - u_g and the pass-A gradient
 // preparation {e_g, w_g - kappa} with its sums S0 = sum e, S1 = sum e*s0, S2 = sum e*s0^2
 // (s0_g = w_g - kappa: the step value of a background cell relative to which pass A measures the
-// listed cells; kappa = lagged centring constant, see k_fin).  One 1024-thread workgroup per
+// listed cells; kappa = lagged centring constant, advanced by k_finstep to the e-weighted mean just measured:
+// kappa += S1 / S0).  One 1024-thread workgroup per
 // kRedfinGroups = 16 groups (313 workgroups at 5k groups: the 10 MB of partial rows pass B left
 // behind are read by the whole chip, not by 79 CUs): thread t sums rows t/16, t/16 + 64, ... of
 // group t%16 (a row's 16 groups are one 128-byte line), 64 row slots meet in LDS in fixed order.
 //   nblk > 0: sum partAcc[b*G + g] over b;  nblk == 0: Acc already holds the totals.
-// Block 0 also leaves the totals of the per-workgroup ELBO terms for k_fin in totS[0..2].
-constexpr int kRedfinParts = 5;
-constexpr int kRedfinGroups = 16;
+// Block 0 also leaves the totals of the per-workgroup ELBO terms for k_finstep in totS[0..2].
 __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int nblk, int fxrows,
                                                 unsigned long long *tail, int zero_tail,
                                                 int npartS, const double *partAcc, const double *Acc,
@@ -311,9 +419,13 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
   }
   if (fx) s = __longlong_as_double(si);  // carried through the LDS exchange as bits
   // per-group operands of the math below: loaded now, needed after the reductions
+  // (the math is shared by the first two wavefronts, 16 lanes each: wavefront 0 takes lgamma and the bound's terms,
+  // wavefront 1 digamma and the gradient's -- two latency chains side by side instead of one after the other)
+  const bool mathlane = (tid & 63) < kRedfinGroups && tid < 128 && g < G;
+  const int role = tid >> 6;
   double ug0 = 0.0, eg0 = 0.0, al0 = 0.0;
   long long th = 0, tl = 0;  // the guarded ECs' shares of the group (sell.hpp), two fixed-point limbs
-  if (tid < kRedfinGroups && g < G) {
+  if (mathlane) {
     ug0 = u[g];
     eg0 = e[g];
     al0 = alpha0[g];
@@ -322,7 +434,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
       tl = (long long)tail[2 * (size_t)g + 1];
     }
   }
-  // W = sum_j r_j (and, for k_fin, the other two ELBO sums): every workgroup forms them in the
+  // W = sum_j r_j (and, for k_finstep, the other two ELBO sums): every workgroup forms them in the
   // same fixed order
   double t[3] = {0.0, 0.0, 0.0};
   for (int b = tid; b < npartS; b += 1024) {
@@ -331,13 +443,13 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
     t[2] += partS[4 * b + 2];
   }
   if (s0.done) return;
-  if (tail && zero_tail && tid < kRedfinGroups && g < G && (th | tl)) {  // consumed: ready for the next pass B
+  if (tail && zero_tail && mathlane && role == 0 && (th | tl)) {  // consumed: ready for the next pass B
     tail[2 * (size_t)g] = 0;
     tail[2 * (size_t)g + 1] = 0;
   }
   accs[rs][gl] = s;
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(s0.iter, 3, 1);
-  block_sum_n<3>(t, sh);  // its barriers also publish accs
+  block_sum_fixed<3, 16>(t, sh);  // its barriers also publish accs
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(s0.iter, 3, 2);
   const double W = t[2];
   if (blockIdx.x == 0 && tid == 0) {
@@ -345,9 +457,9 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
     totS[1] = t[1];
     totS[2] = t[2];
   }
-  if (tid >= 64) return;
+  if (tid >= 128) return;
   double lgv = 0.0, muv = 0.0, s0v = 0.0, s1v = 0.0, s2v = 0.0;
-  if (tid < kRedfinGroups && g < G) {
+  if (mathlane) {
     double A = 0.0;
     long long ai = 0;
     if (fx) {
@@ -384,152 +496,53 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
       nc = A;
     }
     const double n = al0 + nc;
-    Nc[g] = nc;
-    N[g] = n;
-    lgv = lgamma(n);
-    const double wg = digamma_ref(n) - 1.0 - ug;
-    w[g] = wg;
-    if (flavor == 0) {
-      const double eg = eg0, wc = wg - s0.kappa;
-      const double sb = wc;
-      ew[g] = make_double2(eg, wc);
-      s0v = eg;
-      s1v = eg * sb;
-      s2v = eg * sb * sb;
-    }
-  }
-  lgv = wave_sum(lgv);
-  muv = wave_sum(muv);
-  s0v = wave_sum(s0v);
-  s1v = wave_sum(s1v);
-  s2v = wave_sum(s2v);
-  if (tid == 0) MSW_STAMP_MAX(s0.iter, 3, 7);
-  if (tid == 0) {
-    double *o = partR + kRedfinParts * blockIdx.x;
-    o[0] = lgv;
-    o[1] = muv;
-    o[2] = s0v;
-    o[3] = s1v;
-    o[4] = s2v;
-  }
-}
-
-// ELBO (rcgpar ELBO_rcg_mat + bound_const), the bound < oldbound steepest-descent retry
-// (revert_step) and the convergence test.
-//   mode 2: initial update_N_k only;  otherwise a first evaluation of an iteration, or -- when
-//   reset_pending is set -- the re-evaluation after a rejected step.
-// kappa (centring constant of the pass-A step values) advances to the e-weighted mean just
-// measured: kappa += S1 / S0.
-// totS = {sum c log Z, sum r H, sum r} as left by k_redfin's block 0.
-__global__ __launch_bounds__(1024) void k_fin(Scalars *sc, int mode, int G, int n_lut, int npartR,
-                                             const double *totS, const double *partR,
-                                             const double *Nc, double *u, double *os_u,
-                                             const double *step_u, const double *lut, double *e,
-                                             TabDev X, TraceDev tr) {
-  __shared__ double sh[16 * kRedfinParts];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  // all loads first, then the state decides (one round trip on the critical path, not two)
-  double q[kRedfinParts] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int b = tid; b < npartR; b += nt)
-    for (int i = 0; i < kRedfinParts; ++i) q[i] += partR[kRedfinParts * b + i];
-  const double s_clogZ = totS[0], s_rH = totS[1];
-  const bool inreg = G <= kStepRegs * nt;
-  double sv[kStepRegs];
-  if (inreg) {  // the accepted step becomes oldstep below
-#pragma unroll
-    for (int k = 0; k < kStepRegs; ++k)
-      if (tid + k * nt < G) sv[k] = step_u[tid + k * nt];
-  }
-  if (tid == 0) MSW_STAMP(sc->iter, 4, 0);
-  const Scalars s0 = *sc;  // one read of the whole state
-  if (s0.done) return;
-  if (tid == 0) MSW_STAMP(s0.iter, 4, 1);
-  const int flavor = s0.flavor;
-  const int reeval = s0.reset_pending;
-  const double a = s0.a, oldbound = s0.oldbound;
-  const double beta = s0.beta, tol = s0.tol, csum = s0.csum, kappa = s0.kappa;
-  block_sum_n<kRedfinParts>(q, sh);  // one pair of barriers for the five sums
-  const double lg = q[0], mu = q[1], S0 = q[2], S1 = q[3], S2 = q[4];
-  if (tid == 0) MSW_STAMP(s0.iter, 4, 2);
-  if (mode == 2) {
-    if (tid == 0 && flavor == 0) {
-      sc->V1c = S1;
-      sc->V2c = S2;
-      sc->kappa = kappa + S1 / S0;
-    }
-    return;
-  }
-  const double coef = (flavor == 0) ? (1.0 - a) : 1.0;
-  // (the sweeps' Z carries exp(-a tref): sum c log Z gets a * tref * sum c back; 0 for the dense flavour)
-  const double bound = s0.bound_const + s_clogZ + coef * s_rH + mu + lg + (flavor == 0 ? a * s0.tref * csum : 0.0);
-  const int didreset = s0.didreset;
-  __syncthreads();
-  if (!reeval && bound < oldbound) {
-    // bad step: revert to steepest descent (gamma += oldm; gamma -= oldstep) and re-evaluate
-    double a2 = a;
-    if (beta > 0) {
-      a2 = a - s0.os_a;
-      for (int g = tid; g < G; g += nt) u[g] -= os_u[g];
-    }
-    __syncthreads();
-    if (tid == 0) {
-      sc->a = a2;
-      sc->didreset = 1;
-      sc->reset_pending = 1;
-      sc->bound = bound;
-    }
-    if (flavor == 0) prepB_block(sc, a2, G, n_lut, u, lut, e, X, sh);
-    return;
-  }
-  if (!reeval) {
-    // oldstep = step
-    if (inreg) {
-#pragma unroll
-      for (int k = 0; k < kStepRegs; ++k)
-        if (tid + k * nt < G) os_u[tid + k * nt] = sv[k];
+    if (role == 0) {
+      Nc[g] = nc;
+      N[g] = n;
+      lgv = lgamma(n);
     } else {
-      for (int g = tid; g < G; g += nt) os_u[g] = step_u[g];
+      muv = 0.0;  // (the bound's terms belong to wavefront 0)
+      const double wg = digamma_ref(n) - 1.0 - ug;
+      w[g] = wg;
+      if (flavor == 0) {
+        const double eg = eg0, wc = wg - s0.kappa;
+        const double sb = wc;
+        ew[g] = make_double2(eg, wc);
+        s0v = eg;
+        s1v = eg * sb;
+        s2v = eg * sb * sb;
+      }
     }
   }
-  const int it = s0.iter;
-  if (it < s0.trace_theta && tr.theta) {
-    for (int g = tid; g < G; g += nt) tr.theta[(size_t)it * G + g] = Nc[g] / csum;
-  }
-  int done = 0;
-  // (check_every > 1: the rule is tested after iterations n, 2n, ... only -- msw_core_set_option)
-  if (!s0.fixed_iters && (bound - oldbound < tol) && !didreset && (s0.check_every <= 1 || (it + 1) % s0.check_every == 0))
-    done = 1;
-  if (it + 1 >= s0.max_iters) done = 1;
-  __syncthreads();
-  if (tid == 0) {
-    if (!reeval) sc->os_a = s0.step_a;
-    sc->bound = bound;
-    sc->reset_pending = 0;
-    if (flavor == 0) {
-      sc->V1c = S1;
-      sc->V2c = S2;
-      sc->kappa = kappa + S1 / S0;
+  double *o = partR + kRedfinParts * blockIdx.x;
+  if (role == 0) {  // wave-uniform
+    lgv = wave_sum(lgv);
+    muv = wave_sum(muv);
+    if (tid == 0) {
+      o[0] = lgv;
+      o[1] = muv;
     }
-    if (it < kMaxTrace) {
-      tr.bound[it] = bound;
-      tr.newnorm[it] = s0.newnorm;
-      tr.beta[it] = beta;
-      tr.didreset[it] = didreset;
+  } else {
+    s0v = wave_sum(s0v);
+    s1v = wave_sum(s1v);
+    s2v = wave_sum(s2v);
+    if (tid == 64) {
+      MSW_STAMP_MAX(s0.iter, 3, 7);
+      o[2] = s0v;
+      o[3] = s1v;
+      o[4] = s2v;
     }
-    sc->iter = it + 1;
-    sc->done = done;
-    MSW_STAMP(it, 4, 7);
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // EC-sharded solve (comm.hpp): local sums packed for the two all-reduces of an iteration.
 // ---------------------------------------------------------------------------------------
-// out[0] = sum of part[0..n) (fixed order).  `gate` = 1: skipped like pass A / k_step.
+// out[0] = sum of part[0..n) (fixed order).  `gate` = 1: skipped like pass A.
 __global__ __launch_bounds__(1024) void k_sum_scalar(const Scalars *sc, int gate, int n, const double *part,
                                                     double *out) {
   __shared__ double sh[32];
-  if (gate && (sc->done || sc->reset_pending)) return;
+  if (gate && sc->done) return;
   double p = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) p += part[i];
   p = block_sum(p, sh);
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(1024) void k_sum_scalar(const Scalars *sc, int gate
 }
 
 // out[g] = column sum of this rank's ECs (g < G); out[G .. G+3] = {sum c log Z, sum r H, sum r, 0}
-// in the layout of one partS entry, so that k_redfin / k_fin consume `out` as totals.
+// in the layout of one partS entry, so that k_redfin / k_finstep consume `out` as totals.
 // out = [G column sums][2 G limbs of the guarded ECs' shares (tail; zeroed once read)][4 ELBO terms]
 __global__ __launch_bounds__(1024) void k_colsum(const Scalars *sc, int G, int nrows, int fxrows, int npartS,
                                                 const double *partAcc, const double *Acc,
@@ -725,6 +738,7 @@ __global__ __launch_bounds__(1024) void k_init_state(Scalars *sc, int G, int npa
     z.xb = 1.0;
     z.tref = 0.0;
     z.fx_shift = 9;
+    z.have_eval = 2;  // the initial evaluation follows (k_finstep)
     z.check_every = so.check_every < 1 ? 1 : so.check_every;
     z.em_prior = so.em_prior;
     z.em_stop = so.em_stop;

@@ -322,7 +322,7 @@ __device__ __forceinline__ void cellA(AccA &c, const double p0, const double e, 
 template <int ENC, bool GLDS, bool TLDS, bool ML>
 __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *sc, SellDev S,
                                                        const double2 *ew_g, const double2 *tabA_g,
-                                                       double *partA, GuardDev GD) {
+                                                       double *partA, const double *partR, int npartR, GuardDev GD) {
   extern __shared__ __align__(16) unsigned char smem[];
   using R = Rec<ENC>;
   using RT = typename R::T;
@@ -333,9 +333,9 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   constexpr bool TL = TLDS || HYB;  // the LDS image starts with (a part of) the slot table
   const RecDec D = rec_dec(S);
   const uint32_t n_tab = S.n_tab_lds;
-  // a pending re-evaluation skips pass A; the test sits behind the LDS fill so that the fill's loads
-  // do not wait for this one (one memory round trip less at the head of every sweep)
-  const int skip = sc->done | sc->reset_pending;
+  // (the test sits behind the LDS fill so that the fill's loads do not wait for this one: one memory round trip
+  // less at the head of every sweep)
+  const int skip = sc->done;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t G = S.n_groups, Gp = G + kSentinels;
   const uint32_t bhiA = S.bhiA;
@@ -345,6 +345,23 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   SliceStream<ENC, false> stream(S, uniform(blockIdx.x * (NT / 64) + (tid >> 6)),
                               gridDim.x * (NT / 64), (uint32_t)lane,
                               scratch_off + 256u + uniform(tid >> 6) * kGeoStride);
+  // The two background moments S1 = sum_g e_g s0_g, S2 = sum_g e_g s0_g^2 of the step values (s0_g = w_g - kappa):
+  // k_redfin left one partial pair per workgroup (partR[5 b + 3], [5 b + 4]); every wavefront adds them up for itself,
+  // in the same fixed order -- loads issued here, under the LDS fill, the DPP sums behind the barrier that follows it.
+  // (Until round 4 k_fin summed them into the scalar state and pass A had to wait for its verdict: k_finstep.)
+  // (eight pairs per lane in flight at a time -- 512 workgroups of k_redfin, 8192 groups -- not one round trip each)
+  double m1 = 0.0, m2 = 0.0;
+  for (int b0 = 0; b0 < npartR; b0 += 512) {
+    double t1[8], t2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int b = b0 + 64 * k + lane;
+      t1[k] = b < npartR ? partR[kRedfinParts * b + 3] : 0.0;
+      t2[k] = b < npartR ? partR[kRedfinParts * b + 4] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m1 += t1[k], m2 += t2[k];
+  }
   if (TL) {
     double2 *t = reinterpret_cast<double2 *>(smem);
     for (uint32_t i = tid; i < n_tab; i += NT) t[i] = tabA_g[i];
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
     else return tab16<TL>(xt_b, R::t_off(r, D));
   };
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
-  const double zbase = p0 * U, b1 = p0 * uniform_d(sc->V1c), b2 = p0 * uniform_d(sc->V2c);
+  const double zbase = p0 * U;
   const double gthr = fmax(zbase * kGuardRatio, 2.2250738585072014e-308);  // (Z = 0 is set aside too: reported, not divided by)  // ECs whose Z falls below it are set aside (sell.hpp, guarded ECs)
   const uint32_t gcnt_off = scratch_off + 128u;
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
@@ -384,6 +401,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 0, 0);
   __syncthreads();
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 0, 1);
+  const double b1 = p0 * uniform_d(wave_sum(m1)), b2 = p0 * uniform_d(wave_sum(m2));
 
   // (lanes past the end of a long EC, and the missing last row of an odd slice, take a record of the lane's own
   // sentinel group)
@@ -613,7 +631,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
       __builtin_amdgcn_s_waitcnt(0);
     }
   }
-  nn = block_sum(nn, sh);
+  nn = block_sum_fixed1<NT / 64>(nn, sh);
   if (tid == 0) MSW_STAMP_MAX(sc->iter, 0, 7);
   if (tid == 0) partA[blockIdx.x] = nn;
 }
@@ -1215,14 +1233,16 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       __builtin_amdgcn_s_waitcnt(0);
     }
   }
-  s_clogZ = block_sum(s_clogZ, sh);
-  s_rH = block_sum(s_rH, sh);
-  s_W = block_sum(s_W, sh);
-  if (tid == 0 && (GMODE != 4 || rg.first)) {
-    partS[4 * blockIdx.x + 0] = s_clogZ;
-    partS[4 * blockIdx.x + 1] = s_rH;
-    partS[4 * blockIdx.x + 2] = s_W;
-    partS[4 * blockIdx.x + 3] = 0.0;
+  {  // the three ELBO sums of the workgroup with one pair of barriers (the slice geometry behind the 32 doubles of
+     // reduction scratch is free by now: 48 doubles needed)
+    double t3[3] = {s_clogZ, s_rH, s_W};
+    block_sum_n<3>(t3, sh + 32);
+    if (tid == 0 && (GMODE != 4 || rg.first)) {
+      partS[4 * blockIdx.x + 0] = t3[0];
+      partS[4 * blockIdx.x + 1] = t3[1];
+      partS[4 * blockIdx.x + 2] = t3[2];
+      partS[4 * blockIdx.x + 3] = 0.0;
+    }
   }
   if (tid == 0) MSW_STAMP_MAX(sc->iter, 2, 6);
   if (ALDS) {

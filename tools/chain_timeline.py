@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool: where the time of one RCG iteration goes BETWEEN and INSIDE the five kernels of its chain
-(k_passA -> k_step -> k_passB -> k_redfin -> k_fin), from s_memrealtime stamps (100 MHz) of a diagnostic build:
+"""Developer tool: where the time of one RCG iteration goes BETWEEN and INSIDE the four kernels of its chain
+(k_passA -> k_finstep -> k_passB -> k_redfin), from s_memrealtime stamps (100 MHz) of a diagnostic build:
 
     python tools/ab_build.py stamps "-DMSW_STAMPS=1"
     MSWEEP_CORE_LIB=build_ab/lib_stamps.so python tools/chain_timeline.py [reads groups]
@@ -37,27 +37,28 @@ with Core(0) as core:
     L.msw_debug_stamps(core._h, st.ctypes.data_as(C.c_void_p), 0)
     t = core.last_timing()
 st = st.reshape(64, 5, 8).astype(np.int64)
-names = {(0, 0): "passA entry (wg 0)", (0, 1): "passA LDS filled (wg 0)", (0, 7): "passA last wg done",
-         (1, 0): "k_step entry", (1, 1): "k_step state + loads in", (1, 2): "k_step |g|^2 summed", (1, 3): "k_step u updated",
-         (1, 4): "k_step tables built", (1, 5): "k_step max u", (1, 6): "k_step e_g, U",
-         (2, 0): "passB entry (wg 0)", (2, 1): "passB LDS filled (wg 0)", (2, 6): "passB last wg swept", (2, 7): "passB last wg rows out",
+# One row of stamps = one EVALUATION r (Scalars::iter as the kernels read it): pass B and k_redfin of slot r, then pass A
+# and k_finstep of slot r + 1 (the verdict on evaluation r is taken there and advances the count).
+names = {(2, 0): "passB entry (wg 0)", (2, 1): "passB LDS filled (wg 0)", (2, 6): "passB last wg swept", (2, 7): "passB last wg rows out",
          (3, 0): "k_redfin entry (wg 0)", (3, 1): "k_redfin rows loaded (wg 0)", (3, 2): "k_redfin sums (wg 0)", (3, 7): "k_redfin last wg done",
-         (4, 0): "k_fin entry", (4, 1): "k_fin state + loads in", (4, 2): "k_fin sums", (4, 7): "k_fin done"}
-rows = [i for i in range(64) if st[i, 0, 0] and st[i, 4, 7] and st[(i + 1) % 64, 0, 0] > st[i, 0, 0]]
+         (0, 0): "passA entry (wg 0)", (0, 1): "passA LDS filled (wg 0)", (0, 7): "passA last wg done",
+         (1, 0): "k_finstep entry", (1, 1): "k_finstep state + loads in", (1, 2): "k_finstep six sums (verdict follows)",
+         (1, 3): "k_finstep u updated", (1, 4): "k_finstep tables built", (1, 5): "k_finstep max u", (1, 6): "k_finstep e_g, U"}
+order = [k for kk in (2, 3, 0, 1) for k in sorted(names) if k[0] == kk]
+rows = [i for i in range(64) if st[i, 2, 0] and st[i, 1, 6] and st[(i + 1) % 64, 2, 0] > st[i, 2, 0]]
 print(f"{R} reads x {G} groups: {len(rows)} complete iterations; device time per iteration {t['solve_ms'] / max(t['iters'], 1) * 1e3:.1f} us")
-keys = sorted(names)
-acc = {k: [] for k in keys}
+acc = {k: [] for k in order}
 nxt = []
 for i in rows:
-    t0 = st[i, 0, 0]
-    for k in keys:
+    t0 = st[i, 2, 0]
+    for k in order:
         if st[i][k]:
             acc[k].append((st[i][k] - t0) / 100.0)
-    nxt.append((st[(i + 1) % 64, 0, 0] - t0) / 100.0)
+    nxt.append((st[(i + 1) % 64, 2, 0] - t0) / 100.0)
 prev = 0.0
-for k in keys:
+for k in order:
     if acc[k]:
         m = float(np.mean(acc[k]))
         print(f"  {m:8.2f} us  (+{m - prev:6.2f})  {names[k]}")
         prev = m
-print(f"  {np.mean(nxt):8.2f} us  (+{np.mean(nxt) - prev:6.2f})  next iteration's passA entry")
+print(f"  {np.mean(nxt):8.2f} us  (+{np.mean(nxt) - prev:6.2f})  next iteration's passB entry")
