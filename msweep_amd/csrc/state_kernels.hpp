@@ -164,7 +164,6 @@ __global__ __launch_bounds__(1024) void k_finstep(Scalars *sc, int mode, int G, 
   if (tid == 0) MSW_STAMP(sc->iter, 1, 0);
   const Scalars s0 = *sc;  // one read of the whole state: no dependent scalar round trips later
   if (s0.done) return;
-  if (tid == 0) MSW_STAMP(s0.iter, 1, 1);
   block_sum_fixed<kRedfinParts + 1, 16>(q, sh);  // one pair of barriers for the six sums
   if (tid == 0) MSW_STAMP(s0.iter, 1, 2);
   const double lg = q[0], mu = q[1], S0 = q[2], S1 = q[3], pnsum = q[5];
@@ -321,7 +320,6 @@ __global__ __launch_bounds__(1024) void k_finstep(Scalars *sc, int mode, int G, 
     }
   }
   double p0 = 0.0, tref = 0.0;
-  if (tid == 0) MSW_STAMP(s0.iter, 1, 3);
   if (flavor == 0) {  // per-slot tables of both sweeps (prepB_block's arithmetic)
     const double oma = 1.0 - a_new;
     tref = tref_of(a_new, s0.tmax, s0.tmin);
@@ -333,10 +331,8 @@ __global__ __launch_bounds__(1024) void k_finstep(Scalars *sc, int mode, int G, 
     }
   }
   double M = 0.0, U = 0.0;
-  if (tid == 0) MSW_STAMP(s0.iter, 1, 4);
   if (flavor == 0) {
     M = block_max_fixed<16>(m, sh);
-    if (tid == 0) MSW_STAMP(s0.iter, 1, 5);
     double su = 0.0;
 #pragma unroll
     for (int k = 0; k < kStepRegs; ++k) {

@@ -5,6 +5,9 @@
     python tools/ab_build.py stamps "-DMSW_STAMPS=1"
     MSWEEP_CORE_LIB=build_ab/lib_stamps.so python tools/chain_timeline.py [reads groups]
 
+CAVEAT: with the stamps compiled in, k_finstep no longer fits its registers (it spills ~450 bytes per lane; the product
+build spills nothing) and runs several times slower: read the sweeps', k_redfin's and the boundaries' numbers here, and
+take k_finstep's duration from a rocprofv3 kernel trace of the product build (tools/collect_profiles.sh).
 Prints the mean timeline of the iterations of a fixed-iteration solve (us from the start of pass A).  The stamps exist
 only under MSW_STAMPS; the product build carries none."""
 import ctypes as C
