@@ -38,6 +38,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# CPU baselines: threads pinned next to each other -- read by libgomp when the oracle loads
+os.environ.setdefault("OMP_PROC_BIND", "close")
 
 OUT = sys.stdout
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -104,7 +106,7 @@ def cpu_share():
 
 
 def cpu_info():
-    info = {"logical_cpus": os.cpu_count(), "usable_cpus": cpu_share()}
+    info = {"logical_cpus": os.cpu_count(), "usable_cpus": cpu_share(), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND")}
     try:
         txt = open("/proc/cpuinfo").read()
         models = [ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("model name")]
@@ -118,11 +120,11 @@ def cpu_info():
 
 
 # ---- CPU baselines (oracle legs: test infrastructure, the ONLY place bench.py touches oracle/) ------------------
-def _oracle():
+def _oracle(threads=None, fastmath=False):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import Oracle
-    O = Oracle()
-    cores = cpu_share()
+    O = Oracle(fastmath=fastmath)
+    cores = cpu_share() if threads is None else threads
     O.set_num_threads(cores)
     return O, cores
 
@@ -138,19 +140,38 @@ def _timed_iters(fn, iters):
     return max((t2 - t1) - (t1 - t0), 1e-9), t1 - t0
 
 
-def cpu_dense_state(L, logc, iters, what):
+def cpu_dense_state(L, logc, iters, what, threads=None, fastmath=False):
     """The dense-state RCG exactly as the reference structures it (rcgpar::rcg_optl_omp restated: L, gamma, step,
-    oldstep as G x E fp64), timed on the host cores on the dense matrix L."""
+    oldstep as G x E fp64), timed on the host cores on the dense matrix L.  threads: OpenMP threads (default: the
+    box's CPU share); fastmath: the oracle built with the reference's Release flags (-ffast-math, CMakeLists.txt:20)."""
     import numpy as np
-    O, cores = _oracle()
+    O, cores = _oracle(threads, fastmath)
     G, E = L.shape
     dt, t_first = _timed_iters(lambda n: O.rcg_optl_dense(L, logc, np.ones(G), tol=-1.0, max_iters=n), iters)
     return {"value": E * G * iters / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+            "build": "-O3 -march=x86-64-v3 -fopenmp" + (" -ffast-math -funroll-loops" if fastmath else ""),
             "sample": f"{what} as a dense fp64 matrix ({E} ECs x {G} groups, {E * G * 8 / 1e9:.1f} GB; the reference's "
                       f"four G x E matrices), {iters} RCG iterations of the dense-state restatement of "
-                      f"rcgpar::rcg_optl_omp on {cores} OpenMP threads, {dt:.1f} s (+ {t_first:.1f} s for set-up and one "
-                      f"iteration); iters/s on the sample = {iters / dt:.3f}",
+                      f"rcgpar::rcg_optl_omp on {cores} OpenMP thread{'s' if cores != 1 else ''}, {dt:.1f} s (+ {t_first:.1f} s "
+                      f"for set-up and one iteration); iters/s on the sample = {iters / dt:.3f}",
             "cpu": cpu_info()}
+
+
+def cpu_dense_lines(make_L, logc, n_full, iters, what):
+    """BASELINE.md 2's three CPU lines of the dense-state restatement: all usable cores, the same with the
+    reference's -ffast-math build on the SAME sample, and ONE thread on a tenth of it (the same rows of the same
+    matrix: one thread on the whole sample would take minutes)."""
+    L = make_L(n_full)
+    out = {"cpu_baseline": cpu_dense_state(L, logc[:n_full], iters, what(n_full)),
+           "cpu_baseline_fastmath": cpu_dense_state(L, logc[:n_full], iters, what(n_full), fastmath=True)}
+    n1 = max(n_full // 10, 1)
+    out["cpu_baseline_1thread"] = cpu_dense_state(np_ascontig(L[:, :n1]), logc[:n1], iters, what(n1), threads=1)
+    return out
+
+
+def np_ascontig(a):
+    import numpy as np
+    return np.ascontiguousarray(a)
 
 
 def cpu_structured_csr(rowptr, grp, lutidx, lut, G, logc, iters, what):
@@ -268,7 +289,8 @@ def load_workload(a, core, shard, rank, world):
         log(f"cfg2: dense {G} x {E} generated in {t_gen:.1f}s, resident in {t_up:.2f}s (listed cells {nnz})")
 
         def cpu():
-            out = {"cpu_baseline": cpu_dense_state(p["logl"], p["logc"], a.cpu_iters, "the full cfg2 workload")}
+            out = cpu_dense_lines(lambda n: p["logl"] if n == E else np.ascontiguousarray(p["logl"][:, :n]), p["logc"], E,
+                                  a.cpu_iters, lambda n: "the full cfg2 workload" if n == E else f"first {n} ECs of the cfg2 workload")
             O, cores = _oracle()
             dt, _ = _timed_iters(lambda n: O.rcg_optl_dense_structured(p["logl"], p["logc"], np.ones(G), tol=-1.0,
                                                                        max_iters=n), 5)
@@ -306,8 +328,32 @@ def load_workload(a, core, shard, rank, world):
                              ecc, min_hits=1)
         t_build = time.time() - t0
         hits = int(len(aln["ec_targets"]))
-        del aln
         G2 = lik.n_groups
+        keep = {"aln": aln}
+        del aln
+
+        def first_theta():
+            """msw_core_build_likelihood (--min-hits 1) + solve to --tol 1e-6 on a fresh handle of this (warm) process."""
+            from msweep_amd.core import Core
+            al = keep.pop("aln")
+            out = {}
+            for sched in (False, True):
+                with Core(core.device) as c2:
+                    c2.set_pack_schedule(sched)
+                    t1 = time.perf_counter()
+                    lk = from_alignment(c2, al["ec_tptr"], al["ec_targets"], al["target_group"], p["group_sizes"], ecc,
+                                        min_hits=1, download_log_counts=False)
+                    t2 = time.perf_counter()
+                    r = c2.solve(None, np.ones(lk.n_groups))
+                    t3 = time.perf_counter()
+                out["bank_scheduled" if sched else "unscheduled"] = {
+                    "build_likelihood_ms": (t2 - t1) * 1e3, "solve_ms": (t3 - t2) * 1e3, "total_ms": (t3 - t1) * 1e3,
+                    "iters": int(r["iters"])}
+            out["ms"] = out["unscheduled"]["total_ms"]
+            out["what"] = ("msw_core_build_likelihood(--min-hits 1) + msw_core_solve(--tol 1e-6, log counts resident) on a "
+                           "fresh handle, host wall clock, the pseudoalignment in pageable host memory; `unscheduled` = "
+                           "msw_core_set_pack_schedule(0), the drivers' choice for one solve")
+            return out
         log(f"cfg5: E={E} nnz={nnz} generated in {t_gen:.0f}+{t_aln:.0f}s; build (upload of {hits} target hits, "
             f"K0-K2, --min-hits 1 mask, SELL packing) {t_build:.2f}s; {G2} of {G} groups kept")
 
@@ -317,15 +363,14 @@ def load_workload(a, core, shard, rank, world):
             grp2 = newid[p["grp"]].astype(np.uint32)
             lut = precalc_lls(p["group_sizes"][kept])
             lutidx = (grp2 * lut.shape[1] + p["cnt"]).astype(np.uint32)
-            out = {}
             n = min(200_000, E)
-            out["cpu_baseline"] = cpu_dense_state(dense_sample(p["rowptr"], grp2, p["cnt"], lut, G2, n),
-                                                  lik.log_counts()[:n], a.cpu_iters,
-                                                  f"first {n} ECs of the cfg5 workload x the {G2} groups --min-hits 1 keeps")
+            out = cpu_dense_lines(lambda m: dense_sample(p["rowptr"], grp2, p["cnt"], lut, G2, m), lik.log_counts(), n,
+                                  a.cpu_iters, lambda m: f"first {m} ECs of the cfg5 workload x the {G2} groups --min-hits 1 keeps")
             out["cpu_baseline_structured"] = cpu_structured_csr(p["rowptr"], grp2, lutidx, lut, G2, lik.log_counts(), 3,
                                                                 "full cfg5 workload (compacted to the kept groups)")
             return out
         return dict(E=E, G=G2, nnz=nnz, logc=lik.log_counts() if shard else None, w=None, cpu=cpu, reads=a.reads,
+                    first_theta=None if shard else first_theta,
                     setup_s={"generate": t_gen, "expand_to_targets": t_aln, "build_likelihood": t_build},
                     build={"seconds": t_build, "target_hits": hits, "groups_in": G, "groups_kept": G2,
                            "what": "msw_core_build_likelihood: upload of the pseudoalignment (ec_tptr / ec_targets / "
@@ -356,17 +401,45 @@ def load_workload(a, core, shard, rank, world):
         n = min(a.cpu_sample_ecs, E)
         lutidx = (prob["grp"].astype(np.uint32) * lut.shape[1] + prob["cnt"]).astype(np.uint32)
         logc = np.log(prob["ec_counts"].astype(float))
-        return {"cpu_baseline": cpu_dense_state(dense_sample(prob["rowptr"], prob["grp"], prob["cnt"], lut, G, n), logc[:n],
-                                                a.cpu_iters, f"first {n} ECs of the cfg3 workload x {G} groups"),
-                "cpu_baseline_structured": cpu_structured_csr(prob["rowptr"], prob["grp"], lutidx, lut, G, logc, 5,
-                                                              "full cfg3 workload")}
+        out = cpu_dense_lines(lambda m: dense_sample(prob["rowptr"], prob["grp"], prob["cnt"], lut, G, m), logc, n, a.cpu_iters,
+                              lambda m: f"first {m} ECs of the cfg3 workload x {G} groups")
+        out["cpu_baseline_structured"] = cpu_structured_csr(prob["rowptr"], prob["grp"], lutidx, lut, G, logc, 5,
+                                                            "full cfg3 workload")
+        return out
+    def first_theta():
+        """Time to the FIRST estimate of a likelihood the host holds as CSR-of-ECs: msw_core_set_csr (upload, slot
+        plan, SELL packing -- without the LDS-bank ordering of the cells, which pays from the ~1000th iteration on:
+        what the drivers do for runs of one solve) + the solve to --tol 1e-6, on a fresh handle of this (warm) process."""
+        from msweep_amd.core import Core
+        lut = precalc_lls(prob["group_sizes"])
+        logc = lik.log_counts()
+        out = {}
+        for sched in (False, True):
+            with Core(core.device) as c2:
+                c2.set_pack_schedule(sched)
+                t1 = time.perf_counter()
+                c2.set_csr(prob["rowptr"], prob["grp"], prob["cnt"], lut, np.log(0.01), G)
+                t2 = time.perf_counter()
+                r = c2.solve(logc, np.ones(G))
+                t3 = time.perf_counter()
+            out["bank_scheduled" if sched else "unscheduled"] = {
+                "set_csr_ms": (t2 - t1) * 1e3, "solve_ms": (t3 - t2) * 1e3, "total_ms": (t3 - t1) * 1e3, "iters": int(r["iters"])}
+        out["ms"] = out["unscheduled"]["total_ms"]
+        out["what"] = ("msw_core_set_csr + msw_core_solve(--tol 1e-6) on a fresh handle, host wall clock, inputs in "
+                       "pageable host memory; `unscheduled` = msw_core_set_pack_schedule(0), the drivers' choice for "
+                       "one solve; setup_s.set_csr is the process's FIRST upload (cold allocator) incl. the Python "
+                       "mirror's table and log-count work")
+        return out
+
     if a.group_sizes == "diverse":
         return dict(E=E, G=G, nnz=nnz, logc=lik.log_counts(), w=prob["ec_counts"].astype(np.uint32), cpu=cpu, reads=a.reads,
+                    first_theta=first_theta,
                     setup_s={"generate": t_gen, "set_csr": t_up},
                     desc=f"{a.config} with DIVERSE group sizes (log-normal, up to 400 sequences per group: "
                          f"{int(prob['group_sizes'].max())} here; thousands of used lookup-table slots -> index records + hybrid "
                          "slot area): synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB, fixed iteration count")
     return dict(E=E, G=G, nnz=nnz, logc=lik.log_counts(), w=prob["ec_counts"].astype(np.uint32), cpu=cpu, reads=a.reads,
+                first_theta=first_theta,
                 setup_s={"generate": t_gen, "set_csr": t_up},
                 desc="cfg3: synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB (--algorithm rcggpu), "
                      "fixed iteration count" if a.config == "cfg3" else
@@ -656,6 +729,11 @@ def main():
             line["likelihood_build"] = wl["build"]
         if conv is not None:
             line["time_to_convergence"] = conv
+        if wl.get("first_theta") is not None and n_gpus == 1 and not a.no_extras:
+            try:
+                line["time_to_first_theta"] = wl["first_theta"]()
+            except Exception as ex:  # reporting only
+                line["time_to_first_theta"] = {"ms": None, "what": f"failed: {ex}"}
         if em is not None:
             line["em_algorithm"] = em
         if boot is not None:

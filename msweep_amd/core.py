@@ -244,9 +244,9 @@ class Core:
                                              lut.shape[1], float(logzi), int(n_groups), E))
 
     def build_likelihood(self, ec_tptr, ec_targets, target_group, group_sizes, ec_counts, q=0.65, e=0.01,
-                         zero_inflation=0.01, min_hits=0):
+                         zero_inflation=0.01, min_hits=0, want_logc=True):
         """Device build from the pseudoalignment (replaces LL_WOR21::fill_ll_mat).
-        Returns (n_groups_kept, mask[G] bool, logc[E])."""
+        Returns (n_groups_kept, mask[G] bool, logc[E] or None when want_logc is False)."""
         ec_tptr = _arr(ec_tptr, np.uint64)
         ec_targets = _arr(ec_targets, np.uint32)
         target_group = _arr(target_group, np.uint32)
@@ -257,7 +257,7 @@ class Core:
             raise MswError("build_likelihood: ec_counts length != n_ecs")
         n_out = C.c_size_t()
         mask = np.zeros(G, np.uint8)
-        logc = np.empty(E, np.float64)
+        logc = np.empty(E, np.float64) if want_logc else None
         self._check(self._L.msw_core_build_likelihood(
             self._h, _ptr(ec_tptr), _ptr(ec_targets), E, _ptr(target_group), len(target_group),
             _ptr(group_sizes), G, _ptr(ec_counts), q, e, zero_inflation, int(min_hits), C.byref(n_out),

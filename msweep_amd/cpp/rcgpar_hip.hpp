@@ -21,10 +21,21 @@
 // The preferred integration keeps the likelihood on the device: msw::DeviceLikelihood owns a
 // core handle, is filled once per grouping (set_csr / build / set_dense) and serves the
 // 1 + --iters estimation calls without re-uploading.
+//
+// The UNMODIFIED call sites get the same effect through a one-entry cache: mSWEEP passes the same `ll_mat` object to
+// rcg_optl() once for the estimate and once per bootstrap replicate (src/mSWEEP.cpp:402,507 -- `log_likelihoods->
+// log_mat()`, const for the whole grouping), so the drop-ins below keep the DeviceLikelihood of the last matrix they saw,
+// keyed by (address, rows, columns, a hash of 65 536 sampled cells, device): calls 2 .. 1 + --iters cost their solve, not
+// another host copy + upload + device compression of the G x E matrix.  A matrix that was rewritten in place is
+// caught by the sampled hash -- with the probability of a sample, not with certainty: callers that DO rewrite a
+// matrix at the same address between calls (the reference does not) call rcgpar::forget_likelihood() or set
+// MSWEEP_SHIM_CACHE=0.
 #pragma once
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <memory>
 #include <ostream>
 #include <stdexcept>
 #include <string>
@@ -88,6 +99,9 @@ class DeviceLikelihood {
   DeviceLikelihood(const DeviceLikelihood &) = delete;
   DeviceLikelihood &operator=(const DeviceLikelihood &) = delete;
   msw_handle handle() const { return h_; }
+  // LDS-bank ordering of the cells at upload (msw_core_set_pack_schedule): pays from about the 1 000th iteration on the
+  // same likelihood -- set it for bootstrap runs (--iters >= 5), leave it off for one solve.  Before set_* / build.
+  void set_pack_schedule(bool on) { check(h_, msw_core_set_pack_schedule(h_, on ? 1 : 0)); }
 
   template <class MatrixT>
   void set_dense(const MatrixT &logl) {  // rows = groups (seamat layout)
@@ -176,19 +190,93 @@ inline Gamma gamma_of(DeviceLikelihood &lik, size_t n_groups, size_t n_ecs) {
   return out;
 }
 
+// ---- the likelihood of the unmodified call sites, kept across calls (file header) -------------------------------
+namespace detail {
+struct ShimCache {
+  const void *addr = nullptr;
+  size_t rows = 0, cols = 0;
+  uint64_t hash = 0;
+  int device = -1;
+  DeviceLikelihood *lik = nullptr;  // owned; deliberately NOT destroyed at process exit (the HIP runtime may be gone
+                                    // by then: the driver reclaims device memory anyway) -- forget_likelihood() frees it
+  size_t hits = 0, uploads = 0;
+};
+inline ShimCache &shim_cache() {
+  static thread_local ShimCache c;  // the reference calls from its single main thread (src/mSWEEP.cpp:402,507)
+  return c;
+}
+// FNV-1a over the bit patterns of kSample cells at fixed pseudo-random positions plus the four corners
+template <class MatrixT>
+uint64_t sample_hash(const MatrixT &logl) {
+  const size_t G = logl.get_rows(), E = logl.get_cols();
+  uint64_t h = 1469598103934665603ull;
+  auto eat = [&](size_t g, size_t j) {
+    const double v = logl(g, j);
+    uint64_t b;
+    static_assert(sizeof b == sizeof v, "double is 64 bits");
+    __builtin_memcpy(&b, &v, sizeof b);
+    for (int k = 0; k < 8; ++k) h = (h ^ ((b >> (8 * k)) & 0xffu)) * 1099511628211ull;
+  };
+  if (G == 0 || E == 0) return h;
+  constexpr size_t kSample = 65536;
+  const unsigned __int128 n = (unsigned __int128)G * E;
+  uint64_t x = 0x9e3779b97f4a7c15ull;
+  for (size_t i = 0; i < kSample; ++i) {
+    x = x * 6364136223846793005ull + 1442695040888963407ull;
+    const size_t pos = (size_t)(((unsigned __int128)x * n) >> 64);
+    eat(pos / E, pos % E);
+  }
+  eat(0, 0), eat(0, E - 1), eat(G - 1, 0), eat(G - 1, E - 1);
+  return h;
+}
+template <class MatrixT>
+DeviceLikelihood &resident(const MatrixT &logl, int device) {
+  ShimCache &c = shim_cache();
+  const char *sw = std::getenv("MSWEEP_SHIM_CACHE");
+  const bool use = !(sw && sw[0] == '0');
+  const uint64_t h = use ? sample_hash(logl) : 0;
+  if (use && c.lik && c.addr == static_cast<const void *>(&logl) && c.rows == logl.get_rows() &&
+      c.cols == logl.get_cols() && c.hash == h && c.device == device) {
+    ++c.hits;
+    return *c.lik;
+  }
+  delete c.lik;
+  c.lik = nullptr;
+  c.lik = new DeviceLikelihood(device);
+  c.lik->set_pack_schedule(false);  // the shortest way to the FIRST estimate; a bootstrap pays 5 % per iteration for it
+  c.lik->set_dense(logl);
+  c.addr = &logl, c.rows = logl.get_rows(), c.cols = logl.get_cols(), c.hash = h, c.device = device;
+  ++c.uploads;
+  return *c.lik;
+}
+}  // namespace detail
+
 }  // namespace msw
 
 namespace rcgpar {
 
-// Drop-in for the call at src/mSWEEP.cpp:194 (a dense `ll_mat` is uploaded for the call).
+// Drop-in for the call at src/mSWEEP.cpp:194 (the dense `ll_mat` is uploaded by the first call that sees it and stays
+// resident for the calls that follow: msw::detail::resident).
 template <class MatrixT>
 msw::Gamma rcg_optl_torch(const MatrixT &logl, const std::vector<double> &log_times_observed,
                           const std::vector<double> &alpha0, const double &tol, size_t max_iters, std::ostream &log,
                           int device = 0) {
-  msw::DeviceLikelihood lik(device);
-  lik.set_dense(logl);
+  msw::DeviceLikelihood &lik = msw::detail::resident(logl, device);
   msw::solve(lik, log_times_observed, alpha0, tol, max_iters, MSW_ALGO_RCG, MSW_PREC_DOUBLE, &log);
   return msw::gamma_of(lik, logl.get_rows(), logl.get_cols());
+}
+
+// Frees the likelihood the drop-ins keep resident between calls (and makes the next call upload again).
+inline void forget_likelihood() {
+  msw::detail::ShimCache &c = msw::detail::shim_cache();
+  delete c.lik;
+  c.lik = nullptr;
+  c.addr = nullptr;
+}
+// (uploads, cache hits) of the drop-ins on this thread so far: diagnostics / tests
+inline std::pair<size_t, size_t> likelihood_cache_stats() {
+  const msw::detail::ShimCache &c = msw::detail::shim_cache();
+  return {c.uploads, c.hits};
 }
 
 // Drop-in for the call at src/mSWEEP.cpp:198 (--algorithm rcgcpu, the reference's default): the same
@@ -206,8 +294,7 @@ msw::Gamma em_torch(const MatrixT &logl, const std::vector<double> &log_times_ob
                     const std::vector<double> &alpha0, const double &tol, size_t max_iters, std::ostream &log,
                     std::string precision, int device = 0) {
   if (precision != "double" && precision != "float") throw std::runtime_error("em_torch: unknown precision " + precision);
-  msw::DeviceLikelihood lik(device);
-  lik.set_dense(logl);
+  msw::DeviceLikelihood &lik = msw::detail::resident(logl, device);
   msw::solve(lik, log_times_observed, alpha0, tol, max_iters, MSW_ALGO_EM,
              precision == "float" ? MSW_PREC_FLOAT : MSW_PREC_DOUBLE, &log);
   return msw::gamma_of(lik, logl.get_rows(), logl.get_cols());

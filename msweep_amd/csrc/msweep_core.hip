@@ -888,6 +888,9 @@ int msw_core_create(int device, msw_handle *out) {
     h->device = device;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     MSW_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    hipLaunchKernelGGL(k_warm, dim3(1), dim3(1), 0, h->stream, (int *)nullptr);  // code object load: here, once per process
+    MSW_HIP(hipGetLastError());
+    MSW_HIP(hipStreamSynchronize(h->stream));
     *out = h.release();
     return 0;
   } catch (const std::exception &ex) {

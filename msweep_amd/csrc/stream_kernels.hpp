@@ -7,6 +7,13 @@
 
 namespace msw {
 
+// first launch of the process: loads the library's code object (~15 ms for its few hundred sweep instantiations) at
+// msw_core_create instead of inside the first msw_core_set_csr / msw_core_build_likelihood
+__global__ void k_warm(int *p) {
+  if (p) *p = 0;
+}
+
+
 __global__ __launch_bounds__(1024) void k_stream_read(const double2 *a, size_t n, double *sink) {
   double s0 = 0.0, s1 = 0.0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;

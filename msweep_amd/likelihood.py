@@ -46,15 +46,20 @@ class Likelihood:
     """Device-resident likelihood of one grouping (the object main() keeps at
     src/mSWEEP.cpp:294,346 and passes to rcg_optl at :402 and :507)."""
 
-    def __init__(self, core: Core, log_counts, groups_considered, n_groups, n_ecs):
+    def __init__(self, core: Core, log_counts, groups_considered, n_groups, n_ecs, ec_counts=None):
         self.core = core
-        self._log_counts = np.asarray(log_counts, np.float64)
+        # (log_counts None: formed on first use from the EC counts -- a device build leaves them resident for the
+        # solves, so the 8 * E byte download is only paid by callers that ask for the host vector)
+        self._log_counts = None if log_counts is None else np.asarray(log_counts, np.float64)
+        self._ec_counts = ec_counts
         self._mask = np.asarray(groups_considered, bool)
         self.n_groups = int(n_groups)
         self.n_ecs = int(n_ecs)
 
     # accessor names of include/Likelihood.hpp:72-79
     def log_counts(self):
+        if self._log_counts is None:
+            self._log_counts = np.log(np.asarray(self._ec_counts, np.float64))   # fill_ec_counts, include/Likelihood.hpp:188-195
         return self._log_counts
 
     def groups_considered(self):
@@ -76,11 +81,13 @@ def from_grouped_counts(core: Core, rowptr, grp, cnt, ec_counts, group_sizes, q=
 
 
 def from_alignment(core: Core, ec_tptr, ec_targets, target_group, group_sizes, ec_counts, q=0.65, e=0.01,
-                   zero_inflation=0.01, min_hits=0):
-    """ConstructAdaptiveLikelihood (include/Likelihood.hpp:333-380) on the device."""
+                   zero_inflation=0.01, min_hits=0, download_log_counts=True):
+    """ConstructAdaptiveLikelihood (include/Likelihood.hpp:333-380) on the device.  download_log_counts=False: the
+    log counts stay on the device only (solve(None, ...) uses them there); log_counts() then forms the host vector
+    on demand."""
     n_kept, mask, logc = core.build_likelihood(ec_tptr, ec_targets, target_group, group_sizes, ec_counts,
-                                               q, e, zero_inflation, min_hits)
-    return Likelihood(core, logc, mask, n_kept, len(ec_tptr) - 1)
+                                               q, e, zero_inflation, min_hits, want_logc=download_log_counts)
+    return Likelihood(core, logc, mask, n_kept, len(ec_tptr) - 1, ec_counts=None if download_log_counts else ec_counts)
 
 
 def from_dense(core: Core, logl, log_counts):

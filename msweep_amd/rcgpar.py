@@ -23,11 +23,61 @@ class EcProbs:
         return self.core.gamma()
 
 
+# The dense `logl` of the unmodified call sites stays resident between calls: mSWEEP passes the same matrix once for
+# the estimate and once per bootstrap replicate (src/mSWEEP.cpp:402,507).  One entry, keyed by (object identity,
+# shape, a hash of 65 536 sampled cells, device); replaced -- and its handle closed -- when another matrix arrives.
+# A matrix rewritten in place is caught with the probability of the sample: forget_likelihood() / MSWEEP_SHIM_CACHE=0.
+_cache = {"key": None, "core": None, "uploads": 0, "hits": 0}
+
+
+def _sample_hash(a):
+    n = a.size
+    if n == 0:
+        return 0
+    rng = np.random.Generator(np.random.PCG64(0x9e3779b97f4a7c15))
+    pos = rng.integers(0, n, 65536)
+    flat = a.reshape(-1) if a.flags.c_contiguous else None
+    vals = flat[pos] if flat is not None else a[pos // a.shape[1], pos % a.shape[1]]
+    corners = np.array([a[0, 0], a[0, -1], a[-1, 0], a[-1, -1]])
+    return hash(np.concatenate([vals, corners]).tobytes())
+
+
+def forget_likelihood():
+    """Close the handle the dense call sites keep resident (the next call uploads again)."""
+    if _cache["core"] is not None:
+        _cache["core"].close()
+    _cache["key"], _cache["core"] = None, None
+
+
+def likelihood_cache_stats():
+    return _cache["uploads"], _cache["hits"]
+
+
 def _resolve(logl, log_times_observed, device):
     if isinstance(logl, Likelihood):
         return logl.core
+    import os
+    a = np.asarray(logl, np.float64)
+    if a.ndim != 2:
+        raise MswError("rcg_optl: expected a G x E matrix")
+    if os.environ.get("MSWEEP_SHIM_CACHE", "1") == "0":
+        forget_likelihood()
+        key = None
+    else:
+        key = (id(logl), a.shape, _sample_hash(a), device)
+        if _cache["core"] is not None and _cache["key"] == key:
+            _cache["hits"] += 1
+            return _cache["core"]
+        forget_likelihood()
     core = Core(device)
-    from_dense(core, logl, log_times_observed)
+    try:
+        core.set_pack_schedule(False)     # the shortest way to the first estimate (msw_core_set_pack_schedule)
+        from_dense(core, a, log_times_observed)
+    except Exception:
+        core.close()
+        raise
+    _cache["key"], _cache["core"] = key, core
+    _cache["uploads"] += 1
     return core
 
 

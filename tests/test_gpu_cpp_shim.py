@@ -106,3 +106,70 @@ def test_device_likelihood_build_and_accessors(device_likelihood_binary, gpu_cor
     np.testing.assert_array_equal(np.array(out["logc"].split(), float), lik.log_counts())
     assert int(out["iters"]) == res["iters"]
     np.testing.assert_array_equal(np.array(out["theta"].split(), float), res["theta"])
+
+
+def test_reference_calls_keep_the_likelihood_resident_over_the_bootstrap_loop(reference_calls_binary, gpu_core, tmp_path):
+    """src/mSWEEP.cpp:402,507: the same `ll_mat` goes to rcg_optl() 1 + --iters times.  Through the verbatim call
+    expressions: ONE upload for the estimate and 20 replicates (the shim keeps the matrix resident, keyed by address,
+    shape and a sampled content hash), every later call served at the cost of its solve + the dense gamma it must
+    return; a matrix rewritten in place at the same address is uploaded again."""
+    from conftest import dense_from_csr
+    from msweep_amd import synth
+    from msweep_amd.likelihood import from_dense, precalc_lls
+    G, B = 120, 20
+    p = synth.make_csr_problem(60000, G, seed=71, max_other=6)
+    L = dense_from_csr(p, precalc_lls(p["group_sizes"]))
+    E = L.shape[1]
+    logc = np.log(p["ec_counts"].astype(float))
+    alpha0 = np.ones(G)
+    path = tmp_path / "problem.bin"
+    with open(path, "wb") as f:
+        np.array([G, E], np.uint64).tofile(f)
+        L.tofile(f)
+        logc.tofile(f)
+        alpha0.tofile(f)
+    r = subprocess.run([reference_calls_binary, "rcgcpu", str(path), str(B)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(line.split(" ", 1) for line in r.stdout.strip().splitlines())
+    print({k: v for k, v in out.items() if not k.startswith("theta")})
+    assert int(out["uploads"]) == 1 and int(out["hits"]) == B
+    assert int(out["uploads_after_change"]) == 2
+    first, later, solve = float(out["first_ms"]), float(out["later_ms"]), float(out["later_solve_ms"])
+    assert later < 0.6 * first, (first, later)          # the host copy + upload + device compression are paid once
+    # the answers: the estimate, replicate 1 (log counts rotated by one) and the rewritten matrix, against the Python
+    # mirror on the same inputs
+    from_dense(gpu_core, L, logc)
+    assert_theta(np.array(out["theta"].split(), float), gpu_core.solve(logc, alpha0)["theta"], rel=1e-9, abs_=1e-12)
+    assert_theta(np.array(out["theta_b1"].split(), float), gpu_core.solve(np.roll(logc, -1), alpha0)["theta"], rel=1e-9, abs_=1e-12)
+    L2 = np.where(L > -4.0, L - 0.25, L)
+    from_dense(gpu_core, L2, logc)
+    ref2 = gpu_core.solve(logc, alpha0)["theta"]
+    th2 = np.array(out["theta_changed"].split(), float)
+    assert_theta(th2, ref2, rel=1e-9, abs_=1e-12)
+    assert np.max(np.abs(th2 - np.array(out["theta"].split(), float))) > 1e-6      # and it IS another answer
+    print(f"first call {first:.1f} ms, later calls {later:.1f} ms each (solve {solve:.1f} ms + the dense gamma the boundary returns)")
+
+
+def test_python_mirror_keeps_the_dense_likelihood_resident(gpu_core):
+    from conftest import dense_from_csr
+    from msweep_amd import rcgpar, synth
+    from msweep_amd.likelihood import precalc_lls
+    p = synth.make_csr_problem(20000, 40, seed=72, max_other=5)
+    L = dense_from_csr(p, precalc_lls(p["group_sizes"]))
+    logc = np.log(p["ec_counts"].astype(float))
+    alpha0 = np.ones(40)
+    rcgpar.forget_likelihood()
+    u0, h0 = rcgpar.likelihood_cache_stats()
+    a = rcgpar.rcg_optl("rcgcpu", L, logc, alpha0)
+    b = rcgpar.rcg_optl("rcggpu", L, np.roll(logc, -1), alpha0)
+    c = rcgpar.rcg_optl("emgpu", L, logc, alpha0)
+    assert rcgpar.likelihood_cache_stats() == (u0 + 1, h0 + 2)
+    assert a.core is b.core is c.core
+    first_core = a.core
+    L[L > -4.0] -= 0.25                      # rewritten in place: same object, same shape
+    d = rcgpar.rcg_optl("rcgcpu", L, logc, alpha0)
+    assert rcgpar.likelihood_cache_stats()[0] == u0 + 2 and d.core is not first_core
+    assert first_core._h is None             # the handle it replaced was closed, not leaked
+    assert np.max(np.abs(d.theta - a.theta)) > 1e-6
+    rcgpar.forget_likelihood()
+    assert d.core._h is None
