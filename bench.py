@@ -38,8 +38,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# CPU baselines: threads pinned next to each other -- read by libgomp when the oracle loads
-os.environ.setdefault("OMP_PROC_BIND", "close")
 
 OUT = sys.stdout
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -106,7 +104,9 @@ def cpu_share():
 
 
 def cpu_info():
-    info = {"logical_cpus": os.cpu_count(), "usable_cpus": cpu_share(), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND")}
+    info = {"logical_cpus": os.cpu_count(), "usable_cpus": cpu_share(), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND", "unset")}
+    # (not forced to `close`: a GPU box grants a CPU SHARE of a host its other tenants use too -- pinning 16 threads to
+    # the first 16 hardware threads of that host stalled the baseline for minutes; the scheduler places them)
     try:
         txt = open("/proc/cpuinfo").read()
         models = [ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("model name")]
@@ -162,10 +162,14 @@ def cpu_dense_lines(make_L, logc, n_full, iters, what):
     reference's -ffast-math build on the SAME sample, and ONE thread on a tenth of it (the same rows of the same
     matrix: one thread on the whole sample would take minutes)."""
     L = make_L(n_full)
-    out = {"cpu_baseline": cpu_dense_state(L, logc[:n_full], iters, what(n_full)),
-           "cpu_baseline_fastmath": cpu_dense_state(L, logc[:n_full], iters, what(n_full), fastmath=True)}
+    log(f"cpu baseline: dense-state restatement, {L.shape[1]} ECs x {L.shape[0]} groups, all cores ...")
+    out = {"cpu_baseline": cpu_dense_state(L, logc[:n_full], iters, what(n_full))}
+    log(f"cpu baseline: {out['cpu_baseline']['value']:.3g} cells/s; the -ffast-math build ...")
+    out["cpu_baseline_fastmath"] = cpu_dense_state(L, logc[:n_full], iters, what(n_full), fastmath=True)
     n1 = max(n_full // 10, 1)
+    log(f"cpu baseline: {out['cpu_baseline_fastmath']['value']:.3g} cells/s; one thread on {n1} ECs ...")
     out["cpu_baseline_1thread"] = cpu_dense_state(np_ascontig(L[:, :n1]), logc[:n1], iters, what(n1), threads=1)
+    log(f"cpu baseline: {out['cpu_baseline_1thread']['value']:.3g} cells/s")
     return out
 
 
