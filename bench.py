@@ -52,8 +52,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100; cfg4: 4 replicates per rank)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20; cfg4: 1)")
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg3",
-                    help="BASELINE.json configuration (default cfg3, the one the metric is quoted on)")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5", "e2e"], default="cfg3",
+                    help="BASELINE.json configuration (default cfg3, the one the metric is quoted on); e2e: cfg3's reads "
+                         "from Themisto plaintext files to abundances.txt (SURVEY 8f-1: reader + collapse, device build, "
+                         "solve, writer -- its own JSON object)")
     ap.add_argument("--reads", type=int, default=None, help="cfg3/4/5: reads (default 10M; cfg5 50M); cfg2: ECs (1M)")
     ap.add_argument("--groups", type=int, default=None, help="default 5000 (cfg2: 500, cfg5: 20000)")
     ap.add_argument("--seed", type=int, default=None, help="generator seed (default: 2; cfg2: 1; cfg5: 3)")
@@ -78,7 +80,7 @@ def parse():
                     help="initialise torch.distributed / RCCL even with one rank (exercises the N > 1 code path)")
     a = ap.parse_args()
     dflt = {"cfg2": (1_000_000, 500, 1), "cfg3": (10_000_000, 5000, 2), "cfg4": (10_000_000, 5000, 2),
-            "cfg5": (50_000_000, 20_000, 3)}[a.config]
+            "cfg5": (50_000_000, 20_000, 3), "e2e": (10_000_000, 5000, 2)}[a.config]
     a.default_shape = (a.reads, a.groups, a.seed) == (None, None, None) and a.group_sizes == "poisson"
     a.reads = dflt[0] if a.reads is None else a.reads
     a.groups = dflt[1] if a.groups is None else a.groups
@@ -271,6 +273,129 @@ def launch_selftest(a, rank, world):
     if rank == 0:
         print(json.dumps({"selftest": True, "n_gpus": world, "gathered": [float(x.item()) for x in out]}), flush=True)
     dist.destroy_process_group()
+
+
+# ---- end to end from Themisto text ---------------------------------------------------------------
+def run_e2e(a):
+    """cfg3's reads as two Themisto plaintext strands -> msw_alignment_read (parse, paired-end intersection, collapse
+    into equivalence classes) -> msw_core_build_likelihood -> solve to --tol 1e-6 -> abundances.txt.  One GPU.  Beside
+    it: the same files through the Python mirror of include/mSWEEP_alignment.hpp (msweep_amd/alignment.py) on a bounded
+    prefix, and a gzip pair (single-threaded zlib inflate in front of the same parser)."""
+    import gzip
+    import io
+    import shutil
+    import tempfile
+    import numpy as np
+    from msweep_amd import synth
+    from msweep_amd.alignment import Alignment
+    from msweep_amd.core import Core, read_alignment
+    from msweep_amd.likelihood import from_alignment
+    from msweep_amd.sample import PlainSample
+    G, R = a.groups, a.reads
+    tmp = tempfile.mkdtemp(prefix="msweep_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        t0 = time.time()
+        prob = synth.make_csr_problem(R, G, seed=a.seed)
+        aln = synth.csr_to_targets(prob, shuffle=False)
+        E = len(prob["ec_counts"])
+        log(f"e2e: {R} reads x {G} groups generated ({E} ECs, {aln['n_targets']} targets) in {time.time() - t0:.0f}s; writing text ...")
+        rng = np.random.default_rng(11)
+        ec_of = rng.permutation(np.repeat(np.arange(E, dtype=np.int64), prob["ec_counts"].astype(np.int64)))
+        f1, f2 = os.path.join(tmp, "reads_1.txt"), os.path.join(tmp, "reads_2.txt")
+        t0 = time.time()
+        nbytes = 0
+        for k, path in enumerate((f1, f2)):
+            # the second strand disagrees with its mate on a tenth of the reads (one more target: gone after the
+            # intersection), so the merge has something to do
+            nbytes += synth.write_themisto(path, ec_of, aln["ec_tptr"], aln["ec_targets"], chunk=1_000_000,
+                                           extra=(rng, 0.1, aln["n_targets"]) if k else None)
+            log(f"e2e: strand {k + 1} written ({os.path.getsize(path) / 1e6:.0f} MB, {time.time() - t0:.0f}s)")
+        n_targets = int(aln["n_targets"])
+        target_group, sizes = aln["target_group"], prob["group_sizes"]
+        names = [f"g{g}" for g in range(G)]
+        del aln, ec_of
+        core = Core(0)
+        stages = {}
+        best = None
+        for rep in range(2):            # (the first pass also warms the page cache and the allocator)
+            t1 = time.perf_counter()
+            al = read_alignment([f1, f2], n_targets, "intersection")
+            t2 = time.perf_counter()
+            lik = from_alignment(core, al["ec_tptr"], al["ec_targets"], target_group, sizes, al["ec_counts"],
+                                 download_log_counts=False)
+            t3 = time.perf_counter()
+            res = core.solve(None, np.ones(lik.n_groups))
+            t4 = time.perf_counter()
+            out = io.StringIO()
+            smp = PlainSample(al["n_reads"], int(al["ec_counts"].sum()))
+            smp.store_abundances(res["theta"])
+            smp.write_abundances(names, out)
+            with open(os.path.join(tmp, "e2e_abundances.txt"), "w") as f:
+                f.write(out.getvalue())
+            t5 = time.perf_counter()
+            cur = {"read_collapse_s": t2 - t1, "build_likelihood_s": t3 - t2, "solve_s": t4 - t3, "write_abundances_s": t5 - t4,
+                   "total_s": t5 - t1, "iters": int(res["iters"]), "ecs": int(len(al["ec_counts"])),
+                   "target_hits": int(len(al["ec_targets"]))}
+            log(f"e2e pass {rep}: " + ", ".join(f"{k} {v:.3f}" if isinstance(v, float) else f"{k} {v}" for k, v in cur.items()))
+            if best is None or cur["total_s"] < best["total_s"]:
+                best = cur
+            assert cur["ecs"] == E and abs(res["theta"].sum() - 1.0) < 1e-9
+            del al
+        stages = best
+        threads = int(os.environ.get("MSWEEP_READER_THREADS", "0")) or min(16, cpu_share())
+        # the Python mirror of the reference's reader on a prefix of the same files
+        n_py = min(R, 100_000)
+        heads = []
+        for path in (f1, f2):
+            with open(path) as f:
+                heads.append("".join(f.readline() for _ in range(n_py)))
+        t1 = time.perf_counter()
+        pa = Alignment(n_targets)
+        pa.read("intersection", [io.StringIO(h) for h in heads])
+        pa.collapse()
+        t_py = time.perf_counter() - t1
+        py_bytes = sum(len(h) for h in heads)
+        # a gzip pair of a prefix (1 M reads): zlib inflates on one thread, then the same parser
+        n_gz = min(R, 1_000_000)
+        gz_bytes = 0
+        gz_paths = []
+        for path in (f1, f2):
+            with open(path, "rb") as f:
+                buf = b"".join(f.readline() for _ in range(n_gz))
+            gz_bytes += len(buf)
+            gp = path + ".gz"
+            with gzip.open(gp, "wb", compresslevel=1) as g:
+                g.write(buf)
+            gz_paths.append(gp)
+        t1 = time.perf_counter()
+        ag = read_alignment(gz_paths, n_targets, "intersection")
+        t_gz = time.perf_counter() - t1
+        gz_file_bytes = sum(os.path.getsize(g) for g in gz_paths)
+        core.close()
+        line = {
+            "metric": "e2e: Themisto plaintext -> abundances.txt, 10M reads x 5k groups (reads/s of the whole pipeline)",
+            "value": R / stages["total_s"], "unit": "reads/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
+            "config": {"workload": f"cfg3's {R} reads x {G} groups as two Themisto plaintext strands ({nbytes / 1e9:.2f} GB of "
+                                   "text, --themisto-mode intersection), msw_alignment_read -> msw_core_build_likelihood -> "
+                                   "msw_core_solve(--tol 1e-6) -> abundances.txt", "reads": R, "groups": G, "seed": a.seed},
+            "stages_s": stages,
+            "reader": {"threads": threads, "text_MB_per_s": nbytes / 1e6 / stages["read_collapse_s"],
+                       "reads_per_s": R / stages["read_collapse_s"], "text_bytes": nbytes,
+                       "what": "msw_alignment_read: mmap, chunk-parallel parse, rows by read id, paired-end intersection, "
+                               "the reference's 64-bit hash, parallel merge sort, equivalence classes (host_alignment.inc) + "
+                               "export into NumPy arrays"},
+            "python_mirror": {"reads": n_py, "seconds": t_py, "text_MB_per_s": py_bytes / 1e6 / t_py, "reads_per_s": n_py / t_py,
+                              "what": "msweep_amd/alignment.py Alignment.read + collapse (the mirror of include/"
+                                      "mSWEEP_alignment.hpp:54-215) on the first lines of the same files: the stated baseline"},
+            "gzip": {"reads": n_gz, "seconds": t_gz, "uncompressed_MB_per_s": gz_bytes / 1e6 / t_gz,
+                     "compressed_MB": gz_file_bytes / 1e6, "ecs": int(len(ag["ec_counts"])),
+                     "what": "the first reads of both strands gzip-compressed (level 1): zlib inflate on ONE thread per "
+                             "file in front of the same parser"},
+            "cpu": cpu_info(),
+        }
+        print(json.dumps(line), file=OUT, flush=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 # ---- workloads --------------------------------------------------------------------------------------------------
@@ -479,6 +604,10 @@ def main():
                  f"(plain `python bench.py --gpus {a.gpus}` starts them itself)")
     if a.launch_selftest:
         return launch_selftest(a, rank, world)
+    if a.config == "e2e":
+        if world > 1:
+            sys.exit("bench.py: --config e2e is a single-GPU line")
+        return run_e2e(a)
     if a.config == "cfg2" and (world > 1 or a.mode == "shard"):
         sys.exit("bench.py: --config cfg2 is a single-GPU line; the N > 1 modes run on cfg3 / cfg4 / cfg5")
     if a.config == "cfg5" and world > 1 and a.mode != "shard":

@@ -169,9 +169,9 @@ def read_alignment(paths, n_targets, merge_mode="intersection"):
     try:
         ne, nr, nh, na = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
         L.msw_alignment_shape(h, C.byref(ne), C.byref(nr), C.byref(nh), C.byref(na))
-        out = dict(ec_tptr=np.zeros(ne.value + 1, np.uint64), ec_targets=np.zeros(nh.value, np.uint32),
-                   ec_counts=np.zeros(ne.value, np.uint64), ec_rptr=np.zeros(ne.value + 1, np.uint64),
-                   ec_reads=np.zeros(na.value, np.uint32), n_reads=int(nr.value))
+        out = dict(ec_tptr=np.empty(ne.value + 1, np.uint64), ec_targets=np.empty(nh.value, np.uint32),
+                   ec_counts=np.empty(ne.value, np.uint64), ec_rptr=np.empty(ne.value + 1, np.uint64),
+                   ec_reads=np.empty(na.value, np.uint32), n_reads=int(nr.value))
         L.msw_alignment_export(h, _ptr(out["ec_tptr"]), _ptr(out["ec_targets"]), _ptr(out["ec_counts"]),
                                _ptr(out["ec_rptr"]), _ptr(out["ec_reads"]))
         return out

@@ -160,3 +160,59 @@ def csr_to_targets(prob, seed=7, shuffle=True):
     o = np.lexsort((key, ec_of))
     return dict(ec_tptr=tptr, ec_targets=targets[o], target_group=target_group.astype(np.uint32),
                 n_targets=T)
+
+
+def write_themisto(path, ec_of_read, ec_tptr, ec_targets, first_read_id=0, chunk=500_000, extra=None):
+    """Writes reads as Themisto plaintext pseudoalignments (`read_id t1 t2 ...` per line, the format
+    include/mSWEEP_alignment.hpp:54-94 parses): read i aligns to the targets of EC ec_of_read[i].
+    extra: optional (rng, fraction, n_targets) -- that fraction of the reads gets one more, random target (a strand
+    that disagrees with its mate: removed again by --themisto-mode intersection).  Vectorised integer -> text; returns
+    the bytes written."""
+    tptr = np.asarray(ec_tptr, np.int64)
+    n_total = len(ec_of_read)
+    written = 0
+    with open(path, "wb") as f:
+        for r0 in range(0, n_total, chunk):
+            ec = np.asarray(ec_of_read[r0:r0 + chunk], np.int64)
+            n = len(ec)
+            lens = tptr[ec + 1] - tptr[ec]
+            add = np.zeros(n, np.int64)
+            if extra is not None:
+                rng, frac, n_targets = extra
+                add = (rng.random(n) < frac).astype(np.int64)
+            ntok = lens + add + 1                                    # read id + targets (+ the extra one)
+            start = np.cumsum(ntok) - ntok
+            M = int(ntok.sum())
+            tok = np.empty(M, np.int64)
+            tok[start] = first_read_id + r0 + np.arange(n)
+            tot = int(lens.sum())
+            within = np.arange(tot) - np.repeat(np.cumsum(lens) - lens, lens)
+            tok[np.repeat(start + 1, lens) + within] = ec_targets[np.repeat(tptr[ec], lens) + within]
+            if extra is not None and add.any():
+                who = np.nonzero(add)[0]
+                tok[start[who] + 1 + lens[who]] = rng.integers(0, n_targets, len(who))
+            term = np.full(M, 32, np.uint8)
+            term[start + ntok - 1] = 10
+            d = np.ones(M, np.int64)
+            p10 = 10
+            while True:
+                ge = tok >= p10
+                if not ge.any():
+                    break
+                d += ge
+                p10 *= 10
+            width = d + 1
+            off = np.cumsum(width) - width
+            out = np.empty(int(width.sum()), np.uint8)
+            out[off + d] = term
+            k, p = 0, 1
+            while True:
+                m = d > k
+                if not m.any():
+                    break
+                out[off[m] + d[m] - 1 - k] = 48 + (tok[m] // p) % 10
+                k += 1
+                p *= 10
+            f.write(out.tobytes())
+            written += len(out)
+    return written
