@@ -339,7 +339,9 @@ def run_e2e(a):
             log(f"e2e pass {rep}: " + ", ".join(f"{k} {v:.3f}" if isinstance(v, float) else f"{k} {v}" for k, v in cur.items()))
             if best is None or cur["total_s"] < best["total_s"]:
                 best = cur
-            assert cur["ecs"] == E and abs(res["theta"].sum() - 1.0) < 1e-9
+            # (a few ECs fewer than the generator made: the reference keys reads by a 64-bit XOR-shift hash of their
+            # target set alone and merges what collides -- include/mSWEEP_alignment.hpp:152-156,186 -- as this reader does)
+            assert E - 64 <= cur["ecs"] <= E and abs(res["theta"].sum() - 1.0) < 1e-9
             del al
         stages = best
         threads = int(os.environ.get("MSWEEP_READER_THREADS", "0")) or min(16, cpu_share())
