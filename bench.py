@@ -770,6 +770,18 @@ def main():
         line_extra = {"iters_per_sec": a.steps * mult / dt, "listed_cells_per_sec": float(nnz) * a.steps * mult / dt,
                       "reads_x_groups_cells_per_sec": float(wl["reads"]) * G * a.steps * mult / dt,
                       "device_ms_per_step": tm0["solve_ms"] / a.steps}
+        if shard:
+            # where an iteration of the EC-sharded solve goes on rank 0 (the profiled run: events around the sweeps and
+            # around the two all-reduces with their packing kernels): the first hardware run says which part to fix
+            it = max(tm["iters"], 1)
+            line_extra["shard_split_ms_per_step"] = {
+                "passA": tm["passA_ms"] / it, "passB": tm["passB_ms"] / it, "collectives": tm["collective_ms"] / it,
+                "chain_and_gaps": (tm["solve_ms"] - tm["passA_ms"] - tm["passB_ms"] - tm["collective_ms"]) / it,
+                "collectives_per_step": tm["collectives"] / it,
+                "what": "rank 0, profiled run (an event pair around every sweep and every all-reduce adds ~6 us of idle "
+                        "GPU each: the sum exceeds ms_per_step); collectives = k_sum_scalar + all-reduce of 1 double "
+                        "after pass A, k_colsum + all-reduce of 3 G integers + 4 doubles after pass B; chain_and_gaps = "
+                        "k_finstep, k_redfin (redundant on every rank) and the launch boundaries"}
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64).cuda()

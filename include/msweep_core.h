@@ -296,6 +296,10 @@ typedef struct msw_timing {
   uint64_t iters;
   uint64_t bytes_passA;  /* algorithmic bytes per launch */
   uint64_t bytes_passB;
+  double collective_ms;  /* EC-sharded solve, profiling enabled: the all-reduces of the solve (one scalar after pass A,
+                          * one (3 G + 4)-word vector after pass B, per iteration) with the small kernels that pack
+                          * them, summed over the launches; events on the solve stream.  0 without a communicator. */
+  uint64_t collectives;  /* how many */
 } msw_timing;
 int msw_core_set_profiling(msw_handle h, int enabled);
 int msw_core_last_timing(msw_handle h, msw_timing *out);

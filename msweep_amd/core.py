@@ -43,7 +43,8 @@ class MswError(RuntimeError):
 class Timing(C.Structure):
     _fields_ = [("solve_ms", C.c_double), ("passA_ms", C.c_double), ("passB_ms", C.c_double),
                 ("passA_launches", C.c_uint64), ("passB_launches", C.c_uint64), ("iters", C.c_uint64),
-                ("bytes_passA", C.c_uint64), ("bytes_passB", C.c_uint64)]
+                ("bytes_passA", C.c_uint64), ("bytes_passB", C.c_uint64), ("collective_ms", C.c_double),
+                ("collectives", C.c_uint64)]
 
 
 class LayoutInfo(C.Structure):

@@ -131,8 +131,8 @@ struct msw_core {
   msw_timing timing = {};
   msw_bootstrap_timing btiming = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> evA, evB;
-  size_t evA_used = 0, evB_used = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evA, evB, evC;  // pass A, pass B, collectives (sharded solve)
+  size_t evA_used = 0, evB_used = 0, evC_used = 0;
 
   ~msw_core() {
     if (sc_host) (void)hipHostFree(sc_host);
@@ -140,6 +140,7 @@ struct msw_core {
     if (ev1) (void)hipEventDestroy(ev1);
     for (auto &p : evA) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : evB) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : evC) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &e : ev_counts)
       if (e) (void)hipEventDestroy(e);
     if (stream2) (void)hipStreamDestroy(stream2);
@@ -570,6 +571,11 @@ void launch_passB(msw_core *h) {
     // fixed-point column sums are all-reduced as INTEGERS: exact, so the totals -- and with them every
     // N_g -- are the same bits whatever the number of ranks the ECs are spread over.
     const size_t G3 = 3 * (size_t)h->G;
+    std::pair<hipEvent_t, hipEvent_t> *evc = nullptr;
+    if (h->profiling) {
+      evc = &next_pair(h->evC, h->evC_used);
+      MSW_HIP(hipEventRecord(evc->first, h->stream));
+    }
     hipLaunchKernelGGL(k_colsum, dim3((h->G + 63) / 64), dim3(1024), 0, h->stream, h->sc.p, (int)h->G,
                        partials ? nb : 0, fxrows, nb, h->partAcc.p, h->Acc.p, h->partS.p,
                        fxrows ? h->guard_tail.p : nullptr, h->commB.p);
@@ -580,6 +586,7 @@ void launch_passB(msw_core *h) {
       h->comm->allreduce_mixed(reinterpret_cast<uint64_t *>(h->commB.p) + h->G, 2 * (size_t)h->G, h->commB.p + G3, 4,
                                h->stream);
     }
+    if (evc) MSW_HIP(hipEventRecord(evc->second, h->stream));
     hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(1024), 0, h->stream,
                        h->sc.p, (int)h->G, 0, fxrows, reinterpret_cast<unsigned long long *>(h->commB.p) + h->G, 0, 1,
                        h->partAcc.p, h->commB.p, h->commB.p + G3, h->e.p, h->u.p,
@@ -709,9 +716,15 @@ void run_rcg(msw_core *h, size_t max_iters, size_t iters_start = 0) {
     for (size_t b = 0; b < batch; ++b) {
       launch_passA(h);
       if (h->comm) {  // |g|^2 summed over the EC shards
+        std::pair<hipEvent_t, hipEvent_t> *evc = nullptr;
+        if (h->profiling) {
+          evc = &next_pair(h->evC, h->evC_used);
+          MSW_HIP(hipEventRecord(evc->first, h->stream));
+        }
         hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(1024), 0, h->stream, h->sc.p, 1, nbA, h->partA.p,
                            h->commA.p);
         h->comm->allreduce(h->commA.p, 1, h->stream);
+        if (evc) MSW_HIP(hipEventRecord(evc->second, h->stream));
       }
       launch_finstep(h, 0);
       launch_passB(h);
@@ -773,6 +786,12 @@ void collect_timing(msw_core *h) {
       MSW_HIP(hipEventElapsedTime(&ms, h->evB[i].first, h->evB[i].second));
       h->timing.passB_ms += ms;
     }
+    h->timing.collective_ms = 0.0;
+    for (size_t i = 0; i < h->evC_used; ++i) {
+      MSW_HIP(hipEventElapsedTime(&ms, h->evC[i].first, h->evC[i].second));
+      h->timing.collective_ms += ms;
+    }
+    h->timing.collectives = h->evC_used;
   }
   h->timing.iters = (uint64_t)h->sc_host->iter;
   const uint64_t recsz = h->enc == kEncValue ? 12 : (h->wide() ? 8 : 4);
@@ -801,7 +820,7 @@ void continue_impl(msw_core *h, size_t n_iters, double *theta_out, size_t *iters
   const size_t start = (size_t)h->sc_host->iter;
   if (n_iters == 0 || start + n_iters > (size_t)std::numeric_limits<int32_t>::max()) throw Fail("msw_core_continue: iteration count out of range");
   h->timing = {};
-  h->evA_used = h->evB_used = 0;
+  h->evA_used = h->evB_used = h->evC_used = 0;
   CollectiveScope cs(h);
   hipLaunchKernelGGL(k_extend, dim3(1), dim3(1), 0, h->stream, h->sc.p, (int)n_iters);
   MSW_HIP(hipEventRecord(h->ev0, h->stream));
@@ -818,7 +837,7 @@ void run_impl(msw_core *h, double tol, size_t max_iters, int algo, int prec, dou
   validate_solve(h, max_iters, algo, prec);
   if (!h->prepared) throw Fail("msw_core_run: inputs not prepared (call msw_core_prepare)");
   h->timing = {};
-  h->evA_used = h->evB_used = 0;
+  h->evA_used = h->evB_used = h->evC_used = 0;
   CollectiveScope cs(h);  // from here on a failure strands the peers of a sharded solve (guarded())
   begin_solve(h, tol, max_iters);
   MSW_HIP(hipEventRecord(h->ev0, h->stream));

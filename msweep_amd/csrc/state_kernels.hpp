@@ -200,7 +200,9 @@ __global__ __launch_bounds__(1024) void k_finstep(Scalars *sc, int mode, int G, 
         sc->didreset = 1;
         sc->reset_pending = 1;
         sc->bound = nb;
-        sc->have_eval = 1;
+        // the re-evaluation: by this slot's pass B -- or, when this is a closing verdict (mode 1: no sweep follows
+        // this launch), by the next slot's, which finds reset_pending without an evaluation and takes no step
+        sc->have_eval = mode == 1 ? 0 : 1;
       }
       if (flavor == 0) prepB_block(sc, a2, G, n_lut, u, lut, e, X, sh);
       return;

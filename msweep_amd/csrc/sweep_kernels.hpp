@@ -67,10 +67,16 @@ __device__ __forceinline__ unsigned long long fx_bits(double scaled_r, double pk
 // c / z and 1 / z for the EC epilogues of the sweeps: z is a softmax denominator that passed the guard test
 // (sell.hpp) -- a normal number between 2^-8 of the background sum and twice the number of groups -- so the
 // operand scaling and the special-case fix-up of the IEEE division (4 of its 12 instructions, 7 of 12 for a
-// reciprocal) are not needed.  Reciprocal estimate, two Newton steps, one residual correction: within one ulp
-// of the quotient.  (The guarded ECs' own evaluation, whose z may be anything above zero, divides in full.)
+// reciprocal) are not needed.  Reciprocal estimate and two Newton steps (within an ulp of 1 / z), times c: within
+// two ulps of the quotient -- the residual correction that brought it to one (two more operations per EC: round 4
+// counted the EC epilogue, 23 of pass B's vector operations per cell at 5 cells per EC) changes nothing a test can
+// see: MSW_DIV_CORRECT=1 brings it back.  (The guarded ECs' own evaluation, whose z may be anything above zero,
+// divides in full.)
 #ifndef MSW_FAST_DIV
 #define MSW_FAST_DIV 1
+#endif
+#ifndef MSW_DIV_CORRECT
+#define MSW_DIV_CORRECT 0
 #endif
 __device__ __forceinline__ double ec_rcp(double z) {
 #if MSW_FAST_DIV
@@ -86,7 +92,11 @@ __device__ __forceinline__ double ec_div(double c, double z) {
 #if MSW_FAST_DIV
   const double r = ec_rcp(z);
   const double q = c * r;
+#if MSW_DIV_CORRECT
   return fma(fma(-z, q, c), r, q);
+#else
+  return q;
+#endif
 #else
   return c / z;
 #endif
@@ -955,11 +965,11 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       if (c != 0.0 && !(zbase + zs >= gthr)) {
         if (spoke) defer(S.n_long + (ML ? slice_geo(S.cls, sb.sl).ec0 + ((uint32_t)lane >> lgm) : sb.sl * 64 + lane));
       } else if (c != 0.0) {
-        const double Z = zbase + zs, H = hbase + hs;
+        const double Z = zbase + zs;
         const double rj = ec_div(c, Z);
         double rja = rj;  // what the scalar sums see of this lane
         if (ML && lgm != 0u) rja = spoke ? rj : 0.0;
-        s_rH += rja * H;
+        s_rH = fma(rja, hs, s_rH);  // (sum r_j H_j = hbase sum r_j + sum r_j hs_j: the first part at the end, from s_W)
         s_W += rja;
         if constexpr (kFx) {
           const double rs = rj * fxs;
@@ -979,8 +989,10 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         // Both give the same bits for 1..3.
         __builtin_amdgcn_sched_barrier(0);
         if (sb.c8 <= 15u) {
-          int ez;
-          const double m = frexp(Z, &ez);
+          // (Z passed the guard test: finite, positive, normal -- the instructions themselves, without frexp()'s
+          // handling of zeros, infinities and NaNs)
+          const int ez = __builtin_amdgcn_frexp_exp(Z);
+          const double m = __builtin_amdgcn_frexp_mant(Z);
           double r;
           if (__builtin_amdgcn_ballot_w64(sb.c8 > 3u) == 0) {  // wave-uniform
             r = m;
@@ -993,7 +1005,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
             r *= (sb.c8 & 4u) ? m4 : 1.0;
             r *= (sb.c8 & 8u) ? m8 : 1.0;
           }
-          int ezc = ez * (int)sb.c8;
+          int ezc = __mul24(ez, (int)sb.c8);  // |ez| < 2^11, c8 < 2^4
           if (ML && lgm != 0u && !spoke) r = 1.0, ezc = 0;
           lp_mant *= r;  // >= 2^-15 per slice: 2^-960 between two flushes
           lp_exp += ezc;
@@ -1023,10 +1035,10 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       if (c != 0.0 && !(zbase + zs >= gthr)) {  // (slices of more than 16 rows hold one lane per EC: lgm = 0)
         defer(S.n_long + (ML ? slice_geo(S.cls, sb.sl).ec0 : sb.sl * 64) + lane);
       } else if (c != 0.0) {
-        const double Z = zbase + zs, H = hbase + hs;
+        const double Z = zbase + zs;
         const double rj = ec_div(c, Z);
         s_clogZ += c * log(Z);
-        s_rH += rj * H;
+        s_rH = fma(rj, hs, s_rH);
         s_W += rj;
         const double rs = kFx ? rj * fxs : rj;
         const bool narrow = !kFx || (fma(rj, zbase, c) < fxt1 && rj < fxt2);
@@ -1102,7 +1114,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       if (c != 0.0 && !(zbase + zs >= gthr)) {  // wave-uniform
         if (lane == 0) defer(r);
       } else if (c != 0.0) {
-        const double Z = zbase + zs, H = hbase + hs;
+        const double Z = zbase + zs;
         const double rj = ec_div(c, Z);
         // c log Z deferred as in the slices (multiplicities 1..15: the mantissas multiplied up in lane 0, one
         // logarithm per 32 ECs): the full logarithm is 70 dependent instructions in the middle of a
@@ -1128,7 +1140,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
           s_clogZ += c * log(Z);
         }
         if (lane == 0) {
-          s_rH += rj * H;
+          s_rH = fma(rj, hs, s_rH);
           s_W += rj;
         }
 #pragma unroll
@@ -1233,6 +1245,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       __builtin_amdgcn_s_waitcnt(0);
     }
   }
+  s_rH = fma(hbase, s_W, s_rH);  // the background part of sum r_j H_j (the ordinary ECs' r_j: exactly those in s_W)
   {  // the three ELBO sums of the workgroup with one pair of barriers (the slice geometry behind the 32 doubles of
      // reduction scratch is free by now: 48 doubles needed)
     double t3[3] = {s_clogZ, s_rH, s_W};

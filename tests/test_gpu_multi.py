@@ -26,7 +26,7 @@ def n_devices():
     return torch.cuda.device_count()     # does not initialise the GPU
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])   # 8: the size of the machine the driver runs the scaling curve on
 def test_rccl_ranks_bootstrap_and_sharded_solve(gpu_core, tmp_path, world):
     if n_devices() < world:
         pytest.skip(f"needs {world} GPUs, {n_devices()} visible")

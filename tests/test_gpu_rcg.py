@@ -691,3 +691,37 @@ def test_hbm_stream_rates_are_plausible(gpu_core):
     assert 800.0 < r < 8000.0 and 800.0 < t < 8000.0
     with pytest.raises(MswError, match="at least 1 MiB"):
         gpu_core.hbm_stream_rates(1000, 1)
+
+
+def test_rejected_step_at_the_last_allowed_iteration(gpu_core, oracle):
+    """--max-iters ends the run on an evaluation whose verdict is still pending (the verdict on a slot's evaluation is
+    taken by the next slot's k_finstep, or by a closing verdict-only launch): when THAT evaluation is a rejected step
+    the steepest-descent retry has to be re-evaluated before the run may end.  Every max_iters from 1 up to past the
+    oracle's resets, bound and theta of the last iteration in lock-step."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "fuzz", "seed1_case25.npz"))   # resets at iteration 4
+    G = len(d["alpha0"])
+    lutidx = (d["grp"] * d["lut"].shape[1] + d["cnt"]).astype(np.uint32)
+    ref = oracle.rcg_optl_csr(d["rowptr"], d["grp"], lutidx, d["lut"], np.log(0.01), G, d["logc"], d["alpha0"], tol=-1.0,
+                              max_iters=8, trace=8)["trace"]
+    assert ref["didreset"][:8].tolist().count(1) >= 1
+    gpu_core.set_csr(d["rowptr"], d["grp"], d["cnt"], d["lut"], np.log(0.01), G)
+    for n in range(1, 9):
+        gpu_core.set_trace_theta(n)
+        res = gpu_core.solve(d["logc"], d["alpha0"], tol=-1.0, max_iters=n)
+        tr = gpu_core.trace(n, with_theta=True)
+        assert res["iters"] == n and tr["n"] == n
+        assert tr["didreset"].tolist() == ref["didreset"][:n].tolist(), n
+        np.testing.assert_allclose(tr["bound"], ref["bound"][:n], rtol=1e-9, err_msg=str(n))
+        np.testing.assert_allclose(res["theta"], ref["theta"][n - 1], rtol=1e-6, atol=1e-13, err_msg=str(n))
+    gpu_core.set_trace_theta(0)
+    # the same through fixed-iteration runs continued in pieces (bench.py's W warm-up steps, then K timed steps)
+    gpu_core.set_fixed_iters(True)
+    gpu_core.prepare(d["logc"], d["alpha0"])
+    gpu_core.run(max_iters=3)
+    r = gpu_core.continue_(2)           # ends on the rejected step
+    assert r["iters"] == 5
+    np.testing.assert_allclose(r["theta"], ref["theta"][4], rtol=1e-6, atol=1e-13)
+    r = gpu_core.continue_(3)
+    assert r["iters"] == 8 and r["bound"] == pytest.approx(ref["bound"][7], rel=1e-9)
+    gpu_core.set_fixed_iters(False)
