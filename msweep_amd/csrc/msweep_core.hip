@@ -51,6 +51,7 @@ struct msw_core {
   bool glds = true, tlds = true;
   int gmodeB = 1;  // k_passB GMODE (sweep_kernels.hpp)
   uint32_t enc_shift = 0, enc_mask = 0, enc_bhi = 0, enc_bhiA = 0;  // record encoding (sell.hpp)
+  uint32_t enc_shiftH = 0, enc_maskH = 0;               // index records: the rows of a hot segment
   uint32_t n_area = 0;                                  // 16-byte entries of the slot area
   uint32_t n_tab_lds = 0;                               // ... of which the LDS images hold (all, the hot head, none)
   DevBuf<uint8_t> slice_hot;                            // index records: rows of every slice's hot segment
@@ -60,7 +61,7 @@ struct msw_core {
   bool packed_scheduled = false;                        // ... as the resident likelihood was packed
   bool wide() const { return enc == kEncWide; }
   bool hybrid() const { return enc == kEncIndex; }
-  RecDec dec() const { return RecDec{enc_shift, enc_mask, enc_bhi, enc_bhiA}; }
+  RecDec dec() const { return RecDec{enc_shift, enc_mask, enc_bhi, enc_bhiA, enc_shiftH, enc_maskH}; }
   uint32_t long_row = kLongRow;                         // ECs with more cells go one per wavefront (reset_likelihood)
   DevBuf<uint32_t> area_slot;
   DevBuf<double> lut_area;  // lut[area_slot[i]]: what the per-slot tables are built from, in their order
@@ -216,6 +217,8 @@ SellDev sell_view(msw_core *h) {
   S.mask = h->enc_mask;
   S.bhi = h->enc_bhi;
   S.bhiA = h->enc_bhiA;
+  S.shiftH = h->enc_shiftH;
+  S.maskH = h->enc_maskH;
   S.n_tab_lds = h->n_tab_lds;
   S.slice_hot = h->slice_hot.p;
   S.lut_area = h->lut_area.p;
@@ -336,6 +339,12 @@ bool choose_hybrid_layout(msw_core *h) {
   h->enc_shift = eb;
   h->enc_mask = (1u << eb) - 1u;
   h->n_tab_lds = std::min(n_hot, h->n_area);
+  // the rows of a hot segment carry 16 * entry (entry < n_tab_lds): as many bits as the table's LDS image takes
+  uint32_t hb = 4;
+  while ((1ull << hb) < 16ull * std::max<uint32_t>(h->n_tab_lds, 1)) ++hb;
+  if (hb + gb > 32) return false;  // (cannot happen while the table's image and the group vectors share 160 KB of LDS)
+  h->enc_shiftH = hb;
+  h->enc_maskH = (1u << hb) - 1u;
   h->enc_bhi = h->enc_bhiA = sell_bhi(h->n_tab_lds);
   h->gmodeB = passB_mode(h, h->glds, h->n_tab_lds, true);
   return true;

@@ -112,13 +112,16 @@ __device__ __forceinline__ uint32_t pack_entry(const PackEnc &pe, int lane, uint
   if (lane < 0 || j == UINT32_MAX) return pe.canon[idx];
   return pe.rep_base + (j >> 1) * 16 + 2 * (kRPosDev[lane] >> 1) + (j & 1);
 }
+// hot: a row of an index-record slice's hot segment -- the record form with the entry pre-multiplied by 16 (sell.hpp)
 template <int ENC>
-__device__ __forceinline__ void pack_put(uint32_t *dst, size_t slot, const PackEnc &pe, uint32_t g, uint32_t entry) {
+__device__ __forceinline__ void pack_put(uint32_t *dst, size_t slot, const PackEnc &pe, uint32_t g, uint32_t entry,
+                                         bool hot = false) {
   if constexpr (ENC == kEncValue) {
     Rec<ENC>::store(dst, slot, ValRec{8u * g, entry == kPackPad ? pe.tnull : pe.cell_val[entry]});
   } else {
     if (entry == kPackPad) entry = pe.canon[pe.sentinel_slot];
-    reinterpret_cast<typename Rec<ENC>::T *>(dst)[slot] = Rec<ENC>::make(g, entry, pe.dec);
+    if constexpr (ENC == kEncIndex) dst[slot] = hot ? Rec<ENC>::make_h(g, entry, pe.dec) : Rec<ENC>::make(g, entry, pe.dec);
+    else reinterpret_cast<typename Rec<ENC>::T *>(dst)[slot] = Rec<ENC>::make(g, entry, pe.dec);
   }
 }
 
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
           pick_g = cg[lane * kRowW + c];
           pick_e = ce[lane * kRowW + c];
         }
-        pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, pick_g, pick_e);
+        pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, pick_g, pick_e, ENC == kEncIndex && !streaming);
       }
       for (uint32_t k = 0; schedule && k < nhot; ++k) {
         for (int w = lane; w < 196; w += 64) reinterpret_cast<uint32_t *>(&bk)[w] = w < 192 ? 0xffffffffu : 0u;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
           }
           __syncthreads();
         }
-        pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, pick_g, pick_e);
+        pack_put<ENC>(rec, base + (size_t)(k0 + k) * 64 + lane, pe, pick_g, pick_e, ENC == kEncIndex && !streaming);
       }
       // the cold segment (index records; nhot = the window's rows otherwise): what is left, in CSR order, then
       // the lane's sentinel

@@ -32,6 +32,10 @@ namespace msw {
 //     segment is worked through and consumed after it).  The split is wave-uniform (one byte per slice,
 //     slice_hot): no per-gather branch.  Slices whose ECs hold more cold cells than kColdRows take every table
 //     entry from memory (nhot = 0), like the streaming slices of more than 16 rows.
+//     The rows of a HOT segment carry their entry pre-multiplied by 16 (round 4): group << shiftH | 16 * entry, shiftH =
+//     bits of the LDS image of the table -- one VALU operation for the slot gather, as with byte-offset records (hot
+//     entries are below n_tab_lds, so this form always fits 32 bits); cold rows, whole-memory slices, streaming slices and
+//     long ECs keep group << shift | entry, whose entry index may need all the bits the group leaves.
 //   value record (12 B, ENC 3): {hi, T} -- the cell's log-likelihood itself instead of a table position, for
 //     matrices whose listed values are (nearly) all different (a dense `logl` with continuous values handed to
 //     msw_core_set_dense_logl: one table slot per cell would cost 16 bytes gathered + 40 bytes rebuilt per cell
@@ -102,6 +106,7 @@ struct SellDev {
   uint32_t n_tab_lds;         // slot-area entries held in LDS (all of them, the hot head of a hybrid area, or 0)
   uint32_t shift, mask, bhi;  // record encoding (narrow: shift / lo mask; all: bhi = LDS byte offset of e_g[0])
   uint32_t bhiA;              // LDS byte offset of pass A's {e, w}[0] (2 * bhi but for index records)
+  uint32_t shiftH, maskH;     // index records, rows of a hot segment: group << shiftH | 16 * entry
   const double *lut_area;     // table value of every slot-area entry (utility kernels: the value of a cell)
   SliceClasses cls;           // slice classes: lanes per EC (above)
 };
@@ -129,6 +134,7 @@ constexpr uint32_t kGeoLgmShift = 11, kGeoNecShift = 14;
 // what a sweep needs to decode a record (SGPRs)
 struct RecDec {
   uint32_t shift, mask, bhi, bhiA;
+  uint32_t shiftH, maskH;  // index records: the hot rows' form
 };
 enum { kEncNarrow = 0, kEncWide = 1, kEncIndex = 2, kEncValue = 3 };
 // A slice has as many rows as its longest EC has cells (until round 3 that was rounded up to an even number: 5 % of
@@ -182,6 +188,12 @@ struct Rec<kEncIndex> {
   static __host__ __device__ __forceinline__ uint32_t t_off(T r, const RecDec &d) { return (r & d.mask) << 4; }
   static __host__ __device__ __forceinline__ uint32_t grp(T r, const RecDec &d) { return r >> d.shift; }
   static __host__ __device__ __forceinline__ T make(uint32_t g, uint32_t entry, const RecDec &d) { return (g << d.shift) | entry; }
+  // the rows of a hot segment (file header): entry pre-multiplied by 16
+  static __device__ __forceinline__ uint32_t e_off_h(T r, const RecDec &d) { return ((r >> d.shiftH) << 3) + d.bhi; }
+  static __device__ __forceinline__ uint32_t ew_off_h(T r, const RecDec &d) { return ((r >> d.shiftH) << 4) + d.bhiA; }
+  static __host__ __device__ __forceinline__ uint32_t t_off_h(T r, const RecDec &d) { return r & d.maskH; }
+  static __host__ __device__ __forceinline__ uint32_t grp_h(T r, const RecDec &d) { return r >> d.shiftH; }
+  static __host__ __device__ __forceinline__ T make_h(uint32_t g, uint32_t entry, const RecDec &d) { return (g << d.shiftH) | (entry << 4); }
 };
 template <>
 struct Rec<kEncValue> {
@@ -199,29 +211,54 @@ struct Rec<kEncValue> {
   static __device__ __forceinline__ uint32_t ew_off(T r, const RecDec &) { return r.hi << 1; }
   static __host__ __device__ __forceinline__ uint32_t grp(T r, const RecDec &) { return r.hi >> 3; }
 };
+// the three byte offsets of a record; HOT = a row of an index-record slice's hot segment (every other encoding and
+// row: one form)
+template <int ENC, bool HOT>
+__device__ __forceinline__ uint32_t rec_e_off(typename Rec<ENC>::T r, const RecDec &d) {
+  if constexpr (ENC == kEncIndex && HOT) return Rec<ENC>::e_off_h(r, d);
+  else return Rec<ENC>::e_off(r, d);
+}
+template <int ENC, bool HOT>
+__device__ __forceinline__ uint32_t rec_ew_off(typename Rec<ENC>::T r, const RecDec &d) {
+  if constexpr (ENC == kEncIndex && HOT) return Rec<ENC>::ew_off_h(r, d);
+  else return Rec<ENC>::ew_off(r, d);
+}
+template <int ENC, bool HOT>
+__device__ __forceinline__ uint32_t rec_t_off(typename Rec<ENC>::T r, const RecDec &d) {
+  if constexpr (ENC == kEncIndex && HOT) return Rec<ENC>::t_off_h(r, d);
+  else if constexpr (ENC == kEncValue) return 0u;
+  else return Rec<ENC>::t_off(r, d);
+}
 // dwords of a record array of n cells
 __host__ __device__ inline size_t rec_words(int enc, size_t n) {
   return enc == kEncValue ? ((n + 63) / 64) * kValRowWords : (enc == kEncWide ? 2 * n : n);
 }
-__host__ __device__ inline RecDec rec_dec(const SellDev &S) { return RecDec{S.shift, S.mask, S.bhi, S.bhiA}; }
-// the log-likelihood of a record's cell (utility kernels)
+__host__ __device__ inline RecDec rec_dec(const SellDev &S) { return RecDec{S.shift, S.mask, S.bhi, S.bhiA, S.shiftH, S.maskH}; }
+// is row k of slice s a row of a hot segment (index records: the other record form)?
 template <int ENC>
-__device__ __forceinline__ double rec_value(const SellDev &S, typename Rec<ENC>::T r) {
+__device__ __forceinline__ bool rec_row_hot(const SellDev &S, uint32_t s, uint32_t k) {
+  if constexpr (ENC == kEncIndex) return k < (uint32_t)S.slice_hot[s];
+  else return false;
+}
+// group id / slot-area entry / log-likelihood of a record (utility kernels; the sweeps never form them)
+template <int ENC>
+__device__ __forceinline__ uint32_t rec_grp(const SellDev &S, typename Rec<ENC>::T r, bool hot = false) {
+  if constexpr (ENC == kEncIndex) return hot ? Rec<ENC>::grp_h(r, rec_dec(S)) : Rec<ENC>::grp(r, rec_dec(S));
+  else return Rec<ENC>::grp(r, rec_dec(S));
+}
+template <int ENC>
+__device__ __forceinline__ uint32_t rec_entry(const SellDev &S, typename Rec<ENC>::T r, bool hot = false) {
+  if constexpr (ENC == kEncIndex) return (hot ? Rec<ENC>::t_off_h(r, rec_dec(S)) : Rec<ENC>::t_off(r, rec_dec(S))) >> 4;
+  else return Rec<ENC>::t_off(r, rec_dec(S)) >> 4;
+}
+template <int ENC>
+__device__ __forceinline__ double rec_value(const SellDev &S, typename Rec<ENC>::T r, bool hot = false) {
   if constexpr (ENC == kEncValue) return r.t;
-  else return S.lut_area[Rec<ENC>::t_off(r, rec_dec(S)) >> 4];
-}
-// group id / LUT slot of a record (utility kernels; the sweeps never form them)
-template <int ENC>
-__device__ __forceinline__ uint32_t rec_grp(const SellDev &S, typename Rec<ENC>::T r) {
-  return Rec<ENC>::grp(r, rec_dec(S));
+  else return S.lut_area[rec_entry<ENC>(S, r, hot)];
 }
 template <int ENC>
-__device__ __forceinline__ uint32_t rec_entry(const SellDev &S, typename Rec<ENC>::T r) {
-  return Rec<ENC>::t_off(r, rec_dec(S)) >> 4;
-}
-template <int ENC>
-__device__ __forceinline__ uint32_t rec_idx(const SellDev &S, typename Rec<ENC>::T r) {
-  return S.area_slot[rec_entry<ENC>(S, r)];
+__device__ __forceinline__ uint32_t rec_idx(const SellDev &S, typename Rec<ENC>::T r, bool hot = false) {
+  return S.area_slot[rec_entry<ENC>(S, r, hot)];
 }
 
 // Visit the cells of the EC at permuted position p (utility kernels only): f(group id, log-likelihood).
@@ -238,10 +275,11 @@ __device__ __forceinline__ void for_each_cell(const SellDev &S, uint32_t p, F f)
     slice_of_position(S.cls, p - S.n_long, s, lgm, l0);
     const uint32_t o0 = S.slice_off[s], len = S.slice_off[s + 1] - o0;
     for (uint32_t k = 0; k < len; ++k) {
+      const bool hot = rec_row_hot<ENC>(S, s, k);
       for (uint32_t t = 0; t < (1u << lgm); ++t) {
         const typename R::T r = R::load(S.rec, ((size_t)o0 + k) * 64 + l0 + t);
-        const uint32_t g = rec_grp<ENC>(S, r);
-        if (g < S.n_groups) f(g, rec_value<ENC>(S, r));
+        const uint32_t g = rec_grp<ENC>(S, r, hot);
+        if (g < S.n_groups) f(g, rec_value<ENC>(S, r, hot));
       }
     }
   }
@@ -265,8 +303,9 @@ __device__ __forceinline__ void wave_cells(const SellDev &S, uint32_t p, uint32_
     // a lane per (row, sub-lane) of the EC
     for (uint32_t i = lane; i < (len << lgm); i += 64) {
       const typename R::T r = R::load(S.rec, ((size_t)o0 + (i >> lgm)) * 64 + l0 + (i & ((1u << lgm) - 1u)));
-      const uint32_t g = rec_grp<ENC>(S, r);
-      if (g < S.n_groups) f(g, rec_value<ENC>(S, r));
+      const bool hot = rec_row_hot<ENC>(S, s, i >> lgm);
+      const uint32_t g = rec_grp<ENC>(S, r, hot);
+      if (g < S.n_groups) f(g, rec_value<ENC>(S, r, hot));
     }
   }
 }

@@ -145,10 +145,11 @@ __device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uin
 // index records: rows [0, nhot) into r, the cold rows [nhot, len) -- at most kColdRows, or the packer has set
 // nhot = 0 and the whole slice is taken from memory -- into rc
 __device__ __forceinline__ void load_slice_split(const uint32_t *rec, size_t base, uint32_t len, uint32_t nhot,
-                                                 uint32_t (&r)[kRegCells], uint32_t (&rc)[kColdRows], uint32_t nullr) {
+                                                 uint32_t (&r)[kRegCells], uint32_t (&rc)[kColdRows], uint32_t nullr,
+                                                 uint32_t nullr_hot) {
   const uint32_t ncold = len - nhot;
   if (ncold <= (uint32_t)kColdRows) {
-    load_slice<kEncIndex>(rec, base, nhot, r, nullr);
+    load_slice<kEncIndex>(rec, base, nhot, r, nullr_hot);  // (the rows of a hot segment: the hot record form, sell.hpp)
 #pragma unroll
     for (int j = 0; j < kColdRows; ++j)
       if ((uint32_t)j < ncold) rc[j] = rec[base + (size_t)(nhot + j) * 64];
@@ -200,6 +201,7 @@ struct SliceStream {
   uint32_t s_first, nw, n_mine, lane;
   uint32_t geo;  // LDS byte offset of this wave's 64 (+2 dummy) {slice_off[s], slice_off[s+1]} pairs
   typename Rec<ENC>::T nullr = {};  // the lane's null record (the missing last row of an odd slice: load_slice)
+  typename Rec<ENC>::T nullr_hot = {};  // ... in the form of a hot segment's rows (index records)
   uint2 pend = make_uint2(0, 0);
   __device__ __forceinline__ SliceStream(const SellDev &S_, uint32_t first, uint32_t nw_, uint32_t lane_,
                                          uint32_t geo_)
@@ -251,7 +253,7 @@ struct SliceStream {
       const uint32_t ox = uniform(oe.x);
       b.o = ox & ((1u << kGeoHotShift) - 1u);
       b.nhot = ox >> kGeoHotShift;
-      if (b.len <= (uint32_t)kRegCells) load_slice_split(S.rec, (size_t)b.o * 64 + lane, b.len, b.nhot, b.r, b.rc, nullr);
+      if (b.len <= (uint32_t)kRegCells) load_slice_split(S.rec, (size_t)b.o * 64 + lane, b.len, b.nhot, b.r, b.rc, nullr, nullr_hot);
     } else {
       b.o = uniform(oe.x);
       if (b.len <= (uint32_t)kRegCells) load_slice<ENC>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r, nullr);
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   const unsigned char *ew_b = reinterpret_cast<const unsigned char *>(ew_g) - bhiA;
   const unsigned char *xt_b = reinterpret_cast<const unsigned char *>(tabA_g);
   auto EW_ = [&](RT r) -> double2 { return tab16<GLDS>(ew_b, R::ew_off(r, D)); };
+  auto EWh_ = [&](RT r) -> double2 { return tab16<GLDS>(ew_b, rec_ew_off<ENC, true>(r, D)); };  // a hot segment's row
   // the cell's {x, D} = {exp(a (T - tref)), (1 - a)(T - log zi)}: from the slot table, or -- value records -- formed here
   [[maybe_unused]] const double va = uniform_d(sc->a), vtref = uniform_d(sc->tref), vlogzi = uniform_d(sc->logzi);
   [[maybe_unused]] const double voma = 1.0 - va;
@@ -391,9 +394,9 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
     if constexpr (VAL) return make_double2(exp(va * (r.t - vtref)), voma * (r.t - vlogzi));
     else return tab16<TLDS>(xt_b, R::t_off(r, D));
   };
-  auto XT_ = [&](RT r) -> double2 {    // hybrid: hot entries only
+  auto XT_ = [&](RT r) -> double2 {    // hybrid: hot entries only, from a hot segment's row (16 * entry ready-made)
     if constexpr (VAL) return XTg_(r);
-    else return tab16<TL>(xt_b, R::t_off(r, D));
+    else return tab16<TL>(xt_b, rec_t_off<ENC, true>(r, D));
   };
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U;
@@ -417,6 +420,8 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   // sentinel group)
   const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
   stream.nullr = null_rec;
+  if constexpr (HYB) stream.nullr_hot = R::make_h(G + (uint32_t)lane, 0u, D);
+  else stream.nullr_hot = null_rec;
   auto issue = [&](SliceBuf<ENC> &) {};
   auto process = [&](SliceBuf<ENC> &sb) {
     const uint32_t len = sb.len;
@@ -433,9 +438,8 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
 #pragma unroll
         for (int k = 0; k < B; ++k) {
           if (k0 + k < L) {
-            ewv[k] = EW_(b[k0 + k]);
-            if constexpr (decltype(ANY)::value) xtv[k] = XTg_(b[k0 + k]);
-            else xtv[k] = XT_(b[k0 + k]);
+            if constexpr (decltype(ANY)::value) ewv[k] = EW_(b[k0 + k]), xtv[k] = XTg_(b[k0 + k]);
+            else ewv[k] = EWh_(b[k0 + k]), xtv[k] = XT_(b[k0 + k]);
           }
         }
 #pragma unroll
@@ -701,6 +705,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   unsigned char *acc_b = reinterpret_cast<unsigned char *>(accGlobal) - bhi;
   const unsigned char *xt_b = reinterpret_cast<const unsigned char *>(tabB_g);
   auto E_ = [&](RT r) -> double { return tab8<GLDS>(e_b, R::e_off(r, D)); };
+  auto Eh_ = [&](RT r) -> double { return tab8<GLDS>(e_b, rec_e_off<ENC, true>(r, D)); };  // a hot segment's row
   // the cell's {x - p0, x T - p0 log zi}, x = exp(a (T - tref)): from the slot table, or -- value records -- formed here
   [[maybe_unused]] const double va = uniform_d(sc->a), vtref = uniform_d(sc->tref), vlogzi = uniform_d(sc->logzi);
   [[maybe_unused]] const double vp0 = uniform_d(sc->p0), vp0l = vp0 * vlogzi;
@@ -712,20 +717,24 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       return tab16<TLDS>(xt_b, R::t_off(r, D));
     }
   };
-  auto XT_ = [&](RT r) -> double2 {    // hybrid: hot entries only
+  auto XT_ = [&](RT r) -> double2 {    // hybrid: hot entries only, from a hot segment's row (16 * entry ready-made)
     if constexpr (VAL) return XTg_(r);
-    else return tab16<TL>(xt_b, R::t_off(r, D));
+    else return tab16<TL>(xt_b, rec_t_off<ENC, true>(r, D));
   };
   auto XMg_ = [&](RT r) -> double {
     if constexpr (VAL) return exp(va * (r.t - vtref)) - vp0;
     else return tab8<TLDS>(xt_b, R::t_off(r, D));
   };
+  auto XMgh_ = [&](RT r) -> double {   // the same for a hot segment's row
+    if constexpr (VAL) return exp(va * (r.t - vtref)) - vp0;
+    else return tab8<TLDS>(xt_b, rec_t_off<ENC, true>(r, D));
+  };
   typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
   // one column-sum update: v = the value to add (fp64 build), or its fixed-point image (kFx)
-  auto addACC = [&](RT r, auto v) {
+  auto addACCx = [&](RT r, auto v, auto HOT) {
     using V = decltype(v);
     using LT = typename std::conditional<std::is_same<V, double>::value, lds_d_t, lds_u64_t>::type;
-    const uint32_t off = R::e_off(r, D);
+    const uint32_t off = rec_e_off<ENC, decltype(HOT)::value>(r, D);
     if constexpr (GMODE == 2)
       __hip_atomic_fetch_add((LT *)(size_t)(off + kAccFixed), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if constexpr (GMODE == 1)
@@ -745,15 +754,18 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   // (Scalars::xb bounds every table value of the pass), so ONE test per EC covers all its cells.  ECs
   // that fail it -- a large multiplicity over a small Z -- split each addend into two parts of 32 and 51
   // bits (two atomics; sums are modulo 2^64, so the parts need not be added together).
-  auto addFX = [&](RT r, double rs, double pk) { addACC(r, fx_bits(rs, pk)); };
-  auto addFXwide = [&](RT r, double rs, double pk) {
+  auto addACC = [&](RT r, auto v) { addACCx(r, v, std::false_type{}); };
+  auto addFXx = [&](RT r, double rs, double pk, auto HOT) { addACCx(r, fx_bits(rs, pk), HOT); };
+  auto addFXwidex = [&](RT r, double rs, double pk, auto HOT) {
     const double q = rs * pk;
     const double vh = fma(q, 0x1p-32, kFxMagic);
     const double qh = vh - kFxMagic;                       // rint(q / 2^32), exact
     const double ql = fma(-qh, 0x1p32, q);                 // |ql| <= 2^31, exact
-    addACC(r, (unsigned long long)(uint32_t)__double2loint(vh) << 32);
-    addACC(r, fx_bits(1.0, ql));
+    addACCx(r, (unsigned long long)(uint32_t)__double2loint(vh) << 32, HOT);
+    addACCx(r, fx_bits(1.0, ql), HOT);
   };
+  auto addFX = [&](RT r, double rs, double pk) { addFXx(r, rs, pk, std::false_type{}); };
+  auto addFXwide = [&](RT r, double rs, double pk) { addFXwidex(r, rs, pk, std::false_type{}); };
   const double p0 = uniform_d(sc->p0), U = uniform_d(sc->U);
   const double zbase = p0 * U, hbase = p0 * uniform_d(sc->logzi) * U;
   const int fxe = (int)uniform((uint32_t)fx_expbits(sc->fx_shift));
@@ -784,6 +796,8 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   const uint32_t n_lanes = S.nslices * 64u;
   const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
   stream.nullr = null_rec;
+  if constexpr (HYB) stream.nullr_hot = R::make_h(G + (uint32_t)lane, 0u, D);
+  else stream.nullr_hot = null_rec;
   auto issue = [&](SliceBuf<ENC> &sb) {
     // (a byte per slice lane: the lanes of an EC that takes several hold the same one; lanes without an EC 0)
     const uint32_t q = sb.sl * 64 + lane;
@@ -822,9 +836,8 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
 #pragma unroll
         for (int k = 0; k < B; ++k) {
           if (k0 + k < L) {
-            ev[k] = E_(b[k0 + k]);
-            if constexpr (decltype(ANY)::value) xt[k] = XTg_(b[k0 + k]);
-            else xt[k] = XT_(b[k0 + k]);
+            if constexpr (decltype(ANY)::value) ev[k] = E_(b[k0 + k]), xt[k] = XTg_(b[k0 + k]);
+            else ev[k] = Eh_(b[k0 + k]), xt[k] = XT_(b[k0 + k]);
           }
         }
 #pragma unroll
@@ -878,21 +891,24 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       for (int k = 0; k < kRegCells; k += 2) {
         if ((uint32_t)k < n) {  // (n odd: the pair's second record is the lane's null record, load_slice)
           double x0, x1;
+          // (KEPT rows: the slice's register rows with their kept values -- for index records a hot segment's rows)
+          auto e_of = [&](RT r) { if constexpr (KP) return Eh_(r); else return E_(r); };
+          auto xm_of = [&](RT r) { if constexpr (KP) return XMgh_(r); else return XMg_(r); };
           if constexpr (kFx) {
-            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : fx_factor(E_(b[k]), fxe) * XMg_(b[k]);
-            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : fx_factor(E_(b[k + 1]), fxe) * XMg_(b[k + 1]);
+            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : fx_factor(e_of(b[k]), fxe) * xm_of(b[k]);
+            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : fx_factor(e_of(b[k + 1]), fxe) * xm_of(b[k + 1]);
             if constexpr (WA) {
-              addFXwide(b[k], rj, x0);
-              addFXwide(b[k + 1], rj, x1);
+              addFXwidex(b[k], rj, x0, KEPT);
+              addFXwidex(b[k + 1], rj, x1, KEPT);
             } else {
-              addFX(b[k], rj, x0);
-              addFX(b[k + 1], rj, x1);
+              addFXx(b[k], rj, x0, KEPT);
+              addFXx(b[k + 1], rj, x1, KEPT);
             }
           } else {
-            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : XMg_(b[k]);
-            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : XMg_(b[k + 1]);
-            addACC(b[k], rj * x0);
-            addACC(b[k + 1], rj * x1);
+            x0 = KP && k < KEEPN ? xv[k < KEEPN ? k : 0] : xm_of(b[k]);
+            x1 = KP && k + 1 < KEEPN ? xv[k + 1 < KEEPN ? k + 1 : 0] : xm_of(b[k + 1]);
+            addACCx(b[k], rj * x0, KEPT);
+            addACCx(b[k + 1], rj * x1, KEPT);
           }
         }
       }
