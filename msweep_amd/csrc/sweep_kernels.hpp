@@ -358,12 +358,14 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
                               gridDim.x * (NT / 64), (uint32_t)lane,
                               scratch_off + 256u + uniform(tid >> 6) * kGeoStride);
   // The two background moments S1 = sum_g e_g s0_g, S2 = sum_g e_g s0_g^2 of the step values (s0_g = w_g - kappa):
-  // k_redfin left one partial pair per workgroup (partR[5 b + 3], [5 b + 4]); every wavefront adds them up for itself,
-  // in the same fixed order -- loads issued here, under the LDS fill, the DPP sums behind the barrier that follows it.
-  // (Until round 4 k_fin summed them into the scalar state and pass A had to wait for its verdict: k_finstep.)
+  // k_redfin left one partial pair per workgroup (partR[5 b + 3], [5 b + 4]); the first wavefront of every workgroup adds
+  // them up, in the same fixed order everywhere -- loads issued here, under the LDS fill, the DPP sums in front of the
+  // barrier that follows it, the two totals handed to the other wavefronts through LDS.  (All sixteen wavefronts
+  // summing for themselves cost pass A 2.5 us: 33 MB of L2 reads at the head of the sweep.  Until round 4 k_fin
+  // summed them into the scalar state and pass A had to wait for its verdict: k_finstep.)
   // (eight pairs per lane in flight at a time -- 512 workgroups of k_redfin, 8192 groups -- not one round trip each)
   double m1 = 0.0, m2 = 0.0;
-  for (int b0 = 0; b0 < npartR; b0 += 512) {
+  for (int b0 = 0; tid < 64 && b0 < npartR; b0 += 512) {
     double t1[8], t2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -411,10 +413,15 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   double nn = 0.0;
   if (skip) return;
   if (tid == 0) *(lds_u32_t *)(size_t)gcnt_off = 0u;
+  if (tid < 64) {  // (wave-uniform)
+    m1 = wave_sum(m1);
+    m2 = wave_sum(m2);
+    if (tid == 0) sh[18] = m1, sh[19] = m2;  // (reduction scratch: doubles 0..15 the block sums, byte 128 the guard counter)
+  }
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 0, 0);
   __syncthreads();
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 0, 1);
-  const double b1 = p0 * uniform_d(wave_sum(m1)), b2 = p0 * uniform_d(wave_sum(m2));
+  const double b1 = p0 * uniform_d(sh[18]), b2 = p0 * uniform_d(sh[19]);
 
   // (lanes past the end of a long EC, and the missing last row of an odd slice, take a record of the lane's own
   // sentinel group)
