@@ -4,11 +4,15 @@
 // GPU (msw_core_build_likelihood), RCG / EM abundances (--algorithm rcggpu|emgpu), bootstrap
 // (--iters / --seed / --bootstrap-count, src/mSWEEP.cpp:496-518) and abundances.txt in the format of
 // PlainSample / BootstrapSample::write_abundances[2] (src/PlainSample.cpp:32-71,
-// src/BootstrapSample.cpp:75-130).  Same flags and messages as the reference for what it covers;
-// the Python mirror `python -m msweep_amd` carries the remaining outputs (probs, likelihood files,
-// RATE) and is held byte-for-byte against this program in tests/test_gpu_cli_toy.py.
+// src/BootstrapSample.cpp:75-130), plus the consumers around the path: --write-probs / --print-probs (Sample::write_probs,
+// src/Sample.cpp:63-85,154-186: streamed from the device in blocks of ECs), --write-likelihood / --read-likelihood /
+// --no-fit-model (include/Likelihood.hpp:224-273, src/mSWEEP.cpp:357-386) and --run-rate (src/Sample.cpp:99-152,
+// src/mSWEEP.cpp:524-548).  Same flags and messages as the reference for what it covers; held byte-for-byte against
+// the Python mirror `python -m msweep_amd` in tests/test_gpu_cli_toy.py.
 //
 //   g++ -std=c++17 -O2 -o msweep_mini msweep_mini.cpp -L.. -lmsweep_core -Wl,-rpath,..
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +39,8 @@ struct Args {
   double q = 0.65, e = 0.01, zero_inflation = 0.01, tol = 1e-6;
   int gpu = 0;
   bool verbose = false;
+  bool write_probs = false, print_probs = false, write_likelihood = false, no_fit_model = false, run_rate = false;
+  std::string read_likelihood;
 };
 
 std::vector<std::string> split(const std::string &s, char d) {
@@ -75,6 +81,12 @@ Args parse(int argc, char **argv) {
     else if (k == "--gpu-index") a.gpu = std::stoi(val());
     else if (k == "-t") (void)val();  // host threads: nothing to set here
     else if (k == "--verbose") a.verbose = true;
+    else if (k == "--write-probs") a.write_probs = true;
+    else if (k == "--print-probs") a.print_probs = true;
+    else if (k == "--write-likelihood") a.write_likelihood = true;
+    else if (k == "--read-likelihood") a.read_likelihood = val();
+    else if (k == "--no-fit-model") a.no_fit_model = true;
+    else if (k == "--run-rate") a.run_rate = true;
     else throw std::runtime_error("unknown argument " + k);
   }
   if (a.themisto.empty()) {
@@ -118,6 +130,92 @@ void check(msw_handle h, int rc) {
   if (rc != 0) throw std::runtime_error(msw_last_error(h));
 }
 
+// a number as the reference's `*of << x` prints it (default ostream formatting: 6 significant digits)
+std::string g6(double x) {
+  char buf[64];
+  snprintf(buf, sizeof buf, "%g", x);
+  return buf;
+}
+
+// LL_WOR21::from_file (include/Likelihood.hpp:224-253): one line per equivalence class, `count \t L(0,j) ... L(G-1,j)`
+void read_likelihood_file(const std::string &path, size_t G, std::vector<uint64_t> &counts, std::vector<double> &L) {
+  std::ifstream in(path);
+  if (!in) throw std::runtime_error("Could not read from the likelihoods file.");
+  std::vector<std::vector<double>> cols;
+  std::string line;
+  while (std::getline(in, line)) {
+    const auto parts = split(line, '\t');
+    if (parts.size() != G + 1) throw std::runtime_error("Could not read from the likelihoods file.");
+    counts.push_back(std::stoull(parts[0]));
+    std::vector<double> c(G);
+    for (size_t g = 0; g < G; ++g) c[g] = std::stod(parts[g + 1]);
+    cols.push_back(std::move(c));
+  }
+  const size_t E = cols.size();
+  L.assign(G * E, 0.0);
+  for (size_t j = 0; j < E; ++j)
+    for (size_t g = 0; g < G; ++g) L[g * E + j] = cols[j][g];
+}
+
+// Sample::write_probs[2] (src/Sample.cpp:63-85,154-186): header `ec_id` + group names, one line per equivalence class
+// of exp(gamma); the G x E matrix is streamed from the device 8192 classes at a time (msw_core_gamma_block)
+void write_probs(std::ostream &of, msw_handle h, const std::vector<std::string> &names, const std::vector<std::string> &zero_names,
+                 size_t n_groups, size_t n_ecs) {
+  of << "ec_id";
+  for (auto &n : names) of << '\t' << n;
+  for (auto &n : zero_names) of << '\t' << n;
+  of << '\n';
+  const size_t block = 8192;
+  std::vector<double> buf(n_groups * block);
+  for (size_t e0 = 0; e0 < n_ecs; e0 += block) {
+    const size_t w = std::min(block, n_ecs - e0);
+    check(h, msw_core_gamma_block(h, e0, e0 + w, buf.data(), w));
+    for (size_t jj = 0; jj < w; ++jj) {
+      of << e0 + jj;
+      for (size_t g = 0; g < n_groups; ++g) of << '\t' << g6(std::exp(buf[g * w + jj]));
+      for (size_t z = 0; z < zero_names.size(); ++z) of << "\t0";
+      of << '\n';
+    }
+  }
+  of << '\n';
+  of.flush();
+}
+
+// digamma as the reference evaluates it (src/Sample.cpp:87-97)
+double digamma_ref(double x) {
+  double result = 0, xx, xx2, xx4;
+  for (; x < 7; ++x) result -= 1 / x;
+  x -= 1.0 / 2.0;
+  xx = 1.0 / x;
+  xx2 = xx * xx;
+  xx4 = xx2 * xx2;
+  result += std::log(x) + (1. / 24.) * xx2 - (7.0 / 960.0) * xx4 + (31.0 / 8064.0) * xx4 * xx2 - (127.0 / 30720.0) * xx4 * xx4;
+  return result;
+}
+// Sample::dirichlet_kld + get_rates (src/Sample.cpp:99-152) on alphas_i = theta_i * sum c -- the column sums the solve
+// already reduced on the device
+void dirichlet_kld_rate(const std::vector<double> &alphas, std::vector<double> &kld, std::vector<double> &rate) {
+  double a0 = 0.0;
+  for (double a : alphas) a0 += a;
+  std::vector<double> lk(alphas.size());
+  double mx = 0.0;
+  for (size_t i = 0; i < alphas.size(); ++i) {
+    const double aj = alphas[i];
+    const double v = std::lgamma(a0) - std::lgamma(a0 - aj) - std::lgamma(aj) + aj * (digamma_ref(aj) - digamma_ref(a0));
+    lk[i] = std::log(std::max(v, 1e-16));
+    mx = std::max(mx, lk[i]);
+  }
+  double s = 0.0;
+  for (double v : lk) s += std::exp(v - mx);
+  const double lsum = std::log(s) + mx;
+  kld.resize(lk.size());
+  rate.resize(lk.size());
+  for (size_t i = 0; i < lk.size(); ++i) {
+    kld[i] = std::exp(lk[i]);
+    rate[i] = std::exp(lk[i] - lsum);
+  }
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -134,21 +232,23 @@ int main(int argc, char **argv) {
   size_t n_ecs = 0, n_reads = 0, n_hits = 0, n_aligned = 0;
   try {
     grouping = read_grouping(a.indicators);
-    if (a.themisto.empty()) throw std::runtime_error("no pseudoalignment files given");
-    if (a.mode != "intersection" && a.mode != "union")
-      throw std::runtime_error("Unrecognized option `" + a.mode + "` for --themisto-mode");
-    std::vector<const char *> paths;
-    for (auto &p : a.themisto) paths.push_back(p.c_str());
-    msw_alignment_t aln = nullptr;
-    if (msw_alignment_read(paths.data(), paths.size(), grouping.indicators.size(),
-                           a.mode == "union" ? MSW_MERGE_UNION : MSW_MERGE_INTERSECTION, &aln))
-      throw std::runtime_error(msw_alignment_last_error());
-    msw_alignment_shape(aln, &n_ecs, &n_reads, &n_hits, &n_aligned);
-    ec_tptr.resize(n_ecs + 1);
-    ec_counts.resize(n_ecs);
-    ec_targets.resize(n_hits);
-    msw_alignment_export(aln, ec_tptr.data(), ec_targets.data(), ec_counts.data(), nullptr, nullptr);
-    msw_alignment_destroy(aln);
+    if (a.read_likelihood.empty()) {  // (--read-likelihood needs no pseudoalignments: src/mSWEEP.cpp:296-370)
+      if (a.themisto.empty()) throw std::runtime_error("no pseudoalignment files given");
+      if (a.mode != "intersection" && a.mode != "union")
+        throw std::runtime_error("Unrecognized option `" + a.mode + "` for --themisto-mode");
+      std::vector<const char *> paths;
+      for (auto &p : a.themisto) paths.push_back(p.c_str());
+      msw_alignment_t aln = nullptr;
+      if (msw_alignment_read(paths.data(), paths.size(), grouping.indicators.size(),
+                             a.mode == "union" ? MSW_MERGE_UNION : MSW_MERGE_INTERSECTION, &aln))
+        throw std::runtime_error(msw_alignment_last_error());
+      msw_alignment_shape(aln, &n_ecs, &n_reads, &n_hits, &n_aligned);
+      ec_tptr.resize(n_ecs + 1);
+      ec_counts.resize(n_ecs);
+      ec_targets.resize(n_hits);
+      msw_alignment_export(aln, ec_tptr.data(), ec_targets.data(), ec_counts.data(), nullptr, nullptr);
+      msw_alignment_destroy(aln);
+    }
   } catch (const std::exception &ex) {
     std::cerr << "Reading the pseudoalignments failed:\n  " << ex.what() << "\nexiting\n";
     return 1;
@@ -164,18 +264,48 @@ int main(int argc, char **argv) {
   msw_handle h = nullptr;
   size_t n_kept = 0;
   std::vector<uint8_t> mask(G, 1);
+  std::vector<double> logc_file;  // --read-likelihood: the log counts of the file (the build leaves its own on the device)
   try {
     if (msw_core_create(a.gpu, &h) != 0) throw std::runtime_error(msw_last_error(nullptr));
-    if (n_ecs == 0) throw std::runtime_error("no read aligned against the reference");
     // ordering the cells for the LDS banks pays from about the 1 000th iteration on: bootstrap runs
     check(h, msw_core_set_pack_schedule(h, a.iters >= 5 ? 1 : 0));
-    check(h, msw_core_build_likelihood(h, ec_tptr.data(), ec_targets.data(), n_ecs, grouping.indicators.data(),
-                                       grouping.indicators.size(), grouping.sizes.data(), G, ec_counts.data(), a.q,
-                                       a.e, a.zero_inflation, a.min_hits, &n_kept, mask.data(), nullptr));
+    if (!a.read_likelihood.empty()) {
+      // --read-likelihood (include/Likelihood.hpp:224-253): the dense matrix of a file through the dense boundary
+      std::vector<double> L;
+      read_likelihood_file(a.read_likelihood, G, ec_counts, L);
+      n_ecs = ec_counts.size();
+      if (n_ecs == 0) throw std::runtime_error("Could not read from the likelihoods file.");
+      check(h, msw_core_set_dense_logl(h, L.data(), G, n_ecs, n_ecs));
+      n_kept = G;
+      for (uint64_t c : ec_counts) {
+        logc_file.push_back(std::log((double)c));
+        n_reads += c;   // (no alignment: the reads are those the file counts, as the Python mirror reports them)
+      }
+    } else {
+      if (n_ecs == 0) throw std::runtime_error("no read aligned against the reference");
+      check(h, msw_core_build_likelihood(h, ec_tptr.data(), ec_targets.data(), n_ecs, grouping.indicators.data(),
+                                         grouping.indicators.size(), grouping.sizes.data(), G, ec_counts.data(), a.q,
+                                         a.e, a.zero_inflation, a.min_hits, &n_kept, mask.data(), nullptr));
+    }
+    if (a.write_likelihood) {
+      // --write-likelihood (include/Likelihood.hpp:255-273; the file: src/OutfileDesignator.cpp:67-74)
+      std::vector<double> L(n_kept * n_ecs);
+      check(h, msw_core_get_dense_logl(h, L.data(), n_ecs));
+      std::ofstream lf(a.prefix.empty() ? std::string("likelihoods.tsv") : a.prefix + "_likelihoods.tsv");
+      for (size_t j = 0; j < n_ecs; ++j) {
+        lf << ec_counts[j];
+        for (size_t g = 0; g < n_kept; ++g) lf << '\t' << g6(L[g * n_ecs + j]);
+        lf << '\n';
+      }
+    }
   } catch (const std::exception &ex) {
     std::cerr << "Building the log-likelihood array failed:\n  " << ex.what() << "\nexiting\n";
     msw_core_destroy(h);
     return 1;
+  }
+  if (a.no_fit_model) {  // src/mSWEEP.cpp:385-386
+    msw_core_destroy(h);
+    return 0;
   }
   std::vector<double> prior(n_kept, 1.0);
   if (!a.alphas.empty()) {
@@ -189,13 +319,16 @@ int main(int argc, char **argv) {
   }
   uint64_t total = 0;
   for (uint64_t c : ec_counts) total += c;
+  std::vector<std::string> est_names, zero_names;
+  for (size_t g = 0; g < G; ++g) (mask[g] ? est_names : zero_names).push_back(grouping.names[g]);
   std::vector<std::vector<double>> results;  // [0] = estimate without resampling (include/Sample.hpp:157)
   try {
     std::vector<double> theta(n_kept);
     size_t it = 0;
     double bound = 0.0;
     // logc = NULL: the log counts stay where the build left them, on the device
-    check(h, msw_core_solve(h, nullptr, prior.data(), a.tol, a.max_iters, algo, prec, theta.data(), &it, &bound));
+    check(h, msw_core_solve(h, logc_file.empty() ? nullptr : logc_file.data(), prior.data(), a.tol, a.max_iters, algo, prec,
+                            theta.data(), &it, &bound));
     if (a.verbose) {
       const size_t n = std::min<size_t>(it, 4096);
       std::vector<double> b(n), nn(n);
@@ -225,6 +358,18 @@ int main(int argc, char **argv) {
       for (size_t b = 0; b < a.iters; ++b)
         results.emplace_back(thetas.begin() + b * n_kept, thetas.begin() + (b + 1) * n_kept);
     }
+    // --write-probs / --print-probs: the probabilities of the un-resampled estimate (the replicates ran on solver
+    // states of their own: the handle still holds it -- the reference writes them before its replicate loop,
+    // src/mSWEEP.cpp:471-493)
+    if (a.write_probs || a.print_probs) {
+      const std::vector<std::string> none;
+      const std::vector<std::string> &zn = a.min_hits > 0 ? zero_names : none;
+      if (a.write_probs && !a.prefix.empty()) {
+        std::ofstream pf(a.prefix + "_probs.tsv");
+        write_probs(pf, h, est_names, zn, n_kept, n_ecs);
+      }
+      if (a.print_probs || (a.write_probs && a.prefix.empty())) write_probs(std::cout, h, est_names, zn, n_kept, n_ecs);
+    }
   } catch (const std::exception &ex) {
     std::cerr << "Estimating relative abundances failed:\n  " << ex.what() << "\nexiting\n";
     msw_core_destroy(h);
@@ -237,6 +382,18 @@ int main(int argc, char **argv) {
   if (!a.prefix.empty()) file.open(a.prefix + "_abundances.txt");
   std::ostream &of = a.prefix.empty() ? std::cout : file;
   of << "#mSWEEP_version:\t" << kVersion << '\n' << "#num_reads:\t" << n_reads << '\n' << "#num_aligned:\t" << total << '\n';
+  if (a.run_rate) {
+    // experimental RATE / KLD (src/Sample.cpp:99-152; the table: src/mSWEEP.cpp:529-545)
+    std::vector<double> alphas(n_kept), kld, rate;
+    for (size_t i = 0; i < n_kept; ++i) alphas[i] = results[0][i] * (double)total;
+    dirichlet_kld_rate(alphas, kld, rate);
+    of << "#c_id\tmean_theta\tRATE\tKLD\n";
+    for (size_t i = 0; i < n_kept; ++i)
+      of << est_names[i] << '\t' << g6(results[0][i]) << '\t' << g6(rate[i]) << '\t' << g6(kld[i]) << '\n';
+    for (auto &n : zero_names) of << n << "\t0\t0\t0\n";
+    of.flush();
+    return 0;
+  }
   if (a.iters > 0) of << "#bootstrap_iters:\t" << a.iters << '\n' << "#c_id\tmean_theta\tbootstrap_mean_thetas\n";
   else of << "#c_id\tmean_theta\n";
   size_t row = 0;

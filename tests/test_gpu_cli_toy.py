@@ -161,9 +161,13 @@ def mini_binary(tmp_path_factory):
 
 
 @pytest.mark.parametrize("extra", [[], ["--min-hits", "400"], ["--iters", "3", "--seed", "42"],
-                                   ["--algorithm", "emgpu", "--themisto-mode", "union"]])
+                                   ["--algorithm", "emgpu", "--themisto-mode", "union"],
+                                   ["--write-probs"], ["--write-probs", "--min-hits", "400", "--iters", "2", "--seed", "5"],
+                                   ["--run-rate"], ["--run-rate", "--min-hits", "400"],
+                                   ["--write-likelihood", "--write-probs"], ["--write-likelihood", "--no-fit-model"]])
 def test_native_driver_matches_python_cli(tmp_path, mini_binary, extra):
-    """Same flags, same abundances file, byte for byte (bootstrap included: the device stream is seeded)."""
+    """Same flags, same files, byte for byte (bootstrap included: the device stream is seeded): abundances, and --
+    with their flags -- the probabilities, the likelihood file and the RATE / KLD table."""
     import subprocess
     _toy(tmp_path)
     common = ["--themisto-1", str(tmp_path / "toy_1.txt"), "--themisto-2", str(tmp_path / "toy_2.txt"),
@@ -171,7 +175,44 @@ def test_native_driver_matches_python_cli(tmp_path, mini_binary, extra):
     assert main(common + ["-o", str(tmp_path / "py")]) == 0
     p = subprocess.run([mini_binary] + common + ["-o", str(tmp_path / "cc")], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert (tmp_path / "cc_abundances.txt").read_text() == (tmp_path / "py_abundances.txt").read_text()
+    outputs = [] if "--no-fit-model" in extra else ["abundances.txt"]
+    outputs += ["probs.tsv"] if "--write-probs" in extra and "--no-fit-model" not in extra else []
+    outputs += ["likelihoods.tsv"] if "--write-likelihood" in extra else []
+    for name in outputs:
+        got, want = (tmp_path / ("cc_" + name)).read_text(), (tmp_path / ("py_" + name)).read_text()
+        assert len(want) > 20 and got == want, name
+    if "--no-fit-model" in extra:
+        assert not (tmp_path / "cc_abundances.txt").exists() and not (tmp_path / "py_abundances.txt").exists()
+
+
+def test_native_driver_reads_a_likelihood_file(tmp_path, mini_binary):
+    """--read-likelihood in the native program: the file another run wrote, no pseudoalignments given; the same
+    abundances and probabilities as the Python mirror on the same file, and -- to the 6 digits the file keeps -- the
+    estimate of the run that wrote it.  --print-probs goes to stdout."""
+    import subprocess
+    _toy(tmp_path)
+    common = ["--themisto-1", str(tmp_path / "toy_1.txt"), "--themisto-2", str(tmp_path / "toy_2.txt"),
+              "-i", str(tmp_path / "clustering.txt")]
+    p = subprocess.run([mini_binary] + common + ["-o", str(tmp_path / "w"), "--write-likelihood"],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rd = ["-i", str(tmp_path / "clustering.txt"), "--read-likelihood", str(tmp_path / "w_likelihoods.tsv"), "--write-probs"]
+    assert main(rd + ["-o", str(tmp_path / "py")]) == 0
+    p = subprocess.run([mini_binary] + rd + ["-o", str(tmp_path / "cc")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    for name in ("abundances.txt", "probs.tsv"):
+        assert (tmp_path / ("cc_" + name)).read_text() == (tmp_path / ("py_" + name)).read_text(), name
+    h0, r0 = _parse(str(tmp_path / "w_abundances.txt"))
+    h1, r1 = _parse(str(tmp_path / "cc_abundances.txt"))
+    assert h1["#num_aligned:"] == h0["#num_aligned:"]
+    assert [n for n, _ in r1] == [n for n, _ in r0]
+    np.testing.assert_allclose([v[0] for _, v in r1], [v[0] for _, v in r0], rtol=2e-4, atol=1e-7)
+    p = subprocess.run([mini_binary] + rd[:-1] + ["--print-probs"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.startswith((tmp_path / "cc_probs.tsv").read_text())      # then the abundances, also on stdout
+    p = subprocess.run([mini_binary, "-i", str(tmp_path / "clustering.txt"), "--read-likelihood", str(tmp_path / "toy_1.txt")],
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "Could not read from the likelihoods file." in p.stderr
 
 
 def test_native_driver_errors(tmp_path, mini_binary):
