@@ -253,6 +253,13 @@ int msw_comm_rccl_count(msw_comm_t c, int *count);
  * device staging buffers).  The exchange step of the bootstrap (src/mSWEEP.cpp:513-517 stores every
  * replicate's abundances in one table, include/Sample.hpp:157). */
 int msw_comm_allgather(msw_comm_t c, const double *send, size_t n, double *recv);
+/* The per-iteration exchange of the sharded solve on host buffers (staged through device memory, blocking): ints[0..ni)
+ * and reals[0..nr) are replaced by their sums over the ranks -- integers exactly, doubles in rank order, the same bits
+ * on every rank.  Either part may be empty.  The transport is the communicator's: ncclAllReduce, the in-process
+ * staging of thread-ranks, or -- MSWEEP_ALLREDUCE=peer in the environment when the communicator is created -- one
+ * kernel that writes the message into every peer's inbox (msweep_amd/csrc/peer_comm.hpp).  Tests and timing. */
+int msw_comm_allreduce(msw_comm_t c, uint64_t *ints, size_t ni, double *reals, size_t nr, int repeats,
+                       double *ms_per_call);
 /* comm == NULL detaches.  The communicator must outlive the solves that use it. */
 int msw_core_set_comm(msw_handle h, msw_comm_t comm);
 /* last error text of the msw_comm_* calls of this thread */

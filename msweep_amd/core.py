@@ -30,7 +30,7 @@ EXPORTS = [
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
     "msw_core_set_fixed_iters", "msw_core_hbm_stream_rates", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
     "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
-    "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_core_continue", "msw_core_gamma_block",
+    "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_comm_allreduce", "msw_core_continue", "msw_core_gamma_block",
     "msw_core_last_bootstrap_timing", "msw_core_layout_info", "msw_core_guarded_visits", "msw_core_set_pack_schedule",
     "msw_core_set_option", "msw_core_get_option",
 ]
@@ -129,6 +129,7 @@ def load_library():
     L.msw_comm_size.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.msw_comm_rccl_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.msw_comm_allgather.argtypes = [vp, vp, sz, vp]
+    L.msw_comm_allreduce.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.POINTER(dp)]
     L.msw_core_set_profiling.argtypes = [vp, C.c_int]
     L.msw_core_set_fixed_iters.argtypes = [vp, C.c_int]
     L.msw_core_set_pack_schedule.argtypes = [vp, C.c_int]
@@ -507,6 +508,16 @@ class Comm:
         if self._L.msw_comm_allgather(self._c, _ptr(send), len(send), _ptr(out)) != 0:
             raise MswError(self._L.msw_comm_last_error().decode())
         return out
+
+    def allreduce(self, ints, reals, repeats=1):
+        """Sums over the ranks of a uint64 and a float64 vector (msw_comm_allreduce); returns (ints, reals, ms per call)."""
+        a = np.array(ints, np.uint64).ravel()
+        b = np.array(reals, np.float64).ravel()
+        ms = C.c_double()
+        if self._L.msw_comm_allreduce(self._c, _ptr(a) if len(a) else None, len(a), _ptr(b) if len(b) else None, len(b),
+                                      int(repeats), C.byref(ms)) != 0:
+            raise MswError(self._L.msw_comm_last_error().decode())
+        return a, b, ms.value
 
     def close(self):
         if self._c and self._owner:

@@ -7,6 +7,8 @@
 //   * LocalComm: ranks are host threads of one process (tests on a single GPU, or several GPUs
 //                driven from one process); host-staged, summed in rank order (bitwise identical
 //                on every rank).
+//   * PeerComm (peer_comm.hpp, MSWEEP_ALLREDUCE=peer): wraps either; one kernel per all-reduce that writes into the
+//                peers' inboxes.
 #pragma once
 #include <rccl/rccl.h>
 
@@ -35,6 +37,8 @@ struct msw_comm {
   virtual void allgather_host(const double *send, size_t n, double *recv) = 0;
   // a rank that fails outside a collective calls this so that its peers do not wait for ever
   virtual void abort() {}
+  // called after the solve stream has been synchronised: a collective that failed ON THE DEVICE throws here
+  virtual void check() {}
 };
 
 namespace msw {

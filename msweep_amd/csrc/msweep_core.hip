@@ -24,6 +24,7 @@
 #include "pack_kernels.hpp"
 #include "compress_kernels.hpp"
 #include "comm.hpp"
+#include "peer_comm.hpp"
 #include "likelihood_kernels.hpp"
 #include "bootstrap_kernels.hpp"
 #include "em_kernels.hpp"
@@ -639,6 +640,7 @@ void launch_finstep(msw_core *h, int mode) {
 void poll(msw_core *h) {
   MSW_HIP(hipMemcpyAsync(h->sc_host, h->sc.p, sizeof(Scalars), hipMemcpyDeviceToHost, h->stream));
   MSW_HIP(hipStreamSynchronize(h->stream));
+  if (h->comm) h->comm->check();
 }
 
 // Inputs of one solve: c_j (from log counts or from bootstrap counts already on the device) and
@@ -1116,6 +1118,7 @@ int msw_comm_rccl_count(msw_comm_t c, int *count) {
     g_create_error = "msw_comm_rccl_count: null argument";
     return 1;
   }
+  if (const PeerComm *pc = dynamic_cast<const PeerComm *>(c)) c = pc->base.get();
   const RcclComm *rc = dynamic_cast<const RcclComm *>(c);
   *count = rc ? rc->count() : 0;
   return 0;
@@ -1132,6 +1135,43 @@ int msw_comm_allgather(msw_comm_t c, const double *send, size_t n, double *recv)
   } catch (const std::exception &ex) {
     g_create_error = ex.what();
     (void)hipGetLastError();
+    c->abort();
+    return 1;
+  }
+}
+
+int msw_comm_allreduce(msw_comm_t c, uint64_t *ints, size_t ni, double *reals, size_t nr, int repeats, double *ms_per_call) {
+  if (!c || (ni && !ints) || (nr && !reals) || repeats < 1) {
+    g_create_error = "msw_comm_allreduce: bad arguments";
+    return 1;
+  }
+  hipStream_t st = nullptr;
+  try {
+    MSW_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    DevBuf<double> buf, work;
+    buf.alloc(ni + nr + 1);
+    work.alloc(ni + nr + 1);
+    if (ni) MSW_HIP(hipMemcpyAsync(buf.p, ints, ni * 8, hipMemcpyHostToDevice, st));
+    if (nr) MSW_HIP(hipMemcpyAsync(buf.p + ni, reals, nr * 8, hipMemcpyHostToDevice, st));
+    // repeats > 1: the same message again and again (timing; the sums of the last one are returned)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < repeats; ++k) {
+      MSW_HIP(hipMemcpyAsync(work.p, buf.p, (ni + nr) * 8, hipMemcpyDeviceToDevice, st));
+      c->allreduce_mixed(reinterpret_cast<uint64_t *>(work.p), ni, work.p + ni, nr, st);
+    }
+    MSW_HIP(hipStreamSynchronize(st));
+    c->check();
+    if (ms_per_call)
+      *ms_per_call = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / repeats;
+    if (ni) MSW_HIP(hipMemcpyAsync(ints, work.p, ni * 8, hipMemcpyDeviceToHost, st));
+    if (nr) MSW_HIP(hipMemcpyAsync(reals, work.p + ni, nr * 8, hipMemcpyDeviceToHost, st));
+    MSW_HIP(hipStreamSynchronize(st));
+    (void)hipStreamDestroy(st);
+    return 0;
+  } catch (const std::exception &ex) {
+    g_create_error = ex.what();
+    (void)hipGetLastError();
+    if (st) (void)hipStreamDestroy(st);
     c->abort();
     return 1;
   }
@@ -1158,7 +1198,9 @@ int msw_comm_create_rccl(const unsigned char id[128], int rank, int nranks, int 
     MSW_HIP(hipSetDevice(device));
     ncclUniqueId uid;
     std::memcpy(&uid, id, 128);
-    *out = new RcclComm(uid, rank, nranks);
+    std::unique_ptr<msw_comm> c(new RcclComm(uid, rank, nranks));
+    if (peer_allreduce_requested() && nranks > 1) c.reset(new PeerComm(std::move(c), /*ipc=*/true));
+    *out = c.release();
     return 0;
   } catch (const std::exception &ex) {
     g_create_error = ex.what();
@@ -1171,9 +1213,21 @@ int msw_comm_create_local(int nranks, msw_comm_t *out) {
     g_create_error = "msw_comm_create_local: bad arguments";
     return 1;
   }
-  auto grp = std::make_shared<LocalGroup>(nranks);
-  for (int r = 0; r < nranks; ++r) out[r] = new LocalComm(grp, r);
-  return 0;
+  try {
+    const bool peer = peer_allreduce_requested() && nranks > 1;
+    auto grp = std::make_shared<LocalGroup>(nranks);
+    for (int r = 0; r < nranks; ++r) out[r] = nullptr;
+    for (int r = 0; r < nranks; ++r) {
+      std::unique_ptr<msw_comm> c(new LocalComm(grp, r));
+      if (peer) c.reset(new PeerComm(std::move(c), /*ipc=*/false));
+      out[r] = c.release();
+    }
+    return 0;
+  } catch (const std::exception &ex) {
+    for (int r = 0; r < nranks; ++r) delete out[r];
+    g_create_error = ex.what();
+    return 1;
+  }
 }
 
 void msw_comm_destroy(msw_comm_t c) { delete c; }

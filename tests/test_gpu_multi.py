@@ -26,12 +26,15 @@ def n_devices():
     return torch.cuda.device_count()     # does not initialise the GPU
 
 
+# transport of the sharded solve's two all-reduces per iteration: ncclAllReduce (the default), or the one-shot kernel
+# that writes into the peers' inboxes over xGMI (hipIpc-mapped; msweep_amd/csrc/peer_comm.hpp) -- same bits either way
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
 @pytest.mark.parametrize("world", [2, 4, 8])   # 8: the size of the machine the driver runs the scaling curve on
-def test_rccl_ranks_bootstrap_and_sharded_solve(gpu_core, tmp_path, world):
+def test_rccl_ranks_bootstrap_and_sharded_solve(gpu_core, tmp_path, world, transport):
     if n_devices() < world:
         pytest.skip(f"needs {world} GPUs, {n_devices()} visible")
     d = str(tmp_path)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MSWEEP_ALLREDUCE=transport)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rank_worker.py"), str(r), str(world), d],
                               env=env) for r in range(world)]
     try:
