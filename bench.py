@@ -43,8 +43,9 @@ OUT = sys.stdout
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 METRIC = "EM iters/sec + reads×groups cells/sec, 10M reads × 5k groups"
 # HBM bytes per launch of the sweeps (rocprofv3 PMC passes, committed): newest file that covers the workload
-TRAFFIC_JSON = {"cfg3": ["r03_traffic_pmc.json", "r02_traffic_pmc.json"], "cfg2": ["r03_cfg2_traffic_pmc.json"],
-                "cfg5": ["r03_cfg5_traffic_pmc.json"], "cfg4": ["r03_traffic_pmc.json", "r02_traffic_pmc.json"]}
+TRAFFIC_JSON = {"cfg3": ["r04_traffic_pmc.json", "r03_traffic_pmc.json"], "cfg2": ["r04_cfg2_traffic_pmc.json", "r03_cfg2_traffic_pmc.json"],
+                "cfg5": ["r04_cfg5_traffic_pmc.json", "r03_cfg5_traffic_pmc.json"],
+                "cfg4": ["r04_traffic_pmc.json", "r03_traffic_pmc.json"]}
 
 
 def parse():
@@ -778,6 +779,7 @@ def main():
                 "passA": tm["passA_ms"] / it, "passB": tm["passB_ms"] / it, "collectives": tm["collective_ms"] / it,
                 "chain_and_gaps": (tm["solve_ms"] - tm["passA_ms"] - tm["passB_ms"] - tm["collective_ms"]) / it,
                 "collectives_per_step": tm["collectives"] / it,
+                "allreduce": os.environ.get("MSWEEP_ALLREDUCE", "rccl"),     # `peer`: msweep_amd/csrc/peer_comm.hpp
                 "what": "rank 0, profiled run (an event pair around every sweep and every all-reduce adds ~6 us of idle "
                         "GPU each: the sum exceeds ms_per_step); collectives = k_sum_scalar + all-reduce of 1 double "
                         "after pass A, k_colsum + all-reduce of 3 G integers + 4 doubles after pass B; chain_and_gaps = "

@@ -195,6 +195,14 @@ __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70);
 // measured: no faster -- the stream already runs at the achievable HBM rate -- and it needs a fixed
 // number of loads per slice plus dummy fetches to keep the compiler's path-insensitive vmcnt
 // accounting exact.
+// MSW_EXPERIMENT_NOSTREAM (tools/ab_build.py; never the shipped build): every slice takes its rows from the first
+// 256 KB of the record stream -- cache-resident -- so that a sweep's time WITHOUT its HBM stream can be measured
+// (replicates sharing a pass).  Plain offset records only: the result is that of another problem.
+#ifdef MSW_EXPERIMENT_NOSTREAM
+#define MSW_REC_ROW(o) ((o) & 1023u)
+#else
+#define MSW_REC_ROW(o) (o)
+#endif
 template <int ENC, bool REVERSE>
 struct SliceStream {
   const SellDev &S;
@@ -256,7 +264,7 @@ struct SliceStream {
       if (b.len <= (uint32_t)kRegCells) load_slice_split(S.rec, (size_t)b.o * 64 + lane, b.len, b.nhot, b.r, b.rc, nullr, nullr_hot);
     } else {
       b.o = uniform(oe.x);
-      if (b.len <= (uint32_t)kRegCells) load_slice<ENC>(S.rec, (size_t)b.o * 64 + lane, b.len, b.r, nullr);
+      if (b.len <= (uint32_t)kRegCells) load_slice<ENC>(S.rec, (size_t)MSW_REC_ROW(b.o) * 64 + lane, b.len, b.r, nullr);
     }
     issue(b);
   }
