@@ -126,6 +126,16 @@ for case in range(n_cases):
                 if dd.max() <= 1e-14 and tr["didreset"][:n].tolist() == dt["didreset"][:n].tolist():
                     print("structured oracle off, dense-state oracle agrees with the HIP path:", tag, flush=True)
                     continue
+                # the two ORACLES apart by more than the HIP path is from either (case 292 of seed 7: deep values,
+                # counts up to 1e5, beta 5.5 at the third iteration -- struct-dense 4.4e-7, hip-struct 3.0e-7,
+                # hip-dense 1.4e-7 at iteration 7, with or without the division's residual correction): the
+                # problem amplifies rounding beyond the tolerance; parity = inside the oracles' own disagreement
+                same = tr["didreset"][:n].tolist() == dt["didreset"][:n].tolist() == rt["didreset"][:n].tolist()
+                rel_ = lambda a, b: np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300) * (np.abs(b) >= 1e-12))  # noqa: E731
+                sd = rel_(rt["theta"][:n], dt["theta"][:n])
+                if same and sd > 1e-7 and max(rel_(tr["theta"][:n], rt["theta"][:n]), rel_(tr["theta"][:n], dt["theta"][:n])) <= sd:
+                    print(f"oracles apart by {sd:.1e}, HIP path between them:", tag, flush=True)
+                    continue
             if d.max() > 1e-14:
                 it, g = np.unravel_index(np.argmax(d), d.shape)
                 raise AssertionError(f"lock-step: iteration {it} group {g}: hip {tr['theta'][it, g]:.6e} oracle {rt['theta'][it, g]:.6e} "
