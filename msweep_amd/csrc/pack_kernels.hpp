@@ -264,14 +264,27 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
         for (int w = lane; w < 196; w += 64) reinterpret_cast<uint32_t *>(&bk)[w] = w < 192 ? 0xffffffffu : 0u;
         uint32_t pick_g = pe.n_groups + lane, pick_e = kPackPad;
         __syncthreads();
-        for (int li = 0; li < 64; ++li) {
-          const int l = (li + (int)(k0 + k) * 7) & 63;  // rotate the priority
-          const uint32_t n_l = (uint32_t)__builtin_amdgcn_readlane((int)ncell, l);
-          const uint32_t t_l = (uint32_t)__builtin_amdgcn_readlane((int)taken, l);
-          const uint32_t avail = ((1u << n_l) - 1u) & ~t_l;  // its unplaced cells (wave-uniform)
-          if (avail == 0) continue;                         // nothing left to place
-          const int R_l = __builtin_amdgcn_readlane(R, l), C_l = l >> 4, H_l = l >> 5;
-          bool valid = lane < 16 && (avail >> cand & 1u);
+        // The lanes take their turns in the rotated order l = start, start + 1, ... (mod 64).  The bank state of the
+        // lanes 0..31 (lane groups C 0-1, R 0-1, H 0) and of the lanes 32..63 (C 2-3, R 2-3, H 1) is disjoint, so the two
+        // half-waves' turns commute: turn t of the lower half (its t-th lane in the rotated order) and turn t of the
+        // upper half are worked TOGETHER, on DPP rows 0 and 2 -- 32 double turns instead of 64 turns, the same choices
+        // (round 4: the packer's records stage 11.2 -> 7 ms at cfg3).
+        const int start = ((int)(k0 + k) * 7) & 63;  // rotate the priority
+        const int sA = start < 32 ? start : 0, sB = start < 32 ? 0 : start - 32;
+        const bool upper = lane >= 32;
+        for (int t2 = 0; t2 < 32; ++t2) {
+          const int la = (sA + t2) & 31, lb = 32 + ((sB + t2) & 31);
+          const uint32_t n_a = (uint32_t)__builtin_amdgcn_readlane((int)ncell, la);
+          const uint32_t t_a = (uint32_t)__builtin_amdgcn_readlane((int)taken, la);
+          const uint32_t n_b = (uint32_t)__builtin_amdgcn_readlane((int)ncell, lb);
+          const uint32_t t_b = (uint32_t)__builtin_amdgcn_readlane((int)taken, lb);
+          const uint32_t avail_a = ((1u << n_a) - 1u) & ~t_a, avail_b = ((1u << n_b) - 1u) & ~t_b;  // unplaced cells
+          if ((avail_a | avail_b) == 0) continue;             // nothing left to place (wave-uniform)
+          const int R_a = __builtin_amdgcn_readlane(R, la), R_b = __builtin_amdgcn_readlane(R, lb);
+          const int l = upper ? lb : la;                      // the lane whose turn this half-wave works
+          const uint32_t avail = upper ? avail_b : avail_a;
+          const int R_l = upper ? R_b : R_a, C_l = l >> 4, H_l = l >> 5;
+          bool valid = (lane & 31) < 16 && (avail >> cand & 1u);
           uint32_t g = 0, i = 0, v_at = 0, v_rg = 0, v_rs = 0, v_hg = 0, key = 0;
           if (valid) {
             g = cg[l * kRowW + cand];
@@ -290,25 +303,36 @@ __global__ __launch_bounds__(64) void k_pack_slices(const uint32_t *rowptr, cons
             if (v_hg == 0xffffffffu || v_hg == g) score += MSW_W_E;                       // e_g b64
             key = ((score << 4) | (15u - cand)) + 1u;  // the highest score; among equals the first cell
           }
-          // row maximum of lanes 0..15 -> lane 15 (row_shr 1, 2, 4, 8; lanes shifted in from outside read 0)
+          // row maxima of lanes 0..15 -> lane 15 and of lanes 32..47 -> lane 47 (row_shr 1, 2, 4, 8; lanes shifted in
+          // from outside a row read 0)
           uint32_t mx = key;
           mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x111, 0xf, 0xf, false));
           mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x112, 0xf, 0xf, false));
           mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x114, 0xf, 0xf, false));
           mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x118, 0xf, 0xf, false));
-          const uint32_t best = (uint32_t)__builtin_amdgcn_readlane((int)mx, 15);
-          if (best != 0) {
-            const int cb = 15 - (int)((best - 1u) & 15u);
-            const uint32_t g_w = (uint32_t)__builtin_amdgcn_readlane((int)g, cb);
-            const uint32_t i_w = (uint32_t)__builtin_amdgcn_readlane((int)i, cb);
-            if (lane == cb) {  // the winner holds the bank words it has just read
-              at[C_l] = v_at | 1u << (g & 15);  // (a bank that is held keeps its address: written back as read)
-              rg[R_l][g & 15] = v_rg == 0xffffffffu ? g : v_rg;
-              rs[R_l][i & 15] = v_rs == 0xffffffffu ? i : v_rs;
-              hg[H_l][g & 31] = v_hg == 0xffffffffu ? g : v_hg;
+          const uint32_t best_a = (uint32_t)__builtin_amdgcn_readlane((int)mx, 15);
+          const uint32_t best_b = (uint32_t)__builtin_amdgcn_readlane((int)mx, 47);
+          const int cb_a = 15 - (int)((best_a - 1u) & 15u), cb_b = 47 - (int)((best_b - 1u) & 15u);  // the winners' lanes
+          if ((best_a != 0 && lane == cb_a) || (best_b != 0 && lane == cb_b)) {  // a winner holds the bank words it has just read
+            at[C_l] = v_at | 1u << (g & 15);  // (a bank that is held keeps its address: written back as read)
+            rg[R_l][g & 15] = v_rg == 0xffffffffu ? g : v_rg;
+            rs[R_l][i & 15] = v_rs == 0xffffffffu ? i : v_rs;
+            hg[H_l][g & 31] = v_hg == 0xffffffffu ? g : v_hg;
+          }
+          if (best_a != 0) {
+            const uint32_t g_w = (uint32_t)__builtin_amdgcn_readlane((int)g, cb_a);
+            const uint32_t i_w = (uint32_t)__builtin_amdgcn_readlane((int)i, cb_a);
+            if (lane == la) {
+              taken |= 1u << cb_a;
+              pick_g = g_w;
+              pick_e = i_w;
             }
-            if (lane == l) {
-              taken |= 1u << cb;
+          }
+          if (best_b != 0) {
+            const uint32_t g_w = (uint32_t)__builtin_amdgcn_readlane((int)g, cb_b);
+            const uint32_t i_w = (uint32_t)__builtin_amdgcn_readlane((int)i, cb_b);
+            if (lane == lb) {
+              taken |= 1u << (cb_b - 32);
               pick_g = g_w;
               pick_e = i_w;
             }
