@@ -244,6 +244,10 @@ typedef struct msw_comm *msw_comm_t;
 int msw_comm_unique_id(unsigned char id_out[128]);
 int msw_comm_create_rccl(const unsigned char id[128], int rank, int nranks, int device, msw_comm_t *out);
 int msw_comm_create_local(int nranks, msw_comm_t *out);
+/* msw_comm_create_shm: the ranks are PROCESSES of one host that meet in a POSIX shared-memory segment `name` ("/..."),
+ * host-staged like the thread-ranks.  Test infrastructure for the process-per-rank paths on a box with one GPU (RCCL
+ * refuses two ranks on one device): with MSWEEP_ALLREDUCE=peer the inboxes travel as hipIpc handles, as under RCCL. */
+int msw_comm_create_shm(const char *name, int rank, int nranks, int device, msw_comm_t *out);
 void msw_comm_destroy(msw_comm_t c);
 /* ranks of the communicator and this rank's index (either pointer may be NULL) */
 int msw_comm_size(msw_comm_t c, int *nranks, int *rank);

@@ -30,7 +30,7 @@ EXPORTS = [
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
     "msw_core_set_fixed_iters", "msw_core_hbm_stream_rates", "msw_comm_unique_id", "msw_comm_create_rccl", "msw_comm_create_local",
     "msw_comm_destroy", "msw_core_set_comm", "msw_comm_last_error", "msw_core_bootstrap_dist",
-    "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_comm_allreduce", "msw_core_continue", "msw_core_gamma_block",
+    "msw_comm_size", "msw_comm_rccl_count", "msw_comm_allgather", "msw_comm_allreduce", "msw_comm_create_shm", "msw_core_continue", "msw_core_gamma_block",
     "msw_core_last_bootstrap_timing", "msw_core_layout_info", "msw_core_guarded_visits", "msw_core_set_pack_schedule",
     "msw_core_set_option", "msw_core_get_option",
 ]
@@ -130,6 +130,7 @@ def load_library():
     L.msw_comm_rccl_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.msw_comm_allgather.argtypes = [vp, vp, sz, vp]
     L.msw_comm_allreduce.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.POINTER(dp)]
+    L.msw_comm_create_shm.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.msw_core_set_profiling.argtypes = [vp, C.c_int]
     L.msw_core_set_fixed_iters.argtypes = [vp, C.c_int]
     L.msw_core_set_pack_schedule.argtypes = [vp, C.c_int]
@@ -487,6 +488,15 @@ class Comm:
         if L.msw_comm_create_local(int(nranks), arr) != 0:
             raise MswError(L.msw_comm_last_error().decode())
         return [cls(C.c_void_p(arr[i])) for i in range(nranks)]
+
+    @classmethod
+    def shm(cls, name, rank, nranks, device=0):
+        """Rank `rank` of `nranks` PROCESSES of this host meeting in the shared-memory segment `name` ("/...")."""
+        L = load_library()
+        out = C.c_void_p()
+        if L.msw_comm_create_shm(name.encode(), int(rank), int(nranks), int(device), C.byref(out)) != 0:
+            raise MswError(L.msw_comm_last_error().decode())
+        return cls(out)
 
     def size(self):
         n, r = C.c_int(), C.c_int()

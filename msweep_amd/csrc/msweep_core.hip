@@ -24,6 +24,7 @@
 #include "pack_kernels.hpp"
 #include "compress_kernels.hpp"
 #include "comm.hpp"
+#include "shm_comm.hpp"
 #include "peer_comm.hpp"
 #include "likelihood_kernels.hpp"
 #include "bootstrap_kernels.hpp"
@@ -1225,6 +1226,23 @@ int msw_comm_create_local(int nranks, msw_comm_t *out) {
     return 0;
   } catch (const std::exception &ex) {
     for (int r = 0; r < nranks; ++r) delete out[r];
+    g_create_error = ex.what();
+    return 1;
+  }
+}
+
+int msw_comm_create_shm(const char *name, int rank, int nranks, int device, msw_comm_t *out) {
+  if (!out || !name || nranks < 1 || rank < 0 || rank >= nranks) {
+    g_create_error = "msw_comm_create_shm: bad arguments";
+    return 1;
+  }
+  try {
+    MSW_HIP(hipSetDevice(device));
+    std::unique_ptr<msw_comm> c(new ShmComm(name, rank, nranks));
+    if (peer_allreduce_requested() && nranks > 1) c.reset(new PeerComm(std::move(c), /*ipc=*/true));
+    *out = c.release();
+    return 0;
+  } catch (const std::exception &ex) {
     g_create_error = ex.what();
     return 1;
   }

@@ -153,7 +153,16 @@ struct PeerComm final : msw_comm {
     if (ipc) {
       hipIpcMemHandle_t hd;
       static_assert(sizeof(hd) <= 64, "hipIpcMemHandle_t is 64 bytes");
-      MSW_HIP(hipIpcGetMemHandle(&hd, fresh));
+      if (hipIpcGetMemHandle(&hd, fresh) != hipSuccess) {
+        // a runtime that exports no handle for a fine-grained allocation: an ordinary one instead -- every access
+        // of the kernel is a system-scope atomic (write-through stores, cache-bypassing loads) either way
+        (void)hipGetLastError();
+        (void)hipFree(fresh);
+        MSW_HIP(hipMalloc(reinterpret_cast<void **>(&fresh), total * 8));
+        MSW_HIP(hipMemsetAsync(fresh, 0, total * 8, stream));
+        MSW_HIP(hipStreamSynchronize(stream));
+        MSW_HIP(hipIpcGetMemHandle(&hd, fresh));
+      }
       std::memcpy(rec, &hd, sizeof hd);
     } else {
       std::memcpy(rec, &fresh, sizeof fresh);

@@ -44,7 +44,48 @@ def messages(n_ranks, rounds, seed):
     return msgs
 
 
+def main_process_rank():
+    """proc-messages | proc-solve  <n_ranks> <rank> <segment>: ONE rank per process (Comm.shm), all on cuda:0 -- the
+    process-per-rank set-up of the sharded solve and, with MSWEEP_ALLREDUCE=peer, the hipIpc-mapped inboxes."""
+    mode, n_ranks, rank, name = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    out = {"mode": mode, "n_ranks": n_ranks, "rank": rank}
+    core = Core(0)
+    comm = Comm.shm(name, rank, n_ranks)
+    if mode == "proc-messages":
+        msgs = messages(n_ranks, 2, 5)
+        sums = []
+        for ints, reals in msgs:
+            a, b, _ = comm.allreduce(ints[rank], reals[rank])
+            sums.append((a, b))
+        _, _, ms = comm.allreduce(msgs[4][0][rank], msgs[4][1][rank], repeats=200)
+        ok = True
+        for (ints, reals), (a, b) in zip(msgs, sums):
+            want_r = np.zeros(reals.shape[1])
+            for r in range(n_ranks):
+                want_r = want_r + reals[r]
+            ok = ok and np.array_equal(a, ints.sum(axis=0, dtype=np.uint64)) and np.array_equal(b, want_r)
+        out.update(ok=bool(ok), n_messages=len(msgs), ms_per_call_15004_words=ms)
+    else:
+        G = 200
+        p = synth.make_csr_problem(60000, G, seed=41, max_other=8)
+        bounds = shard_ecs(p["rowptr"], n_ranks)
+        blk = csr_block(p, bounds[rank], bounds[rank + 1])
+        lik = from_grouped_counts(core, blk["rowptr"], blk["grp"], blk["cnt"], blk["ec_counts"], p["group_sizes"])
+        core.set_comm(comm)
+        core.set_profiling(True)
+        rr = core.solve(lik.log_counts(), np.ones(G), tol=1e-6, algo=ALGO_RCG, max_iters=20000)
+        t = core.last_timing()
+        out.update(theta=rr["theta"].tolist(), iters=int(rr["iters"]), bound=float(rr["bound"]),
+                   collective_ms=float(t["collective_ms"]), collectives=int(t["collectives"]))
+        core.set_comm(None)
+    comm.close()
+    core.close()
+    print(json.dumps(out))
+
+
 def main():
+    if sys.argv[1].startswith("proc-"):
+        return main_process_rank()
     mode, n_ranks = sys.argv[1], int(sys.argv[2])
     out = {"mode": mode, "n_ranks": n_ranks}
     comms = Comm.local(n_ranks)

@@ -52,6 +52,47 @@ def test_peer_wait_is_bounded():
     assert "did not deliver its message" in r["said"][0], r
 
 
+def _run_processes(mode, n_ranks, **env):
+    """n_ranks worker PROCESSES, one rank each (Comm.shm), all on cuda:0."""
+    e = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+    name = f"/msweep_test_{os.getpid()}_{mode.replace('-', '_')}_{env.get('MSWEEP_ALLREDUCE', 'host')}"
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_allreduce_worker.py"), mode, str(n_ranks),
+                               str(r), name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)
+             for r in range(n_ranks)]
+    outs = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=240)
+            assert p.returncode == 0, so + se
+            outs.append(json.loads(so.strip().splitlines()[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return outs
+
+
+def test_peer_inboxes_over_hipipc_between_processes():
+    """One rank per PROCESS (three processes on this GPU, meeting in a shared-memory segment -- RCCL refuses two ranks on
+    one device): the inboxes are exchanged as hipIpc handles and written by the peers' kernels, as between the GPUs of
+    a node.  Messages against numpy; the sharded solve against the host-staged transport of the same processes and
+    against the thread-ranks, bit for bit."""
+    n = 3
+    for r in _run_processes("proc-messages", n, MSWEEP_ALLREDUCE="peer"):
+        assert r["ok"], r
+        print(f"\npeer all-reduce between {n} processes on one GPU (hipIpc inboxes), 15 004 words: "
+              f"{r['ms_per_call_15004_words'] * 1e3:.1f} us per call, rank {r['rank']}")
+    peer = _run_processes("proc-solve", n, MSWEEP_ALLREDUCE="peer")
+    host = _run_processes("proc-solve", n, MSWEEP_ALLREDUCE="rccl")
+    threads = _run("solve", n, MSWEEP_ALLREDUCE="rccl")
+    for r in range(n):
+        for other in (host[r], threads["ranks"][0]):
+            assert peer[r]["iters"] == other["iters"] and peer[r]["bound"] == other["bound"]
+            np.testing.assert_array_equal(peer[r]["theta"], other["theta"])
+    print(f"\n{n} processes: collective_ms per solve  peer {peer[0]['collective_ms']:.2f}  host-staged {host[0]['collective_ms']:.2f}  "
+          f"({peer[0]['collectives']} collectives)")
+
+
 def test_unknown_transport_is_refused():
     r = subprocess.run([sys.executable, "-c", "from msweep_amd.core import Comm; Comm.local(2)"], capture_output=True, text=True,
                        timeout=120, env=dict(os.environ, MSWEEP_ALLREDUCE="ring"), cwd=ROOT)
