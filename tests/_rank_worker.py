@@ -1,6 +1,7 @@
 """One rank of the multi-GPU tests (tests/test_gpu_multi.py): a fresh process that owns GPU `rank`.
-usage: _rank_worker.py RANK WORLD DIR -- the RCCL unique id travels through DIR/uid (rank 0 writes it), the
-results through DIR/out_RANK.npz."""
+usage: _rank_worker.py RANK WORLD DIR [shm] -- the RCCL unique id travels through DIR/uid (rank 0 writes it), the
+results through DIR/out_RANK.npz.  `shm`: every rank on GPU 0, the ranks meet in a shared-memory segment
+(msw_comm_create_shm) instead of an RCCL communicator, which refuses two ranks on one device."""
 import os
 import sys
 import time
@@ -21,8 +22,11 @@ def problem():
 
 def main():
     rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    shm = len(sys.argv) > 4 and sys.argv[4] == "shm"
     uid_path = os.path.join(d, "uid")
-    if rank == 0:
+    if shm:
+        uid = None
+    elif rank == 0:
         uid = Comm.unique_id()
         with open(uid_path + ".tmp", "wb") as f:
             f.write(uid)
@@ -34,11 +38,15 @@ def main():
                 sys.exit("rank %d: no unique id after 120 s" % rank)
             time.sleep(0.05)
         uid = open(uid_path, "rb").read()
-    comm = Comm.rccl(uid, rank, world, rank)
-    assert comm.size() == (world, rank) and comm.rccl_count() == world
+    if shm:
+        comm = Comm.shm("/msweep_rankworker_" + os.path.basename(d), rank, world, 0)
+        assert comm.size() == (world, rank) and comm.rccl_count() == 0
+    else:
+        comm = Comm.rccl(uid, rank, world, rank)
+        assert comm.size() == (world, rank) and comm.rccl_count() == world
     p, G = problem()
     alpha0 = np.ones(G)
-    core = Core(rank)
+    core = Core(0 if shm else rank)
     # (a) the replicate loop over the GPUs: every rank holds the whole likelihood
     from_grouped_counts(core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
     w = p["ec_counts"].astype(np.uint32)

@@ -22,21 +22,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def n_devices():
-    import torch
-    return torch.cuda.device_count()     # does not initialise the GPU
+    # through the HIP runtime the library itself is linked against (the handle of the `gpu_core` fixture has initialised
+    # it).  NOT through torch: its wheel brings a second copy of the ROCm runtime into the process, and a process that
+    # has used both aborts at exit ("double free or corruption" after pytest's summary, exit code 134)
+    import ctypes
+    n = ctypes.c_int(0)
+    rc = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))
+    return n.value if rc == 0 else 0
 
 
-# transport of the sharded solve's two all-reduces per iteration: ncclAllReduce (the default), or the one-shot kernel
-# that writes into the peers' inboxes over xGMI (hipIpc-mapped; msweep_amd/csrc/peer_comm.hpp) -- same bits either way
-@pytest.mark.parametrize("transport", ["rccl", "peer"])
-@pytest.mark.parametrize("world", [2, 4, 8])   # 8: the size of the machine the driver runs the scaling curve on
-def test_rccl_ranks_bootstrap_and_sharded_solve(gpu_core, tmp_path, world, transport):
-    if n_devices() < world:
-        pytest.skip(f"needs {world} GPUs, {n_devices()} visible")
+def _run_ranks(tmp_path, world, env, shm=False):
     d = str(tmp_path)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MSWEEP_ALLREDUCE=transport)
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rank_worker.py"), str(r), str(world), d],
-                              env=env) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rank_worker.py"), str(r), str(world), d]
+                              + (["shm"] if shm else []), env=env) for r in range(world)]
     try:
         rcs = [p.wait(timeout=600) for p in procs]
     finally:
@@ -44,7 +42,10 @@ def test_rccl_ranks_bootstrap_and_sharded_solve(gpu_core, tmp_path, world, trans
             if p.poll() is None:
                 p.kill()
     assert rcs == [0] * world, rcs
-    out = [np.load(os.path.join(d, f"out_{r}.npz")) for r in range(world)]
+    return [np.load(os.path.join(d, f"out_{r}.npz")) for r in range(world)]
+
+
+def _check_against_single_gpu(gpu_core, out, world):
     p = synth.make_csr_problem(60000, 200, seed=41, max_other=8)
     G, B = 200, 2 * world + 1
     lik = from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
@@ -59,3 +60,25 @@ def test_rccl_ranks_bootstrap_and_sharded_solve(gpu_core, tmp_path, world, trans
         assert int(out[r]["iters"]) == int(out[0]["iters"]) and float(out[r]["bound"]) == float(out[0]["bound"])
     assert int(out[0]["iters"]) == single["iters"]
     assert_theta(out[0]["theta"], single["theta"])
+
+
+# transport of the sharded solve's two all-reduces per iteration: ncclAllReduce (the default), or the one-shot kernel
+# that writes into the peers' inboxes over xGMI (hipIpc-mapped; msweep_amd/csrc/peer_comm.hpp) -- same bits either way
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+@pytest.mark.parametrize("world", [2, 4, 8])   # 8: the size of the machine the driver runs the scaling curve on
+def test_rccl_ranks_bootstrap_and_sharded_solve(gpu_core, tmp_path, world, transport):
+    if n_devices() < world:
+        pytest.skip(f"needs {world} GPUs, {n_devices()} visible")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MSWEEP_ALLREDUCE=transport)
+    _check_against_single_gpu(gpu_core, _run_ranks(tmp_path, world, env), world)
+
+
+@pytest.mark.parametrize("transport", ["rccl", "peer"])   # ("rccl" = the set-up communicator's own, host-staged here)
+def test_process_ranks_on_one_gpu_bootstrap_and_sharded_solve(gpu_core, tmp_path, transport):
+    """The same two modes with one PROCESS per rank on ONE GPU (runs on the one-GPU box): the ranks meet in a
+    shared-memory segment (msw_comm_create_shm) because RCCL refuses two ranks on one device.  What this covers that the
+    thread-ranks do not: a process per rank with its own HIP context, the block partition of the replicate stream by
+    rank, the gather of the table across processes, the hipIpc-mapped inboxes of the peer transport."""
+    world = 3
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MSWEEP_ALLREDUCE=transport, GPU_MAX_HW_QUEUES="8")
+    _check_against_single_gpu(gpu_core, _run_ranks(tmp_path, world, env, shm=True), world)
