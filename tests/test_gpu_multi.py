@@ -22,12 +22,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def n_devices():
-    # through the HIP runtime the library itself is linked against (the handle of the `gpu_core` fixture has initialised
-    # it).  NOT through torch: its wheel brings a second copy of the ROCm runtime into the process, and a process that
-    # has used both aborts at exit ("double free or corruption" after pytest's summary, exit code 134)
+    # through the HIP runtime this process ALREADY uses (the library is loaded RTLD_GLOBAL, its dependencies with it; the
+    # `gpu_core` fixture has initialised it).  Not through torch.cuda -- the torch wheel brings its own copy of the ROCm
+    # runtime: a process that first used the system's and then torch's aborts at exit ("double free or corruption" after
+    # pytest's summary, exit code 134) -- and not by loading /opt/rocm's libamdhip64.so by path: where torch came first
+    # (pytest imports every test module when it collects), that one does not resolve against torch's older HSA runtime
     import ctypes
+    from msweep_amd.core import load_library
+    load_library()
     n = ctypes.c_int(0)
-    rc = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))
+    rc = ctypes.CDLL(None).hipGetDeviceCount(ctypes.byref(n))
     return n.value if rc == 0 else 0
 
 
