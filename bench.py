@@ -625,13 +625,22 @@ def main():
     OUT = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     dist = None
+    # MSWEEP_BENCH_ONE_GPU=1 (developer switch, a FUNCTIONAL rehearsal of the N > 1 code of this file on a box with one
+    # GPU, never a measurement): every rank on device 0, torch.distributed over gloo, the library's ranks meeting in a
+    # shared-memory segment (msw_comm_create_shm) -- RCCL, torch's and the library's, refuses two ranks on one device
+    one_gpu = os.environ.get("MSWEEP_BENCH_ONE_GPU", "0") == "1" and world > 1
+    if one_gpu:
+        local_rank = 0
     if world > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     n_gpus = world
 
     import numpy as np
@@ -644,12 +653,16 @@ def main():
     if dist is not None:
         # the library's own RCCL communicator (C ABI: msw_comm_create_rccl); torch.distributed only
         # carries the unique id and the barriers around the timed region
-        uid = [Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = Comm.rccl(uid[0], rank, world, local_rank)
-        rccl_ranks = comm.rccl_count()     # ncclCommCount
-        if rccl_ranks != world:
-            sys.exit(f"bench.py: RCCL communicator spans {rccl_ranks} ranks, expected {world}")
+        if one_gpu:
+            comm = Comm.shm("/msweep_bench_" + os.environ["MASTER_PORT"], rank, world, 0)
+            rccl_ranks = "none: MSWEEP_BENCH_ONE_GPU rehearsal, all ranks on one device (NOT a measurement)"
+        else:
+            uid = [Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = Comm.rccl(uid[0], rank, world, local_rank)
+            rccl_ranks = comm.rccl_count()     # ncclCommCount
+            if rccl_ranks != world:
+                sys.exit(f"bench.py: RCCL communicator spans {rccl_ranks} ranks, expected {world}")
     boot_comm = comm if comm is not None else Comm.local(1)[0]   # one rank: the in-process communicator
     if shard:
         core.set_comm(comm)      # before the likelihood: cfg5's --min-hits counts are all-reduced over the EC shards
@@ -786,7 +799,8 @@ def main():
                         "k_finstep, k_redfin (redundant on every rank) and the launch boundaries"}
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64).cuda()
+        tt = torch.tensor([dt], dtype=torch.float64)
+        tt = tt if one_gpu else tt.cuda()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -803,7 +817,8 @@ def main():
         tb = time.perf_counter() - t1
         if dist is not None:
             import torch
-            tt = torch.tensor([tb], dtype=torch.float64).cuda()
+            tt = torch.tensor([tb], dtype=torch.float64)
+            tt = tt if one_gpu else tt.cuda()
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tb = float(tt.item())
         B = a.bootstrap_per_rank * world

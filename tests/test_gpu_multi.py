@@ -86,3 +86,24 @@ def test_process_ranks_on_one_gpu_bootstrap_and_sharded_solve(gpu_core, tmp_path
     world = 3
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MSWEEP_ALLREDUCE=transport, GPU_MAX_HW_QUEUES="8")
     _check_against_single_gpu(gpu_core, _run_ranks(tmp_path, world, env, shm=True), world)
+
+
+@pytest.mark.parametrize("mode,transport", [("replicates", "rccl"), ("shard", "peer")])
+def test_bench_with_two_ranks_on_one_gpu(mode, transport):
+    """bench.py's N > 1 code (its own launcher, the per-rank replicate, the barriers and the max over ranks around the
+    timed region, the sharded workload, the one JSON line from rank 0) rehearsed with two rank processes on ONE GPU:
+    MSWEEP_BENCH_ONE_GPU=1 -- torch.distributed over gloo, the library's ranks in a shared-memory segment.  A functional
+    check, not a measurement (the line says so in `rccl_ranks`)."""
+    import json
+    env = dict(os.environ, MSWEEP_BENCH_ONE_GPU="1", MSWEEP_ALLREDUCE=transport, GPU_MAX_HW_QUEUES="8",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+           "--reads", "300000", "--groups", "300", "--mode", mode]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and "rehearsal" in d["rccl_ranks"]
+    if mode == "shard":
+        assert d["shard_split_ms_per_step"]["allreduce"] == "peer" and d["shard_split_ms_per_step"]["collectives_per_step"] >= 2
+    else:
+        assert d["bootstrap_cfg4"]["replicates"] == 2 * d["bootstrap_cfg4"]["per_rank"]
