@@ -853,7 +853,8 @@ def main():
                     continue
         gb = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         sharding = "single solve" if n_gpus == 1 else (
-            f"one solve, ECs sharded over {n_gpus} GPUs, RCCL all-reduce of (G+4) fp64 per iteration" if shard else
+            f"one solve, ECs sharded over {n_gpus} GPUs, {os.environ.get('MSWEEP_ALLREDUCE', 'rccl')} all-reduce of 1 double and "
+            "of 3 G integers + 4 doubles per iteration" if shard else
             f"bootstrap replicates, 1 per GPU x {n_gpus}: every rank solves on its replicate's RESAMPLED counts (a third of "
             "the ECs at zero, one in fifty at four or more), a different trajectory from the original counts the "
             "single-GPU line solves on")
