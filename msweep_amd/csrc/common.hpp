@@ -25,6 +25,14 @@ constexpr int kPassThreadsB = MSW_PASS_THREADS_B;
 constexpr int kMaxTrace = 4096;
 constexpr int kRedfinParts = 5;    // doubles per workgroup of k_redfin's partial sums (state_kernels.hpp)
 constexpr int kRedfinGroups = 16;  // groups per workgroup of k_redfin
+// (512 threads: at k_redfin's 68 registers three such workgroups share a CU, so cfg3's 313 workgroups run in ONE round
+// on 256 CUs; with 1024 threads a workgroup is alone on its CU and 57 CUs ran two, one after the other: -3 us per
+// iteration at 5 000 groups in same-box A/Bs, nothing at 2 000)
+#ifndef MSW_REDFIN_THREADS
+#define MSW_REDFIN_THREADS 512
+#endif
+constexpr int kRedfinThreads = MSW_REDFIN_THREADS;           // 512 | 1024: threads per workgroup of k_redfin
+constexpr int kRedfinSlots = kRedfinThreads / kRedfinGroups;  // row slots that meet in LDS
 // column sums of the CSR sweeps as 64-bit fixed point + integer atomics (sweep_kernels.hpp); 0 = fp64
 // atomics, an A/B timing build only
 #ifndef MSW_FX

@@ -598,13 +598,13 @@ void launch_passB(msw_core *h) {
                                h->stream);
     }
     if (evc) MSW_HIP(hipEventRecord(evc->second, h->stream));
-    hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(1024), 0, h->stream,
+    hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(kRedfinThreads), 0, h->stream,
                        h->sc.p, (int)h->G, 0, fxrows, reinterpret_cast<unsigned long long *>(h->commB.p) + h->G, 0, 1,
                        h->partAcc.p, h->commB.p, h->commB.p + G3, h->e.p, h->u.p,
                        h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p, h->totS.p);
     return;
   }
-  hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(1024), 0, h->stream,
+  hipLaunchKernelGGL(k_redfin, dim3((h->G + kRedfinGroups - 1) / kRedfinGroups), dim3(kRedfinThreads), 0, h->stream,
                      h->sc.p, (int)h->G, partials ? nb : 0, fxrows, fxrows ? h->guard_tail.p : nullptr, 1, nb,
                      h->partAcc.p, h->Acc.p, h->partS.p, h->e.p,
                      h->u.p, h->alpha0.p, h->Nc.p, h->N.p, h->w.p, h->ew.p, h->partR.p, h->totS.p);

@@ -379,20 +379,20 @@ __global__ __launch_bounds__(1024) void k_finstep(Scalars *sc, int mode, int G, 
 // preparation {e_g, w_g - kappa} with its sums S0 = sum e, S1 = sum e*s0, S2 = sum e*s0^2
 // (s0_g = w_g - kappa: the step value of a background cell relative to which pass A measures the
 // listed cells; kappa = lagged centring constant, advanced by k_finstep to the e-weighted mean just measured:
-// kappa += S1 / S0).  One 1024-thread workgroup per
+// kappa += S1 / S0).  One workgroup of kRedfinThreads = 512 threads per
 // kRedfinGroups = 16 groups (313 workgroups at 5k groups: the 10 MB of partial rows pass B left
-// behind are read by the whole chip, not by 79 CUs): thread t sums rows t/16, t/16 + 64, ... of
-// group t%16 (a row's 16 groups are one 128-byte line), 64 row slots meet in LDS in fixed order.
+// behind are read by the whole chip, not by 79 CUs): thread t sums rows t/16, t/16 + 32, ... of
+// group t%16 (a row's 16 groups are one 128-byte line), 32 row slots meet in LDS in fixed order.
 //   nblk > 0: sum partAcc[b*G + g] over b;  nblk == 0: Acc already holds the totals.
 // Block 0 also leaves the totals of the per-workgroup ELBO terms for k_finstep in totS[0..2].
-__global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int nblk, int fxrows,
+__global__ __launch_bounds__(kRedfinThreads) void k_redfin(const Scalars *sc, int G, int nblk, int fxrows,
                                                 unsigned long long *tail, int zero_tail,
                                                 int npartS, const double *partAcc, const double *Acc,
                                                 const double *partS, const double *e, const double *u,
                                                 const double *alpha0, double *Nc, double *N, double *w,
                                                 double2 *ew, double *partR, double *totS) {
   __shared__ double sh[48];
-  __shared__ double accs[64][kRedfinGroups];
+  __shared__ double accs[kRedfinSlots][kRedfinGroups];
   const int tid = threadIdx.x, gl = tid & (kRedfinGroups - 1), rs = tid >> 4;
   const int g = blockIdx.x * kRedfinGroups + gl;
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 3, 0);
@@ -406,9 +406,9 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
     if (nblk > 0) {
       if (fx) {
         const long long *pi = reinterpret_cast<const long long *>(partAcc);
-        for (int b = rs; b < nblk; b += 64) si += pi[(size_t)b * G + g];
+        for (int b = rs; b < nblk; b += kRedfinSlots) si += pi[(size_t)b * G + g];
       } else {
-        for (int b = rs; b < nblk; b += 64) s += partAcc[(size_t)b * G + g];
+        for (int b = rs; b < nblk; b += kRedfinSlots) s += partAcc[(size_t)b * G + g];
       }
     } else if (rs == 0) {
       if (fx) si = reinterpret_cast<const long long *>(Acc)[g];
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
   // W = sum_j r_j (and, for k_finstep, the other two ELBO sums): every workgroup forms them in the
   // same fixed order
   double t[3] = {0.0, 0.0, 0.0};
-  for (int b = tid; b < npartS; b += 1024) {
+  for (int b = tid; b < npartS; b += kRedfinThreads) {
     t[0] += partS[4 * b];
     t[1] += partS[4 * b + 1];
     t[2] += partS[4 * b + 2];
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
   }
   accs[rs][gl] = s;
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(s0.iter, 3, 1);
-  block_sum_fixed<3, 16>(t, sh);  // its barriers also publish accs
+  block_sum_fixed<3, kRedfinThreads / 64>(t, sh);  // its barriers also publish accs
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(s0.iter, 3, 2);
   const double W = t[2];
   if (blockIdx.x == 0 && tid == 0) {
@@ -462,10 +462,10 @@ __global__ __launch_bounds__(1024) void k_redfin(const Scalars *sc, int G, int n
     long long ai = 0;
     if (fx) {
 #pragma unroll
-      for (int i = 0; i < 64; ++i) ai += __double_as_longlong(accs[i][gl]);
+      for (int i = 0; i < kRedfinSlots; ++i) ai += __double_as_longlong(accs[i][gl]);
     } else {
 #pragma unroll
-      for (int i = 0; i < 64; ++i) A += accs[i][gl];
+      for (int i = 0; i < kRedfinSlots; ++i) A += accs[i][gl];
     }
     double nc;
     const double ug = ug0;
