@@ -593,6 +593,19 @@ def bootstrap_leg(core, comm, w, per_rank, world, G):
     return dt, iters, bt
 
 
+def iteration_histogram(iters):
+    """RCG iterations to --tol 1e-6 over the replicates: extremes, quartiles and counts per bin of 5."""
+    import numpy as np
+    it = np.asarray(iters, np.int64)
+    if it.size == 0:
+        return None
+    lo = int(it.min()) // 5 * 5
+    bins = np.bincount((it - lo) // 5)
+    return {"min": int(it.min()), "q25": float(np.percentile(it, 25)), "median": float(np.median(it)),
+            "q75": float(np.percentile(it, 75)), "max": int(it.max()), "mean": float(it.mean()),
+            "bins_of_5": {str(lo + 5 * i): int(n) for i, n in enumerate(bins) if n}}
+
+
 def main():
     a = parse()
     if a.gpus < 1:
@@ -737,7 +750,8 @@ def main():
         cells = float(E) * G * tot_iters
         line_extra = {"replicates": steps_total, "replicates_per_sec": steps_total / dt,
                       "iterations_per_replicate": [int(x) for x in iters],
-                      "rank0_split_ms": {k: bt[k] for k in ("table_ms", "solve_ms", "gather_ms")},
+                      "iterations_histogram": iteration_histogram(iters),
+                      "rank0_split_ms": {k: bt[k] for k in ("table_ms", "solve_ms", "gather_ms", "table_reused")},
                       "iters_per_sec": tot_iters / dt, "listed_cells_per_sec": float(nnz) * tot_iters / dt,
                       "reads_x_groups_cells_per_sec": float(wl["reads"]) * G * tot_iters / dt}
         # per-kernel durations for the roofline object: a fixed-iteration solve with events, as for cfg3
@@ -824,7 +838,7 @@ def main():
         B = a.bootstrap_per_rank * world
         boot = {"replicates": B, "per_rank": a.bootstrap_per_rank, "seconds": tb, "replicates_per_sec": B / tb,
                 "iterations": [int(x) for x in iters], "cells_per_sec": float(E) * G * float(iters.sum()) / tb,
-                "rank0_split_ms": {k: bt[k] for k in ("table_ms", "solve_ms", "gather_ms")},
+                "rank0_split_ms": {k: bt[k] for k in ("table_ms", "solve_ms", "gather_ms", "table_reused")},
                 "what": "msw_core_bootstrap_dist(--seed 42): every rank seeks (GF(2) jump-ahead) to its block of the one "
                         "mt19937_64 stream, resamples and solves its replicates to --tol 1e-6, ONE all-gather of the "
                         "B x (G + 1) table; max over ranks of the host wall clock, barrier on both sides"}

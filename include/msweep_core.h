@@ -322,6 +322,7 @@ typedef struct msw_bootstrap_timing {
   double gather_ms;     /* msw_core_bootstrap_dist: the all-gather, waiting for the slowest rank included */
   uint64_t replicates;  /* solved on this rank */
   uint64_t iterations;  /* summed over them */
+  uint64_t table_reused; /* 1: the call brought the EC counts of the resident table again (compared, not rebuilt) */
 } msw_bootstrap_timing;
 int msw_core_last_bootstrap_timing(msw_handle h, msw_bootstrap_timing *out);
 /* Reporting (tests, diagnostics): how many equivalence classes pass B has evaluated through the cancellation guard

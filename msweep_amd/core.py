@@ -57,7 +57,7 @@ class LayoutInfo(C.Structure):
 
 class BootstrapTiming(C.Structure):
     _fields_ = [("table_ms", C.c_double), ("solve_ms", C.c_double), ("gather_ms", C.c_double),
-                ("replicates", C.c_uint64), ("iterations", C.c_uint64)]
+                ("replicates", C.c_uint64), ("iterations", C.c_uint64), ("table_reused", C.c_uint64)]
 
 
 _lib = None

@@ -116,6 +116,8 @@ struct msw_core {
 
   // ---- bootstrap -------------------------------------------------------------------------
   DevBuf<double> cp;
+  std::vector<uint32_t> cp_counts;  // the EC counts `cp` was made from (host_bootstrap.inc: kept across calls)
+  bool cp_hit = false;              // ... and whether the last call found them again
   DevBuf<uint64_t> mtwords;
   DevBuf<uint32_t> bcounts, bcounts2;
   DevBuf<MtState> mt;

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <random>
+#include <sstream>
 #include <vector>
 
 extern "C" {
@@ -27,6 +28,26 @@ void orc_bootstrap_counts_stdlib(const uint32_t *weights, size_t n_ecs, int32_t 
       size_t ec_id = ec_distribution(gen);
       tmp_counts[ec_id] += 1;
     }
+    std::copy(tmp_counts.begin(), tmp_counts.end(), out + r * n_ecs);
+  }
+}
+
+// The same replicate loop entered in the MIDDLE of the stream: the generator takes the state libstdc++ itself
+// printed (operator<< of std::mt19937_64: 312 words, then the position of the next word) after stepping there --
+// tests/golden/mt_deep_state.json holds it for the start of replicate 999 of BASELINE config 4, which is 10^10 - 10^7
+// words from the seed (src/mSWEEP.cpp:496-518 gets there by drawing the 999 replicates before it).
+void orc_bootstrap_counts_stdlib_from_state(const uint32_t *weights, size_t n_ecs, const uint64_t *state312,
+                                            uint64_t pos, size_t bootstrap_count, size_t n_reps, uint32_t *out) {
+  std::ostringstream os;
+  for (int i = 0; i < 312; ++i) os << state312[i] << ' ';
+  os << pos;
+  std::istringstream is(os.str());
+  std::mt19937_64 gen;
+  is >> gen;
+  std::discrete_distribution<uint32_t> ec_distribution(weights, weights + n_ecs);
+  for (size_t r = 0; r < n_reps; ++r) {
+    std::vector<uint32_t> tmp_counts(n_ecs);
+    for (size_t i = 0; i < bootstrap_count; ++i) tmp_counts[ec_distribution(gen)] += 1;
     std::copy(tmp_counts.begin(), tmp_counts.end(), out + r * n_ecs);
   }
 }

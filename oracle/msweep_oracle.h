@@ -131,6 +131,10 @@ size_t orc_em_dense_opts(const double *logl, size_t G, size_t E, const double *l
 void orc_bootstrap_counts_stdlib(const uint32_t *weights, size_t n_ecs, int32_t seed,
                                  size_t bootstrap_count, size_t n_reps,
                                  uint32_t *counts_out);
+/* the libstdc++ replicate loop entered in the middle of the stream, from a state libstdc++ printed itself
+ * (operator<< of std::mt19937_64: 312 words + position; tests/golden/mt_deep_state.json) */
+void orc_bootstrap_counts_stdlib_from_state(const uint32_t *weights, size_t n_ecs, const uint64_t *state312,
+                                            uint64_t pos, size_t bootstrap_count, size_t n_reps, uint32_t *out);
 /* From-scratch restatement of the same stream (MT19937-64 + generate_canonical +
  * lower_bound on the normalised partial sums); this is what the GPU path mirrors. */
 void orc_bootstrap_counts_restated(const uint32_t *weights, size_t n_ecs, int32_t seed,

@@ -81,6 +81,7 @@ class Oracle:
                                         C.POINTER(_EmOpts), C.c_void_p, _dp, C.POINTER(C.c_double)]
         L.orc_bootstrap_counts_stdlib.argtypes = [_u32p, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, _u32p]
         L.orc_bootstrap_counts_restated.argtypes = [_u32p, C.c_size_t, C.c_int32, C.c_size_t, C.c_size_t, _u32p]
+        L.orc_bootstrap_counts_stdlib_from_state.argtypes = [_u32p, C.c_size_t, _u64p, C.c_uint64, C.c_size_t, C.c_size_t, _u32p]
         L.orc_discrete_cp.argtypes = [_u32p, C.c_size_t, _dp]
         L.orc_mt19937_64_words.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, _u64p]
         L.orc_dirichlet_kld_rate.argtypes = [_dp, C.c_size_t, C.c_size_t, _dp, _dp, _dp, _dp]
@@ -216,6 +217,15 @@ class Oracle:
         out = np.empty((n_reps, len(w)), np.uint32)
         f = self.lib.orc_bootstrap_counts_restated if restated else self.lib.orc_bootstrap_counts_stdlib
         f(w, len(w), int(seed), int(bootstrap_count), int(n_reps), out)
+        return out
+
+    def bootstrap_counts_from_state(self, weights, state312, pos, bootstrap_count, n_reps=1):
+        """libstdc++'s replicate loop from a state libstdc++ printed (tests/golden/mt_deep_state.json)."""
+        w = np.ascontiguousarray(weights, np.uint32)
+        st = np.ascontiguousarray(state312, np.uint64)
+        assert st.shape == (312,)
+        out = np.empty((n_reps, len(w)), np.uint32)
+        self.lib.orc_bootstrap_counts_stdlib_from_state(w, len(w), st, int(pos), int(bootstrap_count), int(n_reps), out)
         return out
 
     def discrete_cp(self, weights):

@@ -4,8 +4,11 @@
 #include <array>
 #include <cstdint>
 #include <cstdio>
+#include <fstream>
 #include <random>
+#include <sstream>
 #include <stdexcept>
+#include <string>
 
 #include "host_mtjump.inc"
 
@@ -26,8 +29,39 @@ static std::array<uint64_t, 312> seeded(uint64_t x) {
   return w;
 }
 
-int main() {
+// deep positions no test can step to in seconds: libstdc++'s own state there (tests/golden/mt_deep_state.json, written by
+// discard() in gen_mt_deep_state.cpp), handed over by tests/test_mtjump.py as lines of `seed skip w0 .. w311 pos`
+static int deep_cases(const char *path) {
   int bad = 0;
+  std::ifstream in(path);
+  std::string line;
+  while (std::getline(in, line)) {
+    if (line.empty()) continue;
+    std::istringstream is(line);
+    long long seed;
+    unsigned long long skip;
+    is >> seed >> skip;
+    std::mt19937_64 ref;
+    is >> ref;  // 312 words + position, as operator<< printed them
+    if (!is) {
+      std::printf("deep: unreadable state line\n");
+      return 1;
+    }
+    auto w = seeded((uint64_t)(int64_t)(int32_t)seed);
+    mtjump::jump(w, skip);
+    mtjump::Window win;
+    win.w = w;
+    bool ok = true;
+    for (int i = 0; i < 2000; ++i) ok &= temper(win.step()) == ref();
+    std::printf("deep jump seed %lld skip %llu %s\n", seed, skip, ok ? "ok" : "MISMATCH");
+    bad += !ok;
+  }
+  return bad;
+}
+
+int main(int argc, char **argv) {
+  int bad = 0;
+  if (argc > 1) return deep_cases(argv[1]) ? 1 : 0;
   const uint64_t seed = (uint64_t)(int64_t)(int32_t)-7;  // how std::mt19937_64(int32) widens
   for (uint64_t J : {0ull, 1ull, 155ull, 156ull, 311ull, 312ull, 313ull, 1000003ull, (1ull << 27) + 12345ull}) {
     auto w = seeded(seed);

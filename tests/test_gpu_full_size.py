@@ -244,6 +244,60 @@ def test_cfg4_bootstrap_10M_x_5k(gpu_core, oracle_mt, cfg3):
         assert theta[b].sum() == pytest.approx(1.0, abs=1e-11)       # normalised by the resampled total (:513)
 
 
+def test_cfg4_last_replicate_of_1000_is_bit_exact(gpu_core, oracle_mt, cfg3):
+    """BASELINE config 4 is `--iters 1000` (src/mSWEEP.cpp:132,498): replicate 999 of cfg3's counts starts
+    999 * 10^7 = 9.99e9 words into the ONE mt19937_64(--seed 42) stream.  The device gets there by the host's GF(2)
+    jump-ahead; the reference by drawing the 999 replicates before it.  tests/golden/mt_deep_state.json holds
+    libstdc++'s OWN generator state at that word (84 s of std::mt19937_64::discard, gen_mt_deep_state.cpp): the
+    oracle resumes libstdc++'s mt19937_64 + discrete_distribution<uint32_t> from it (10^7 draws over cfg3's 9.4 M
+    ECs) and the device's counts must be the same bits.  Then the cumulative table: a second bootstrap call with the
+    same EC counts must reuse the resident one (33.6 ms per call in round 4)."""
+    import json
+    p, G = cfg3, 5000
+    from_grouped_counts(gpu_core, p["rowptr"], p["grp"], p["cnt"], p["ec_counts"], p["group_sizes"])
+    w = p["ec_counts"].astype(np.uint32)
+    draws = int(w.sum())
+    assert draws == 10_000_000
+    case = next(c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mt_deep_state.json")))["cases"]
+                if c["seed"] == 42 and c["skip"] == 999 * draws)
+    t0 = time.time()
+    ref = oracle_mt.bootstrap_counts_from_state(w, np.array(case["state"], np.uint64), case["pos"], draws, 1)
+    t1 = time.time()
+    got = gpu_core.resample_counts(w, 42, draws, 999, 1000)
+    t2 = time.time()
+    print(f"replicate 999: libstdc++ from its own state at word {case['skip']}: {t1 - t0:.1f} s; device (jump-ahead + "
+          f"resampling + download) {t2 - t1:.2f} s; {int((got[0] == 0).sum())} ECs drawn zero times")
+    np.testing.assert_array_equal(got, ref)
+    assert int(got.sum()) == draws
+    # ... and a block that STEPS over a replicate boundary after the jump (998 -> 999), as a rank's block does
+    np.testing.assert_array_equal(gpu_core.resample_counts(w, 42, draws, 998, 1000)[1], ref[0])
+    # the cumulative table stays resident across calls that bring the same counts
+    alpha0 = np.ones(G)
+    th1, it1 = gpu_core.bootstrap(w, 42, draws, 999, 1000, alpha0)
+    bt1 = gpu_core.last_bootstrap_timing()
+    th2, it2 = gpu_core.bootstrap(w, 42, draws, 999, 1000, alpha0)
+    bt2 = gpu_core.last_bootstrap_timing()
+    print(f"table_ms: first bootstrap call after resample_counts {bt1['table_ms']:.2f} (reused {bt1['table_reused']}), "
+          f"second {bt2['table_ms']:.2f} (reused {bt2['table_reused']})")
+    assert bt1["table_reused"] == 1 and bt2["table_reused"] == 1 and bt2["table_ms"] < 5.0
+    np.testing.assert_array_equal(th1, th2)
+    assert it1.tolist() == it2.tolist()
+    # the solve of replicate 999 against the oracle on libstdc++'s counts
+    with np.errstate(divide="ignore"):
+        logc = np.log(ref[0].astype(float))
+    k = int(it1[0])
+    ref_tr = oracle_csr_trace(oracle_mt, p, logc, alpha0, k + 16)
+    r, g, a = worst(th1[0], ref_tr["theta"][k - 1])
+    print(f"cfg4 replicate 999: iterations hip {k} / oracle {oracle_stop(ref_tr)}; worst rel err {r:.2e}, abs below floor {a:.2e}")
+    assert r <= REL and a <= ABS
+    assert_stop_within_noise(k, ref_tr, "cfg4 replicate 999")
+    # changed counts are NOT served from the kept table
+    w2 = w.copy()
+    w2[len(w2) // 2] += 1
+    gpu_core.bootstrap(w2, 42, draws, 0, 1, alpha0)
+    assert gpu_core.last_bootstrap_timing()["table_reused"] == 0
+
+
 def test_cfg2_dense_1M_x_500_lockstep(gpu_core, oracle_mt):
     """cfg2's own criterion ("match CPU abundances to 1e-6") at its own size, through the dense
     boundary rcg_optl hands over (msw_core_set_dense_logl), against the structured oracle on the dense

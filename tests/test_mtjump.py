@@ -1,16 +1,38 @@
 """CPU: the MT19937-64 jump-ahead (host side of the multi-GPU bootstrap seek) against libstdc++'s
 std::mt19937_64::discard -- the stream the reference draws its replicates from
 (src/BootstrapSample.cpp:60-73)."""
+import json
 import os
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_jump_ahead_matches_libstdcxx_discard(tmp_path):
+def _build(tmp_path):
     exe = str(tmp_path / "mtjump_test")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "msweep_amd", "csrc"), "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "mtjump_test.cpp")])
+    return exe
+
+
+def test_jump_ahead_matches_libstdcxx_discard(tmp_path):
+    exe = _build(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count(" ok") == 10 and "MISMATCH" not in out.stdout
+
+
+def test_jump_ahead_reaches_the_last_replicate_of_cfg4(tmp_path):
+    """BASELINE config 4 (`--iters 1000 --seed 42`, 10^7 aligned reads): replicate 999 starts 9.99e9 words into the
+    stream.  The fixture holds libstdc++'s own generator state there (84 s of discard(), tests/golden/
+    gen_mt_deep_state.cpp); the host jump must land on it: the next 2000 words agree."""
+    exe = _build(tmp_path)
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "mt_deep_state.json")))["cases"]
+    assert any(c["seed"] == 42 and c["skip"] == 9_990_000_000 for c in cases)
+    path = tmp_path / "deep.txt"
+    with open(path, "w") as f:
+        for c in cases:
+            f.write(f"{c['seed']} {c['skip']} " + " ".join(str(x) for x in c["state"]) + f" {c['pos']}\n")
+    out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(" ok") == len(cases) and "MISMATCH" not in out.stdout

@@ -32,3 +32,22 @@ def test_restated_equals_stdlib_on_larger_inputs(oracle):
     assert np.all(a[:, w == 0] == 0)
     cp = oracle.discrete_cp(w)
     assert cp[-1] == 1.0 and np.all(np.diff(cp) >= 0)
+
+
+def test_from_state_resumes_libstdcxx_deep_in_the_stream(oracle):
+    """tests/golden/mt_deep_state.json: libstdc++'s own mt19937_64 state 9.99e9 words in (the start of replicate 999
+    of BASELINE config 4) and the 16 words it produced next.  The oracle's from-state replicate loop must consume
+    exactly those words: counts = lower_bound of double(word) * 2^-64 on the normalised partial sums."""
+    g = load_golden("mt_deep_state.json")
+    rng = np.random.default_rng(4)
+    w = rng.integers(1, 50, 37).astype(np.uint32)
+    cp = oracle.discrete_cp(w)
+    for c in g["cases"]:
+        words = np.array(c["next_words"], np.uint64)
+        p = np.minimum(words.astype(np.float64) * 2.0 ** -64, np.nextafter(1.0, 0.0))
+        exp = np.bincount(np.searchsorted(cp, p, side="left"), minlength=len(w)).astype(np.uint32)
+        got = oracle.bootstrap_counts_from_state(w, np.array(c["state"], np.uint64), c["pos"], len(words), 1)
+        np.testing.assert_array_equal(got[0], exp)
+    # and at a depth the restated generator can step to: the seed-42 stream's words [1.5e9, 1.5e9 + 16)
+    c = next(c for c in g["cases"] if c["skip"] == 1_500_000_000)
+    assert oracle.mt_words(42, c["skip"], 16).tolist() == c["next_words"]
