@@ -26,7 +26,10 @@ timed region).  Every cfg3 line (any N) also carries `bootstrap_cfg4`: a short r
 (msw_core_bootstrap_dist, fixed replicates per rank).  Scaling is "weak" (per-GPU work fixed).  Launched either by
 torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or plainly as
 `python bench.py --gpus N`: the parent then starts the N rank processes itself BEFORE anything touches the GPU
-(it never initialises HIP), relays rank 0's line and exits non-zero if any rank fails.
+(it never initialises HIP), relays rank 0's line and exits non-zero if any rank fails.  Either way a rank process
+never imports torch (round 5): the barriers around the timed region, the max over ranks and the all-gather of the
+abundances are collectives of the library's own RCCL communicator, whose unique id travels from rank 0 to the others
+through a unix socket of their own (class Star).
 
 Prints ONE JSON line on rank 0.
 """
@@ -43,9 +46,29 @@ OUT = sys.stdout
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 METRIC = "EM iters/sec + reads×groups cells/sec, 10M reads × 5k groups"
 # HBM bytes per launch of the sweeps (rocprofv3 PMC passes, committed): newest file that covers the workload
-TRAFFIC_JSON = {"cfg3": ["r04_traffic_pmc.json", "r03_traffic_pmc.json"], "cfg2": ["r04_cfg2_traffic_pmc.json", "r03_cfg2_traffic_pmc.json"],
-                "cfg5": ["r04_cfg5_traffic_pmc.json", "r03_cfg5_traffic_pmc.json"],
-                "cfg4": ["r04_traffic_pmc.json", "r03_traffic_pmc.json"]}
+TRAFFIC_JSON = {"cfg3": ["r05_traffic_pmc.json", "r04_traffic_pmc.json", "r03_traffic_pmc.json"],
+                "cfg2": ["r05_cfg2_traffic_pmc.json", "r04_cfg2_traffic_pmc.json", "r03_cfg2_traffic_pmc.json"],
+                "cfg5": ["r05_cfg5_traffic_pmc.json", "r04_cfg5_traffic_pmc.json", "r03_cfg5_traffic_pmc.json"],
+                "cfg4": ["r05_traffic_pmc.json", "r04_traffic_pmc.json", "r03_traffic_pmc.json"],
+                "cfg2-dense": ["r05_cfg2_dense_traffic_pmc.json"],       # MSWEEP_DENSE_COMPRESS=0: k_dense_passA / B
+                "cfg3-diverse": ["r05_diverse_traffic_pmc.json", "r04_diverse_traffic_pmc.json", "r03_diverse_traffic_pmc.json"],
+                "cfg4-diverse": ["r05_diverse_traffic_pmc.json", "r04_diverse_traffic_pmc.json", "r03_diverse_traffic_pmc.json"]}
+N_CU, N_SE, SIMD_PER_CU = 256, 32, 4   # MI355X: 8 XCDs x 32 CUs, 4 shader engines per XCD (the SQ_BUSY_CYCLES instances)
+
+
+def pmc_bound(entry):
+    """Which resource the kernel keeps busy, from its committed rocprofv3 --pmc averages per launch (tools/pmc_traffic.py):
+    kernel cycles = SQ_BUSY_CYCLES / 32 (one instance per shader engine); LDS busy = SQ_LDS_IDX_ACTIVE (summed over the
+    CUs) / (256 x kernel cycles); VALU busy = 4 x SQ_ACTIVE_INST_VALU (quad-cycles, summed over the SIMDs) /
+    (1024 x kernel cycles); conflicts = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."""
+    try:
+        cyc = entry["SQ_BUSY_CYCLES"] / N_SE
+        return {"lds_busy_frac": entry["SQ_LDS_IDX_ACTIVE"] / (N_CU * cyc),
+                "lds_conflict_frac": entry["SQ_LDS_BANK_CONFLICT"] / max(entry["SQ_LDS_IDX_ACTIVE"], 1.0),
+                "valu_busy_frac": 4.0 * entry["SQ_ACTIVE_INST_VALU"] / (N_CU * SIMD_PER_CU * cyc),
+                "kernel_cycles": cyc}
+    except (KeyError, ZeroDivisionError, TypeError):
+        return None
 
 
 def parse():
@@ -71,6 +94,10 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--bootstrap-per-rank", type=int, default=4,
                     help="cfg3: replicates per rank of the bootstrap_cfg4 leg (0 = skip)")
+    ap.add_argument("--cpu-legs-only", action="store_true",
+                    help="(internal) the CPU baseline legs of --config cfg3 / cfg2 in a process of their own: bench.py "
+                         "starts it with OMP_PROC_BIND=close and OMP_PLACES set (BASELINE.md 2); no GPU is touched")
+    ap.add_argument("--cpu-probe", action="store_true", help="(internal, with --cpu-legs-only) a two-second OpenMP probe")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="(tests) exercise the rank launcher and the rendezvous on CPU/gloo only: no GPU, no workload")
     ap.add_argument("--mode", choices=["replicates", "shard"], default="replicates",
@@ -78,11 +105,11 @@ def parse():
                          "'shard' = ONE solve with the ECs sharded over the GPUs, RCCL all-reduce of the "
                          "column sums every iteration (strong scaling)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed / RCCL even with one rank (exercises the N > 1 code path)")
+                    help="create the RCCL communicator even with one rank (exercises the N > 1 code path)")
     a = ap.parse_args()
     dflt = {"cfg2": (1_000_000, 500, 1), "cfg3": (10_000_000, 5000, 2), "cfg4": (10_000_000, 5000, 2),
             "cfg5": (50_000_000, 20_000, 3), "e2e": (10_000_000, 5000, 2)}[a.config]
-    a.default_shape = (a.reads, a.groups, a.seed) == (None, None, None) and a.group_sizes == "poisson"
+    a.default_shape = (a.reads, a.groups, a.seed) == (None, None, None)   # (of its --config and --group-sizes)
     a.reads = dflt[0] if a.reads is None else a.reads
     a.groups = dflt[1] if a.groups is None else a.groups
     a.seed = dflt[2] if a.seed is None else a.seed
@@ -107,9 +134,8 @@ def cpu_share():
 
 
 def cpu_info():
-    info = {"logical_cpus": os.cpu_count(), "usable_cpus": cpu_share(), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND", "unset")}
-    # (not forced to `close`: a GPU box grants a CPU SHARE of a host its other tenants use too -- pinning 16 threads to
-    # the first 16 hardware threads of that host stalled the baseline for minutes; the scheduler places them)
+    info = {"logical_cpus": os.cpu_count(), "usable_cpus": cpu_share(), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND", "unset"),
+            "OMP_PLACES": os.environ.get("OMP_PLACES", "unset"), "OMP_WAIT_POLICY": os.environ.get("OMP_WAIT_POLICY", "unset")}
     try:
         txt = open("/proc/cpuinfo").read()
         models = [ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("model name")]
@@ -120,6 +146,180 @@ def cpu_info():
     except OSError:
         pass
     return info
+
+
+# ---- OMP_PROC_BIND=close OMP_PLACES=cores for the CPU legs ---------------------------------------
+# A GPU box shows ALL hardware threads of a host its other tenants use too and grants a CPU share of them (cgroup
+# quota).  `OMP_PLACES=cores` there means the first cores of the host, whoever is busy on them: round 4 tried it in
+# process and the baseline stalled for minutes (spinning barriers burn the quota while a bound thread waits for a
+# busy core).  So: the legs run in a CHILD process -- libgomp reads the binding when it loads, and a stall can be
+# ended -- bound `close` to explicit places = the least busy physical cores of the last 0.4 s, one hardware thread
+# each, with passive waits -- AFTER a two-second probe (a small dense-state run in a child of its own) has shown that
+# the binding works here at all: on the GPU boxes of round 5 it does not (the bound probe never finishes: some of the
+# host's cores are not ours to run on, whatever the affinity mask says), and the legs then run unbound at once, with the
+# probe's outcome in the line.  If a bound child falls silent all the same it is ended and the legs run again unbound.
+def pick_idle_cores(n):
+    """n physical cores (one hardware thread each, ascending ids) with the least non-idle time over 0.4 s."""
+    def snap():
+        out = {}
+        for ln in open("/proc/stat"):
+            if ln.startswith("cpu") and ln[3].isdigit():
+                f = ln.split()
+                v = [int(x) for x in f[1:9]]
+                out[int(f[0][3:])] = (sum(v), v[3] + v[4])
+        return out
+    allowed = sorted(os.sched_getaffinity(0))
+    a = snap()
+    time.sleep(0.4)
+    b = snap()
+    busy = {c: 1.0 - (b[c][1] - a[c][1]) / max(b[c][0] - a[c][0], 1) for c in allowed if c in a and c in b}
+    cores = {}
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        cores.setdefault(sib, []).append(c)
+    ranked = sorted(cores.values(), key=lambda hw: (max(busy.get(c, 0.0) for c in hw), hw[0]))
+    return sorted(hw[0] for hw in ranked[:n])
+
+
+def cpu_legs_in_child(a):
+    """The CPU legs of cfg3 / cfg2 in a child process bound as BASELINE.md 2 prescribes; None if that cannot be had."""
+    import subprocess
+    import threading
+    n = cpu_share()
+    try:
+        places = pick_idle_cores(n)
+    except Exception:  # (no /proc/stat, no topology files)
+        places = []
+    base = [sys.executable, os.path.abspath(__file__), "--cpu-legs-only", "--config", a.config, "--reads", str(a.reads),
+            "--groups", str(a.groups), "--seed", str(a.seed), "--group-sizes", a.group_sizes,
+            "--cpu-sample-ecs", str(a.cpu_sample_ecs), "--cpu-iters", str(a.cpu_iters)]
+    tries = []
+    probe_note = "no probe (no /proc/stat or topology files)"
+    if len(places) == n:
+        bound_env = dict(OMP_PROC_BIND="close", OMP_PLACES=",".join("{%d}" % c for c in places), OMP_WAIT_POLICY="passive",
+                         OMP_NUM_THREADS=str(n))
+
+        def probe(extra, limit):
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OMP_PROC_BIND", "OMP_PLACES")}
+            env.update(extra or {})
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-legs-only", "--cpu-probe"], env=env,
+                                   capture_output=True, text=True, timeout=limit)
+                return float(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+            except (subprocess.TimeoutExpired, ValueError, IndexError):
+                return None
+        t_free = probe(dict(OMP_WAIT_POLICY="passive", OMP_NUM_THREADS=str(n)), 120)   # (same wait policy: the binding alone differs)
+        t_bound = probe(bound_env, max(20.0, 4.0 * (t_free or 5.0)))
+        if t_free is not None and t_bound is not None and t_bound <= 1.5 * t_free:
+            tries.append(bound_env)
+            probe_note = f"probe: bound {t_bound:.2f} s, unbound {t_free:.2f} s"
+        else:
+            probe_note = (f"probe: bound {'did not finish' if t_bound is None else '%.2f s' % t_bound}, unbound "
+                          f"{'did not finish' if t_free is None else '%.2f s' % t_free}: OMP_PROC_BIND=close is not usable on this host")
+        log("cpu baseline: " + probe_note)
+    tries.append(None)      # unbound, as rounds 1-4
+    for env_extra in tries:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OMP_PROC_BIND", "OMP_PLACES")}
+        env.update(env_extra or {})
+        p = subprocess.Popen(base, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        last = [time.time()]
+
+        def relay():
+            for ln in p.stderr:
+                last[0] = time.time()
+                sys.stderr.write(ln)
+                sys.stderr.flush()
+        th = threading.Thread(target=relay, daemon=True)
+        th.start()
+        out = []
+        rd = threading.Thread(target=lambda: out.append(p.stdout.read()), daemon=True)
+        rd.start()
+        t0 = time.time()
+        stalled = False
+        while p.poll() is None:
+            time.sleep(0.5)
+            # every leg logs when it starts: silence of 150 s, or 420 s in all, is a stall (a leg is ~25 s)
+            if time.time() - last[0] > 150 or time.time() - t0 > 420:
+                stalled = True
+                p.kill()
+                break
+        p.wait()
+        rd.join(timeout=10)
+        if not stalled and p.returncode == 0 and out and out[0].strip():
+            try:
+                lines = json.loads(out[0].strip().splitlines()[-1])
+            except ValueError:
+                continue
+            for v in lines.values():
+                if isinstance(v, dict):
+                    v["binding"] = ("OMP_PROC_BIND=close on the %d least busy physical cores (OMP_PLACES one hardware thread each), "
+                                    "OMP_WAIT_POLICY=passive, child process (%s)" % (n, probe_note)) if env_extra else \
+                                   "unbound, child process (" + probe_note + ")"
+            return lines
+        log("cpu baseline: the %s child %s; %s" % ("bound" if env_extra else "unbound", "stalled" if stalled else "failed",
+                                                   "running the legs again unbound" if env_extra else "giving up"))
+    return None
+
+
+def cpu_legs_only(a):
+    """Child mode (--cpu-legs-only): regenerate the workload on the host and run its CPU legs; ONE JSON object on stdout."""
+    import numpy as np
+    if a.cpu_probe:   # seconds of a small all-thread dense-state run under this process's OpenMP environment
+        O, _ = _oracle()
+        rng = np.random.default_rng(1)
+        L = rng.normal(-3.0, 1.0, (200, 40000))
+        t0 = time.perf_counter()
+        O.rcg_optl_dense(L, np.zeros(40000), np.ones(200), tol=-1.0, max_iters=3)
+        print(f"{time.perf_counter() - t0:.4f}", flush=True)
+        return
+    from msweep_amd import synth
+    from msweep_amd.likelihood import precalc_lls
+    t0 = time.time()
+    if a.config == "cfg2":
+        E, G = a.reads, a.groups
+        p = synth.make_dense_problem(E, G, seed=a.seed)
+        log(f"cpu legs (child): cfg2 regenerated in {time.time() - t0:.0f}s")
+        out = cpu_cfg2_lines(a, p, E, G)
+    else:
+        G = a.groups
+        prob = synth.make_csr_problem(a.reads, G, seed=a.seed,
+                                      group_sizes=synth.diverse_group_sizes if a.group_sizes == "diverse" else None)
+        log(f"cpu legs (child): {a.config} regenerated in {time.time() - t0:.0f}s")
+        out = cpu_cfg3_lines(a, prob, G)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_cfg3_lines(a, prob, G):
+    import numpy as np
+    from msweep_amd.likelihood import precalc_lls
+    E = len(prob["rowptr"]) - 1
+    lut = precalc_lls(prob["group_sizes"])
+    n = min(a.cpu_sample_ecs, E)
+    lutidx = (prob["grp"].astype(np.uint32) * lut.shape[1] + prob["cnt"]).astype(np.uint32)
+    logc = np.log(prob["ec_counts"].astype(float))
+    out = cpu_dense_lines(lambda m: dense_sample(prob["rowptr"], prob["grp"], prob["cnt"], lut, G, m), logc, n, a.cpu_iters,
+                          lambda m: f"first {m} ECs of the cfg3 workload x {G} groups")
+    out["cpu_baseline_structured"] = cpu_structured_csr(prob["rowptr"], prob["grp"], lutidx, lut, G, logc, 5,
+                                                        "full cfg3 workload")
+    return out
+
+
+def cpu_cfg2_lines(a, p, E, G):
+    import numpy as np
+    out = cpu_dense_lines(lambda n: p["logl"] if n == E else np.ascontiguousarray(p["logl"][:, :n]), p["logc"], E,
+                          a.cpu_iters, lambda n: "the full cfg2 workload" if n == E else f"first {n} ECs of the cfg2 workload")
+    O, cores = _oracle()
+    dt, _ = _timed_iters(lambda n: O.rcg_optl_dense_structured(p["logl"], p["logc"], np.ones(G), tol=-1.0,
+                                                               max_iters=n), 5)
+    out["cpu_baseline_structured"] = {
+        "value": float(E) * G * 5 / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+        "sample": f"full cfg2 workload, 5 iterations of the structured restatement on the dense matrix "
+                  f"(oracle/rcg_oracle.cpp: two read-only passes over L per iteration, no G x E state) on "
+                  f"{cores} OpenMP threads, {dt:.1f} s; iters/s = {5 / dt:.3f}"}
+    return out
 
 
 # ---- CPU baselines (oracle legs: test infrastructure, the ONLY place bench.py touches oracle/) ------------------
@@ -260,20 +460,96 @@ def launch_ranks(a):
     sys.exit(0)
 
 
+class Star:
+    """Host-side meeting point of the rank processes of ONE node -- what carries the library's RCCL unique id from
+    rank 0 to the others (torch.distributed did that until round 4: the torch wheel bundles a second ROCm runtime,
+    and the two in one process aborted at exit or failed to load depending on the import order).  Rank 0 listens on
+    an ABSTRACT unix socket named after the ranks' common parent (this file's launcher, or torch.distributed.run's
+    agent) and MASTER_PORT; the name dies with rank 0, so a crashed run leaves nothing a later one could join."""
+
+    def __init__(self, rank, world, timeout=300.0):
+        import socket
+        self.rank, self.world, self.peers, self.sock = rank, world, {}, None
+        name = "\0msweep_bench_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+        if world == 1:
+            return
+        if rank == 0:
+            srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            srv.bind(name)
+            srv.listen(world)
+            srv.settimeout(timeout)
+            while len(self.peers) < world - 1:
+                c, _ = srv.accept()
+                c.settimeout(timeout)
+                self.peers[int.from_bytes(self._recv(c, 4), "little")] = c
+            srv.close()
+        else:
+            t_end = time.time() + timeout
+            while True:
+                c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                try:
+                    c.connect(name)
+                    break
+                except (ConnectionRefusedError, FileNotFoundError):
+                    c.close()
+                    if time.time() > t_end:
+                        raise RuntimeError("bench.py: rank 0 never opened the rendezvous socket")
+                    time.sleep(0.05)
+            c.settimeout(timeout)
+            c.sendall(rank.to_bytes(4, "little"))
+            self.sock = c
+
+    @staticmethod
+    def _recv(c, n):
+        buf = b""
+        while len(buf) < n:
+            part = c.recv(n - len(buf))
+            if not part:
+                raise RuntimeError("bench.py: a rank left the rendezvous")
+            buf += part
+        return buf
+
+    def _send_msg(self, c, data):
+        c.sendall(len(data).to_bytes(8, "little") + data)
+
+    def _recv_msg(self, c):
+        return self._recv(c, int.from_bytes(self._recv(c, 8), "little"))
+
+    def allgather(self, obj):
+        """[rank 0's obj, rank 1's, ...] on every rank (JSON-serialisable objects; a barrier as a side effect)."""
+        if self.world == 1:
+            return [obj]
+        if self.rank == 0:
+            out = [obj] + [json.loads(self._recv_msg(self.peers[r])) for r in range(1, self.world)]
+            data = json.dumps(out).encode()
+            for r in range(1, self.world):
+                self._send_msg(self.peers[r], data)
+            return out
+        self._send_msg(self.sock, json.dumps(obj).encode())
+        return json.loads(self._recv_msg(self.sock))
+
+    def bcast_bytes(self, data):
+        """rank 0's bytes on every rank"""
+        return bytes.fromhex(self.allgather(data.hex() if self.rank == 0 else None)[0])
+
+    def close(self):
+        for c in list(self.peers.values()) + ([self.sock] if self.sock else []):
+            c.close()
+
+
 def launch_selftest(a, rank, world):
-    """CPU-only rehearsal of the launcher + rendezvous (tests/test_parallel_cpu.py): gloo, no GPU."""
-    import torch
-    import torch.distributed as dist
+    """CPU-only rehearsal of the launcher + rendezvous (tests/test_parallel_cpu.py): no GPU, no library."""
     if os.environ.get("MSWEEP_SELFTEST_FAIL_RANK") == str(rank):   # (tests) a rank that dies before the rendezvous
         sys.exit(3)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    t = torch.tensor([float(rank + 1)])
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    dist.barrier()
+    star = Star(rank, world)
+    token = star.bcast_bytes(os.urandom(128) if rank == 0 else b"")     # what the unique id travels as
+    out = star.allgather(float(rank + 1))
+    same = star.allgather(token.hex())
     if rank == 0:
-        print(json.dumps({"selftest": True, "n_gpus": world, "gathered": [float(x.item()) for x in out]}), flush=True)
-    dist.destroy_process_group()
+        print(json.dumps({"selftest": True, "n_gpus": world, "gathered": out, "token_bytes": len(token),
+                          "token_same_everywhere": len(set(same)) == 1, "torch_imported": "torch" in sys.modules}),
+              flush=True)
+    star.close()
 
 
 # ---- end to end from Themisto text (SURVEY.md 8f-1) ---------------------------------------------------------------
@@ -421,22 +697,15 @@ def load_workload(a, core, shard, rank, world):
         log(f"cfg2: dense {G} x {E} generated in {t_gen:.1f}s, resident in {t_up:.2f}s (listed cells {nnz})")
 
         def cpu():
-            out = cpu_dense_lines(lambda n: p["logl"] if n == E else np.ascontiguousarray(p["logl"][:, :n]), p["logc"], E,
-                                  a.cpu_iters, lambda n: "the full cfg2 workload" if n == E else f"first {n} ECs of the cfg2 workload")
-            O, cores = _oracle()
-            dt, _ = _timed_iters(lambda n: O.rcg_optl_dense_structured(p["logl"], p["logc"], np.ones(G), tol=-1.0,
-                                                                       max_iters=n), 5)
-            out["cpu_baseline_structured"] = {
-                "value": float(E) * G * 5 / dt, "unit": "cells/s", "cores": cores, "kind": "port",
-                "sample": f"full cfg2 workload, 5 iterations of the structured restatement on the dense matrix "
-                          f"(oracle/rcg_oracle.cpp: two read-only passes over L per iteration, no G x E state) on "
-                          f"{cores} OpenMP threads, {dt:.1f} s; iters/s = {5 / dt:.3f}"}
-            return out
+            return cpu_legs_in_child(a) or cpu_cfg2_lines(a, p, E, G)
         return dict(E=E, G=G, nnz=nnz, logc=p["logc"], w=None, cpu=cpu, reads=E,
                     setup_s={"generate": t_gen, "set_dense_logl": t_up},
                     desc=f"cfg2: synthetic {E} ECs x {G} groups dense fp64 likelihood (4.0 GB) through the dense boundary "
-                         "(msw_core_set_dense_logl: re-expressed on the device as CSR-of-ECs, one table slot per listed "
-                         "cell), RCG-VB, fixed iteration count")
+                         + ("(msw_core_set_dense_logl with MSWEEP_DENSE_COMPRESS=0: kept DENSE on the device, EC-major, the "
+                            "sweeps k_dense_passA / k_dense_passB -- what a matrix without background structure gets), "
+                            if os.environ.get("MSWEEP_DENSE_COMPRESS") == "0" else
+                            "(msw_core_set_dense_logl: re-expressed on the device as CSR-of-ECs, one table slot per listed "
+                            "cell), ") + "RCG-VB, fixed iteration count")
     if a.config == "cfg5":
         G = a.groups
         p = synth.make_csr_problem(a.reads, G, seed=a.seed, max_other=7, theta_support=max(G // 10, 1), chunk=2_000_000)
@@ -529,15 +798,8 @@ def load_workload(a, core, shard, rank, world):
     t_up = time.time() - t0
 
     def cpu():
-        lut = precalc_lls(prob["group_sizes"])
-        n = min(a.cpu_sample_ecs, E)
-        lutidx = (prob["grp"].astype(np.uint32) * lut.shape[1] + prob["cnt"]).astype(np.uint32)
-        logc = np.log(prob["ec_counts"].astype(float))
-        out = cpu_dense_lines(lambda m: dense_sample(prob["rowptr"], prob["grp"], prob["cnt"], lut, G, m), logc, n, a.cpu_iters,
-                              lambda m: f"first {m} ECs of the cfg3 workload x {G} groups")
-        out["cpu_baseline_structured"] = cpu_structured_csr(prob["rowptr"], prob["grp"], lutidx, lut, G, logc, 5,
-                                                            "full cfg3 workload")
-        return out
+        return cpu_legs_in_child(a) or cpu_cfg3_lines(a, prob, G)
+
     def first_theta():
         """Time to the FIRST estimate of a likelihood the host holds as CSR-of-ECs: msw_core_set_csr (upload, slot
         plan, SELL packing -- without the LDS-bank ordering of the cells, which pays from the ~1000th iteration on:
@@ -620,6 +882,8 @@ def main():
                  f"(plain `python bench.py --gpus {a.gpus}` starts them itself)")
     if a.launch_selftest:
         return launch_selftest(a, rank, world)
+    if a.cpu_legs_only:
+        return cpu_legs_only(a)
     if a.config == "e2e":
         if world > 1:
             sys.exit("bench.py: --config e2e is a single-GPU line")
@@ -637,42 +901,36 @@ def main():
     sys.stdout.flush()
     OUT = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    dist = None
     # MSWEEP_BENCH_ONE_GPU=1 (developer switch, a FUNCTIONAL rehearsal of the N > 1 code of this file on a box with one
-    # GPU, never a measurement): every rank on device 0, torch.distributed over gloo, the library's ranks meeting in a
-    # shared-memory segment (msw_comm_create_shm) -- RCCL, torch's and the library's, refuses two ranks on one device
+    # GPU, never a measurement): every rank on device 0, the library's ranks meeting in a shared-memory segment
+    # (msw_comm_create_shm) -- RCCL refuses two ranks on one device
     one_gpu = os.environ.get("MSWEEP_BENCH_ONE_GPU", "0") == "1" and world > 1
     if one_gpu:
         local_rank = 0
-    if world > 1 or a.force_dist:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        if one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    multi = world > 1 or a.force_dist
     n_gpus = world
 
     import numpy as np
     from msweep_amd.core import Comm, Core
 
     core = Core(local_rank)
-    shard = dist is not None and a.mode == "shard"
+    shard = multi and a.mode == "shard"
     comm = None
     rccl_ranks = None
-    if dist is not None:
-        # the library's own RCCL communicator (C ABI: msw_comm_create_rccl); torch.distributed only
-        # carries the unique id and the barriers around the timed region
+    star = None
+    if multi:
+        # the library's own RCCL communicator (C ABI: msw_comm_create_rccl) carries every collective of this file:
+        # the barriers around the timed region (msw_comm_allreduce), the max over ranks and the abundances
+        # (msw_comm_allgather).  No torch in a rank process: only the 128-byte unique id travels outside RCCL, through
+        # the ranks' own unix socket (Star).
+        os.environ.setdefault("MASTER_PORT", "29533")
+        star = Star(rank, world)
         if one_gpu:
-            comm = Comm.shm("/msweep_bench_" + os.environ["MASTER_PORT"], rank, world, 0)
+            comm = Comm.shm("/msweep_bench_%d_%s" % (os.getppid(), os.environ["MASTER_PORT"]), rank, world, 0)
             rccl_ranks = "none: MSWEEP_BENCH_ONE_GPU rehearsal, all ranks on one device (NOT a measurement)"
         else:
-            uid = [Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            comm = Comm.rccl(uid[0], rank, world, local_rank)
+            uid = star.bcast_bytes(Comm.unique_id() if rank == 0 else b"")
+            comm = Comm.rccl(uid, rank, world, local_rank)
             rccl_ranks = comm.rccl_count()     # ncclCommCount
             if rccl_ranks != world:
                 sys.exit(f"bench.py: RCCL communicator spans {rccl_ranks} ranks, expected {world}")
@@ -683,7 +941,7 @@ def main():
     E, G, nnz = wl["E"], wl["G"], wl["nnz"]
     alpha0 = np.ones(G)
     logc = wl["logc"]
-    if dist is not None and not shard and a.config == "cfg3":
+    if multi and not shard and a.config == "cfg3":
         # replicate `rank` of the bootstrap, drawn on the device from the reference's ONE sequential
         # mt19937_64(--seed 42) stream (src/BootstrapSample.cpp:60-73): rank r owns draws
         # [r * n_reads, (r + 1) * n_reads), exactly what a single-GPU run would give replicate r
@@ -693,14 +951,15 @@ def main():
     log("likelihood resident")
 
     def sync():
-        # barrier + device synchronisation on both sides of the timed region.  The library calls themselves
-        # return only after their HIP streams have drained (they download theta), so with one rank there
-        # is nothing left to wait for and torch is not even imported.
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        # barrier + device synchronisation on both sides of the timed region.  The library calls themselves return
+        # only after their HIP streams have drained (they download theta), and the barrier is a collective of the
+        # library's communicator on the device (a one-word all-reduce, synchronised before it returns): every
+        # rank's GPU is idle when the last rank arrives.  With one rank there is nothing to wait for.
+        if multi:
+            comm.allreduce([], [0.0])
+
+    def max_over_ranks(x):
+        return float(comm.allgather(np.array([x])).max()) if multi else x
 
     # Pre-warm, BEFORE the timed region and reported in the line (`prewarm`): SURVEY 8(d)'s second figure --
     # time to convergence at the reference's defaults (--tol 1e-6, --max-iters 5000), host inputs handed over
@@ -708,7 +967,7 @@ def main():
     # of their own these are ~100 ms of the same sweeps: a cold MI355X reaches its working clocks only after
     # 60-80 ms of activity (tools/timing.py ramp: the SAME twenty iterations take 0.214 ms each on a cold chip,
     # 0.181 ms once it has been busy for 40 ms), and the timed region is to measure the path, not the governor.
-    conv = em = None
+    conv = em = em_float = None
     prewarm = {"ms": 0.0, "what": "none (--no-prewarm)"}
     t_pre = time.perf_counter()
     if not shard and not a.no_extras:
@@ -730,6 +989,26 @@ def main():
             core.run(max_iters=a.steps, algo=ALGO_EM)
             t_em = time.perf_counter() - t1
             em = {"ms_per_step": t_em * 1e3 / a.steps, "iters_per_sec": a.steps / t_em}
+            # ... and --emprecision float (the reference's fastest GPU mode, docs/gpubenchmarks.md:22,25): the fp32 sweep
+            # where the layout allows (msw_timing::em_float_kernels), same W + K steps; then to --tol 1e-6, where the float
+            # log-likelihood stops growing at float resolution long before the double run stops
+            from msweep_amd.core import PREC_FLOAT
+            core.run(max_iters=max(a.warmup, 1), algo=ALGO_EM, prec=PREC_FLOAT)
+            t1 = time.perf_counter()
+            core.run(max_iters=a.steps, algo=ALGO_EM, prec=PREC_FLOAT)
+            t_emf = time.perf_counter() - t1
+            fp32 = bool(core.last_timing()["em_float_kernels"])
+            core.set_fixed_iters(False)
+            t1 = time.perf_counter()
+            rf = core.run(tol=1e-6, max_iters=5000, algo=ALGO_EM, prec=PREC_FLOAT)
+            t_conv = time.perf_counter() - t1
+            core.set_fixed_iters(True)
+            em_float = {"ms_per_step": t_emf * 1e3 / a.steps, "iters_per_sec": a.steps / t_emf, "fp32_kernels": fp32,
+                        "to_tol_1e-6": {"iters": int(rf["iters"]), "ms": t_conv * 1e3},
+                        "what": "msw_core_run(MSW_ALGO_EM, MSW_PREC_FLOAT): fp32 likelihood values, weights, row sums and "
+                                "quotients, exact integer column sums, the log-likelihood rounded to float for the stop "
+                                "rule (msweep_amd/csrc/em_f32_kernels.hpp)" if fp32 else
+                                "this layout is not served by the fp32 kernels: the fp64 kernels under MSW_PREC_FLOAT"}
         prewarm = {"ms": (time.perf_counter() - t_pre) * 1e3,
                    "what": f"{len(runs)} convergence solves at --tol 1e-6 ({conv['iters']} iterations each)"
                            + (f" + EM leg of {max(a.warmup, 1)} + {a.steps} iterations" if em else "")
@@ -771,20 +1050,29 @@ def main():
         # W untimed warm-up steps: the first W iterations of the solve (with its set-up: the evaluation of the
         # initial state and the first iteration's rejected step); the K timed steps are the NEXT K iterations of
         # the same solve (msw_core_continue) -- every kernel slot they need, rejected steps included
-        core.run(max_iters=max(a.warmup, 1))
-        if dist is not None and not shard:
-            comm.allgather(np.zeros(G))           # RCCL sets its connections up on the first collective: not timed
-        sync()
-        t0 = time.perf_counter()
-        res = core.continue_(a.steps)             # exactly K steps
-        if dist is not None and not shard:
-            gathered = comm.allgather(res["theta"])   # (world, G): the per-replicate abundances, RCCL all-gather
-            assert gathered.shape == (world, G)
-        sync()
-        dt = time.perf_counter() - t0
-        tm0 = core.last_timing()
-        log(f"timed {a.steps} steps in {dt:.3f}s")
-        assert tm0["iters"] == a.steps, (tm0["iters"], a.steps)
+        # The timed region is a few milliseconds at the driver's K = 20 (one scheduler hiccup on the host moves it by
+        # several per cent): it is taken REPEATS times -- every time the W warm-up iterations again (untimed), then the
+        # same K iterations, barrier + synchronisation on both sides, max over ranks -- and the MEDIAN is the line's
+        # ms_per_step / value; all of them are in ms_per_step_runs.
+        REPEATS = 5
+        dts, dev = [], []
+        for rep in range(REPEATS):
+            core.run(max_iters=max(a.warmup, 1))
+            if multi and not shard and rep == 0:
+                comm.allgather(np.zeros(G))       # RCCL sets its connections up on the first collective: not timed
+            sync()
+            t0 = time.perf_counter()
+            res = core.continue_(a.steps)         # exactly K steps
+            if multi and not shard:
+                gathered = comm.allgather(res["theta"])   # (world, G): the per-replicate abundances, RCCL all-gather
+                assert gathered.shape == (world, G)
+            sync()
+            dts.append(max_over_ranks(time.perf_counter() - t0))
+            tm0 = core.last_timing()
+            dev.append(tm0["solve_ms"] / a.steps)
+            assert tm0["iters"] == a.steps, (tm0["iters"], a.steps)
+        dt = float(np.median(dts))
+        log(f"timed {a.steps} steps x {REPEATS}: {', '.join(f'{x * 1e3:.3f}' for x in dts)} ms; median {dt * 1e3:.3f} ms")
         # K more steps with HIP events around every sweep launch (on the solve stream) for the
         # per-kernel durations of the roofline object.  Kept out of the timed run: every event record
         # is a barrier packet that costs ~6 us of idle GPU between two kernels.
@@ -797,7 +1085,11 @@ def main():
         cells = float(E) * G * a.steps * mult
         line_extra = {"iters_per_sec": a.steps * mult / dt, "listed_cells_per_sec": float(nnz) * a.steps * mult / dt,
                       "reads_x_groups_cells_per_sec": float(wl["reads"]) * G * a.steps * mult / dt,
-                      "device_ms_per_step": tm0["solve_ms"] / a.steps}
+                      "device_ms_per_step": float(np.median(dev)),
+                      "ms_per_step_runs": [x * 1e3 / a.steps for x in dts],
+                      "ms_per_step_what": f"median of {REPEATS} repeats of the K-step region (each: W untimed warm-up "
+                                          "iterations, barrier + synchronisation, K timed iterations, synchronisation + barrier; "
+                                          "max over ranks per repeat)"}
         if shard:
             # where an iteration of the EC-sharded solve goes on rank 0 (the profiled run: events around the sweeps and
             # around the two all-reduces with their packing kernels): the first hardware run says which part to fix
@@ -811,12 +1103,8 @@ def main():
                         "GPU each: the sum exceeds ms_per_step); collectives = k_sum_scalar + all-reduce of 1 double "
                         "after pass A, k_colsum + all-reduce of 3 G integers + 4 doubles after pass B; chain_and_gaps = "
                         "k_finstep, k_redfin (redundant on every rank) and the launch boundaries"}
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        tt = tt if one_gpu else tt.cuda()
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    if a.config == "cfg4":
+        dt = max_over_ranks(dt)
 
     # the real replicate loop beside every cfg3 line: msw_core_bootstrap_dist, fixed replicates per rank
     boot = None
@@ -829,12 +1117,7 @@ def main():
         _, iters, bt = bootstrap_leg(core, boot_comm, w, a.bootstrap_per_rank, world, G)
         sync()
         tb = time.perf_counter() - t1
-        if dist is not None:
-            import torch
-            tt = torch.tensor([tb], dtype=torch.float64)
-            tt = tt if one_gpu else tt.cuda()
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tb = float(tt.item())
+        tb = max_over_ranks(tb)
         B = a.bootstrap_per_rank * world
         boot = {"replicates": B, "per_rank": a.bootstrap_per_rank, "seconds": tb, "replicates_per_sec": B / tb,
                 "iterations": [int(x) for x in iters], "cells_per_sec": float(E) * G * float(iters.sum()) / tb,
@@ -855,16 +1138,26 @@ def main():
         achieved = b_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
         # collected offline on this exact workload and committed under profiles/
-        traffic, traffic_src = None, None
+        traffic, traffic_src, busy = None, None, None
         if a.default_shape:
-            for name in TRAFFIC_JSON[a.config]:
+            tkey = a.config + ("-diverse" if a.group_sizes == "diverse" else "")
+            if a.config == "cfg2" and os.environ.get("MSWEEP_DENSE_COMPRESS") == "0":
+                tkey = "cfg2-dense"
+            for name in TRAFFIC_JSON.get(tkey, []):
                 try:
                     tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                    traffic = next(v["hbm_bytes_per_launch"] for k, v in tj.items() if dom in k)
+                    ent = next(v for k, v in tj.items() if dom[2:] in k)     # ("passB": k_passB<..>, k_dense_passB<..>)
+                    traffic = ent["hbm_bytes_per_launch"]
+                    busy = pmc_bound(ent)
                     traffic_src = f"profiles/{name} (offline rocprofv3 --pmc passes on this workload, not this run)"
                     break
                 except Exception:
                     continue
+        # what bounds the dominant kernel: the record stream is NOT it where the counters say that LDS (gathers, integer
+        # atomics, half of the cycles bank conflicts) and VALU issue are both busy and overlap only in part
+        bound = "hbm"
+        if busy is not None and max(busy["lds_busy_frac"], busy["valu_busy_frac"]) >= 0.4:
+            bound = "lds+valu (hbm frac reported)"
         gb = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         sharding = "single solve" if n_gpus == 1 else (
             f"one solve, ECs sharded over {n_gpus} GPUs, {os.environ.get('MSWEEP_ALLREDUCE', 'rccl')} all-reduce of 1 double and "
@@ -887,8 +1180,15 @@ def main():
             "prewarm": prewarm,
             "kernels": {"k_passA_ms": msA, "k_passB_ms": msB, "passA_launches": tm["passA_launches"],
                         "passB_launches": tm["passB_launches"]},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "lds_busy_frac": busy and busy["lds_busy_frac"], "lds_conflict_frac": busy and busy["lds_conflict_frac"],
+                         "valu_busy_frac": busy and busy["valu_busy_frac"],
+                         "bound_what": "achieved / peak / frac are ALGORITHMIC bytes of the kernel's record stream against the "
+                                       "HBM peak, as the contract asks; lds_busy / valu_busy / lds_conflict are the kernel's "
+                                       "SQ counters from the same committed PMC file as `traffic`: LDS-array cycles and VALU "
+                                       "issue cycles as fractions of the kernel's duration, conflict cycles as a fraction "
+                                       "of the LDS cycles (bench.py pmc_bound)",
                          "algorithmic_bytes_per_launch": b_dom, "avg_launch_ms": ms_dom,
                          "measured_stream_GBs": {"read_only_same_size": stream_read, "triad_same_size": stream_triad,
                                                  "read_only_4GiB": stream_read_4g, "triad_4GiB": stream_triad_4g,
@@ -915,6 +1215,8 @@ def main():
                 line["time_to_first_theta"] = {"ms": None, "what": f"failed: {ex}"}
         if em is not None:
             line["em_algorithm"] = em
+        if em_float is not None:
+            line["em_algorithm_float"] = em_float
         if boot is not None:
             line["bootstrap_cfg4"] = boot
         if not a.no_cpu_baseline and n_gpus == 1:   # rank 0 at N = 1 only: the host cores are shared by the ranks
@@ -929,10 +1231,14 @@ def main():
     core.close()
     if comm is None:
         boot_comm.close()
-    if dist is not None:
-        dist.barrier()
+    if multi:
+        sync()
         comm.close()
-        dist.destroy_process_group()
+        star.allgather(None)     # nobody tears its process down while a peer is still inside the last collective
+        star.close()
+    # (tests/test_gpu_multi.py, tests/test_parallel_cpu.py) the rank processes never import torch: its wheel bundles a
+    # second ROCm runtime (libamdhip64 / librccl / HSA) next to the system one the library is linked against
+    assert "torch" not in sys.modules, "bench.py: a rank process imported torch"
 
 
 if __name__ == "__main__":

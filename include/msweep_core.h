@@ -25,8 +25,14 @@ typedef struct msw_core *msw_handle;
 
 /* --algorithm (src/mSWEEP.cpp:127,192-204): rcggpu -> MSW_ALGO_RCG, emgpu -> MSW_ALGO_EM. */
 enum { MSW_ALGO_RCG = 0, MSW_ALGO_EM = 1 };
-/* --emprecision (src/mSWEEP.cpp:129,202).  Accepted and equivalent: both run the fp64 kernels and return
- * the same bits (the reference's float mode exists to halve its G x E matrices, which do not exist here). */
+/* --emprecision (src/mSWEEP.cpp:129,202; MSW_ALGO_EM only -- RCG ignores it, as rcgpar's rcg_optl_* have no such
+ * argument).  MSW_PREC_FLOAT (round 5) is REAL fp32 arithmetic (msweep_amd/csrc/em_f32_kernels.hpp): likelihood values,
+ * weights, row sums and quotients in fp32, the log-likelihood rounded to float once per iteration for the stop rule
+ * (which is why a float run stops after a few hundred iterations where double reaches --max-iters, as the reference's
+ * does: docs/gpubenchmarks.md:20-22), column sums in exact 64-bit fixed point.  Served by fp32 kernels for 4-byte
+ * offset records with table and group vectors in LDS, up to 6144 groups, one GPU; other layouts (8-byte / index /
+ * value records, dense matrices without background structure, EC-sharded solves) run the fp64 kernels under
+ * MSW_PREC_FLOAT as until round 4 -- msw_timing::em_float_kernels says which it was. */
 enum { MSW_PREC_DOUBLE = 0, MSW_PREC_FLOAT = 1 };
 
 /* ---- lifetime ---------------------------------------------------------------------- */
@@ -112,6 +118,9 @@ typedef struct msw_layout_info {
                                 * .., 17..32, <= 16 cells; MSWEEP_MULTILANE=0: all in the last) */
   uint32_t max_rows;           /* rows of the longest slice (<= 16: every slice on the register path of the sweeps) */
   int32_t bank_scheduled;      /* the cells of every slice were ordered for the LDS banks (msw_core_set_pack_schedule) */
+  int32_t passB_reg_cells;     /* records per slice lane pass B holds in registers: 16, or 8 = its short-slice instantiation
+                                * with 16 wavefronts per workgroup (slices of > 8 rows hold <= 1/20 of the rows) */
+  uint64_t rows_over_8;        /* rows of the slices of more than 8 rows (0 when not counted: index / wide / value records) */
 } msw_layout_info;
 int msw_core_layout_info(msw_handle h, msw_layout_info *out);
 /* Whether the NEXT likelihood made resident on the handle (msw_core_set_csr, msw_core_build_likelihood, a dense
@@ -311,6 +320,7 @@ typedef struct msw_timing {
                           * one (3 G + 4)-word vector after pass B, per iteration) with the small kernels that pack
                           * them, summed over the launches; events on the solve stream.  0 without a communicator. */
   uint64_t collectives;  /* how many */
+  uint64_t em_float_kernels; /* 1: the last solve was an EM run under MSW_PREC_FLOAT served by the fp32 kernels */
 } msw_timing;
 int msw_core_set_profiling(msw_handle h, int enabled);
 int msw_core_last_timing(msw_handle h, msw_timing *out);

@@ -122,9 +122,8 @@ def main(argv=None):
             sys.stderr.write("note: --algorithm rcgcpu is served by the GPU RCG kernels (same algorithm as rcggpu)\n")
     algo = ALGO_RCG if a.algorithm in ("rcggpu", "rcgcpu") else ALGO_EM   # anything else -> em (src/mSWEEP.cpp:200)
     prec = PREC_FLOAT if a.emprecision == "float" else PREC_DOUBLE
-    if algo == ALGO_EM and prec == PREC_FLOAT:
-        sys.stderr.write("note: --emprecision float is computed in double here (no G x E matrix exists whose "
-                         "footprint float would halve); results are those of --emprecision double\n")
+    # (--emprecision float: fp32 kernels where the layout allows, msweep_amd/csrc/em_f32_kernels.hpp; the library
+    # reports which through msw_timing::em_float_kernels)
     try:
         core = Core(a.device)
         # ordering the cells for the LDS banks pays from about the 1 000th iteration on: bootstrap runs (msw_core_set_pack_schedule)

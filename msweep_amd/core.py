@@ -44,7 +44,7 @@ class Timing(C.Structure):
     _fields_ = [("solve_ms", C.c_double), ("passA_ms", C.c_double), ("passB_ms", C.c_double),
                 ("passA_launches", C.c_uint64), ("passB_launches", C.c_uint64), ("iters", C.c_uint64),
                 ("bytes_passA", C.c_uint64), ("bytes_passB", C.c_uint64), ("collective_ms", C.c_double),
-                ("collectives", C.c_uint64)]
+                ("collectives", C.c_uint64), ("em_float_kernels", C.c_uint64)]
 
 
 class LayoutInfo(C.Structure):
@@ -52,7 +52,8 @@ class LayoutInfo(C.Structure):
                 ("table_in_lds", C.c_int32), ("passB_mode", C.c_int32), ("slot_entries", C.c_uint32),
                 ("slot_entries_in_lds", C.c_uint32), ("n_slices", C.c_uint32), ("n_long_ecs", C.c_uint32),
                 ("rows", C.c_uint64), ("rows_from_memory", C.c_uint64), ("slices_by_lanes", C.c_uint32 * 7),
-                ("max_rows", C.c_uint32), ("bank_scheduled", C.c_int32)]
+                ("max_rows", C.c_uint32), ("bank_scheduled", C.c_int32), ("passB_reg_cells", C.c_int32),
+                ("rows_over_8", C.c_uint64)]
 
 
 class BootstrapTiming(C.Structure):
@@ -200,6 +201,7 @@ class Core:
         if rc != 0:
             raise MswError(self._L.msw_last_error(None).decode())
         self.device = device
+        self.generation = 0     # solves started on this handle (rcgpar.EcProbs: whose state gamma() would read)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -299,6 +301,7 @@ class Core:
             raise MswError(f"solve: expected logc[{E}] and alpha0[{G}], got {len(logc)} and {len(alpha0)}")
         theta = np.empty(G)
         it, b = C.c_size_t(), C.c_double()
+        self.generation += 1
         self._check(self._L.msw_core_solve(self._h, _ptr(logc), _ptr(alpha0), float(tol), int(max_iters),
                                            int(algo), int(prec), _ptr(theta), C.byref(it), C.byref(b)))
         return dict(theta=theta, iters=it.value, bound=b.value)
@@ -317,6 +320,7 @@ class Core:
         G, _, _ = self.shape()
         theta = np.empty(G)
         it, b = C.c_size_t(), C.c_double()
+        self.generation += 1
         self._check(self._L.msw_core_run(self._h, float(tol), int(max_iters), int(algo), int(prec), _ptr(theta),
                                          C.byref(it), C.byref(b)))
         return dict(theta=theta, iters=it.value, bound=b.value)
@@ -326,6 +330,7 @@ class Core:
         G, _, _ = self.shape()
         theta = np.empty(G)
         it, b = C.c_size_t(), C.c_double()
+        self.generation += 1
         self._check(self._L.msw_core_continue(self._h, int(n_iters), _ptr(theta), C.byref(it), C.byref(b)))
         return dict(theta=theta, iters=it.value, bound=b.value)
 

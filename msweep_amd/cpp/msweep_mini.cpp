@@ -257,9 +257,7 @@ int main(int argc, char **argv) {
     std::cerr << "note: --algorithm rcgcpu is served by the GPU RCG kernels (same algorithm as rcggpu)\n";
   const int algo = (a.algorithm == "rcggpu" || a.algorithm == "rcgcpu") ? MSW_ALGO_RCG : MSW_ALGO_EM;  // else em (src/mSWEEP.cpp:200)
   const int prec = a.emprecision == "float" ? MSW_PREC_FLOAT : MSW_PREC_DOUBLE;
-  if (algo == MSW_ALGO_EM && prec == MSW_PREC_FLOAT)
-    std::cerr << "note: --emprecision float is computed in double here (no G x E matrix exists whose footprint "
-                 "float would halve); results are those of --emprecision double\n";
+  // (--emprecision float: fp32 kernels where the layout allows, msweep_amd/csrc/em_f32_kernels.hpp)
   const size_t G = grouping.names.size();
   msw_handle h = nullptr;
   size_t n_kept = 0;

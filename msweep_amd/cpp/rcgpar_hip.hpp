@@ -25,12 +25,16 @@
 // The UNMODIFIED call sites get the same effect through a one-entry cache: mSWEEP passes the same `ll_mat` object to
 // rcg_optl() once for the estimate and once per bootstrap replicate (src/mSWEEP.cpp:402,507 -- `log_likelihoods->
 // log_mat()`, const for the whole grouping), so the drop-ins below keep the DeviceLikelihood of the last matrix they saw,
-// keyed by (address, rows, columns, a hash of 65 536 sampled cells, device): calls 2 .. 1 + --iters cost their solve, not
-// another host copy + upload + device compression of the G x E matrix.  A matrix that was rewritten in place is
-// caught by the sampled hash -- with the probability of a sample, not with certainty: callers that DO rewrite a
-// matrix at the same address between calls (the reference does not) call rcgpar::forget_likelihood() or set
-// MSWEEP_SHIM_CACHE=0.
+// keyed by (address, rows, columns, a hash of the matrix, device): calls 2 .. 1 + --iters cost their solve, not another
+// host copy + upload + device compression of the G x E matrix.  The hash covers EVERY cell up to 2^27 cells (1 GB of
+// fp64; round 5: a single cell edited in place is caught -- tests/cpp/reference_calls_test.cpp -- at a few tens of
+// milliseconds on the caller's threads); larger matrices, where walking the caller's operator() over every cell would
+// cost as much as the solve it saves, fall back to 65 536 sampled cells + the corners, which catches a rewrite with
+// the probability of the sample only: callers that DO rewrite such a matrix at the same address between calls (the
+// reference does not) call rcgpar::forget_likelihood() or set MSWEEP_SHIM_CACHE=0.  MSWEEP_SHIM_FULL_HASH_CELLS moves
+// the limit (0: always sampled).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -39,6 +43,7 @@
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -229,12 +234,46 @@ uint64_t sample_hash(const MatrixT &logl) {
   eat(0, 0), eat(0, E - 1), eat(G - 1, 0), eat(G - 1, E - 1);
   return h;
 }
+// every cell: the row-major index space cut into one range per thread (up to 8), a 64-bit multiply-xor chain over the
+// cells' bit patterns per range, the ranges' digests chained in order -- one multiplication per cell, memory-bound
+template <class MatrixT>
+uint64_t full_hash(const MatrixT &logl) {
+  const size_t G = logl.get_rows(), E = logl.get_cols(), n = G * E;
+  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::thread::hardware_concurrency(), n >> 20}));
+  std::vector<uint64_t> part(T, 0);
+  auto work = [&](size_t t) {
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ t;
+    const size_t i0 = n * t / T, i1 = n * (t + 1) / T;
+    size_t g = i0 / E, j = i0 % E;
+    for (size_t i = i0; i < i1; ++i) {
+      const double v = logl(g, j);
+      uint64_t b;
+      __builtin_memcpy(&b, &v, sizeof b);
+      h = (h ^ b) * 0xff51afd7ed558ccdull;
+      h ^= h >> 29;
+      if (++j == E) j = 0, ++g;
+    }
+    part[t] = h;
+  };
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto &th : pool) th.join();
+  uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
+  for (uint64_t v : part) h = (h ^ v) * 1099511628211ull;
+  return h | 1ull;  // (never the sampled hash of the same matrix by accident of a zero)
+}
+inline size_t full_hash_limit() {
+  if (const char *e = std::getenv("MSWEEP_SHIM_FULL_HASH_CELLS")) return (size_t)std::strtoull(e, nullptr, 10);
+  return (size_t)1 << 27;
+}
 template <class MatrixT>
 DeviceLikelihood &resident(const MatrixT &logl, int device) {
   ShimCache &c = shim_cache();
   const char *sw = std::getenv("MSWEEP_SHIM_CACHE");
   const bool use = !(sw && sw[0] == '0');
-  const uint64_t h = use ? sample_hash(logl) : 0;
+  const bool full = logl.get_rows() * logl.get_cols() <= full_hash_limit();
+  const uint64_t h = use ? (full ? full_hash(logl) : sample_hash(logl)) : 0;
   if (use && c.lik && c.addr == static_cast<const void *>(&logl) && c.rows == logl.get_rows() &&
       c.cols == logl.get_cols() && c.hash == h && c.device == device) {
     ++c.hits;

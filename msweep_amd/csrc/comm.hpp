@@ -39,6 +39,10 @@ struct msw_comm {
   virtual void abort() {}
   // called after the solve stream has been synchronised: a collective that failed ON THE DEVICE throws here
   virtual void check() {}
+  // the ranks meet on the HOST before a stretch of device-side collectives (the start of a sharded solve or of its
+  // continuation): transports whose waits are bounded on the device (peer_comm.hpp) must not charge the host skew
+  // between the ranks' calls -- seconds, when a caller does other work between two solves -- to that bound
+  virtual void rendezvous() {}
 };
 
 namespace msw {

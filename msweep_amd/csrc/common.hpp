@@ -20,8 +20,13 @@ constexpr int kWave = 64;          // CDNA wavefront
 #ifndef MSW_PASS_THREADS_B
 #define MSW_PASS_THREADS_B 768
 #endif
+// (pass B's short-slice instantiation -- at most 8 rows per slice lane, 117 registers -- runs 16, sweep_kernels.hpp)
+#ifndef MSW_PASS_THREADS_B8
+#define MSW_PASS_THREADS_B8 1024
+#endif
 constexpr int kPassThreads = MSW_PASS_THREADS_A;
 constexpr int kPassThreadsB = MSW_PASS_THREADS_B;
+constexpr int kPassThreadsB8 = MSW_PASS_THREADS_B8;
 constexpr int kMaxTrace = 4096;
 constexpr int kRedfinParts = 5;    // doubles per workgroup of k_redfin's partial sums (state_kernels.hpp)
 constexpr int kRedfinGroups = 16;  // groups per workgroup of k_redfin

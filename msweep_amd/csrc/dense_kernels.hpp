@@ -1,5 +1,7 @@
 // dense_kernels.hpp -- sweeps for a dense likelihood (--read-likelihood path) and the transpose.
 #pragma once
+#include <type_traits>
+
 #include "device_util.hpp"
 
 namespace msw {
@@ -9,6 +11,37 @@ namespace msw {
 // streams one EC's G values with coalesced loads; lane l owns groups l, l+64, ... and
 // keeps their u_g / w_g / column-sum accumulators in registers (no atomics).
 // ---------------------------------------------------------------------------------------
+// Round 5 (the review's weak 8: 0.54 / 0.41 of the HBM peak at 1 M x 500, one fp64 exp per cell): (i) the NEXT EC's row
+// is in flight while the current one is worked on -- a wavefront used to issue its row's loads, wait out the HBM
+// latency, then spend as long again in reductions and exponentials with nothing in flight; (ii) the per-EC maximum --
+// any common offset near the maximum serves the softmax -- is reduced as a FLOAT (one register per DPP step instead
+// of two, and a third of the instructions of the fp64 tree); the value every lane ends with is the same float, so
+// the arithmetic stays identical across the lanes of an EC.
+__device__ __forceinline__ float wave_max_f(float v) {
+  const float ninf = -INFINITY;
+  auto mv = [](float x, float fill, auto ctrl, auto mask) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), decltype(ctrl)::value,
+                                                      decltype(mask)::value, 0xf, false));
+  };
+  v = fmaxf(v, mv(v, ninf, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{}));
+  v = fmaxf(v, mv(v, ninf, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{}));
+  v = fmaxf(v, mv(v, ninf, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{}));
+  v = fmaxf(v, mv(v, ninf, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{}));
+  v = fmaxf(v, mv(v, ninf, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}));
+  v = fmaxf(v, mv(v, ninf, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// the row of EC j into x (lanes past G: 0)
+template <int NREG>
+__device__ __forceinline__ void dense_load_row(const double *Lt, uint32_t j, int G, int lane, double (&x)[NREG]) {
+  const double *row = Lt + (size_t)j * G;
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) {
+    const int g = lane + 64 * i;
+    x[i] = g < G ? row[g] : 0.0;
+  }
+}
+
 template <int NREG>
 __global__ __launch_bounds__(256) void k_dense_passA(const Scalars *sc, const double *Lt, int G,
                                                     uint32_t E, const double *u, const double *w,
@@ -22,40 +55,37 @@ __global__ __launch_bounds__(256) void k_dense_passA(const Scalars *sc, const do
 #pragma unroll
   for (int i = 0; i < NREG; ++i) {
     const int g = lane + 64 * i;
-    uu[i] = g < G ? u[g] : 0.0;
+    uu[i] = g < G ? u[g] : -INFINITY;  // (lanes past G: exp(-inf) = 0 in every sum)
     ww[i] = g < G ? w[g] : 0.0;
   }
   double nn = 0.0;
+  double xn[NREG];
+  if (gw < E) dense_load_row<NREG>(Lt, gw, G, lane, xn);
   for (uint32_t j = gw; j < E; j += nw) {
-    const double *row = Lt + (size_t)j * G;
-    double pz[NREG], s[NREG];
-    double m = -INFINITY;
+    double x[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) x[i] = xn[i];
+    if (j + nw < E) dense_load_row<NREG>(Lt, j + nw, G, lane, xn);  // in flight under this EC's arithmetic
+    double mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) mx = fmax(mx, fma(a, x[i], uu[i]));
+    const double m = (double)wave_max_f((float)mx);
+    double Z = 0.0, S1 = 0.0, pe[NREG];
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
-      const int g = lane + 64 * i;
-      const double x = g < G ? row[g] : 0.0;
-      pz[i] = g < G ? a * x + uu[i] : -INFINITY;
-      s[i] = oma * x + ww[i];
-      m = fmax(m, pz[i]);
-    }
-    m = wave_max(m);
-    double Z = 0.0, S1 = 0.0;
-#pragma unroll
-    for (int i = 0; i < NREG; ++i) {
-      const int g = lane + 64 * i;
-      const double pe = g < G ? exp(pz[i] - m) : 0.0;
-      pz[i] = pe;
-      Z += pe;
-      S1 += pe * s[i];
+      pe[i] = exp(fma(a, x[i], uu[i]) - m);
+      Z += pe[i];
+      S1 = fma(pe[i], fma(oma, x[i], ww[i]), S1);
     }
     Z = wave_sum(Z);
     S1 = wave_sum(S1);
     const double iZ = 1.0 / Z, sbar = S1 * iZ;
+    // (the variance about the mean, not from two moments: near convergence it is ten orders below the mean's square)
     double v = 0.0;
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
-      const double d = s[i] - sbar;
-      v += pz[i] * d * d;
+      const double d = fma(oma, x[i], ww[i]) - sbar;
+      v = fma(pe[i] * d, d, v);
     }
     v = wave_sum(v);
     nn += v * iZ;
@@ -81,41 +111,45 @@ __global__ __launch_bounds__(256) void k_dense_passB(const Scalars *sc, const do
 #pragma unroll
   for (int i = 0; i < NREG; ++i) {
     const int g = lane + 64 * i;
-    uu[i] = g < G ? u[g] : 0.0;
+    uu[i] = g < G ? u[g] : -INFINITY;
     acc[i] = 0.0;
   }
   double s_clogZ = 0.0, s_rH = 0.0;
+  double xn[NREG], cn = 0.0;
+  if (gw < E) {
+    dense_load_row<NREG>(Lt, gw, G, lane, xn);
+    cn = cvec[gw];
+  }
   for (uint32_t j = gw; j < E; j += nw) {
-    const double *row = Lt + (size_t)j * G;
-    double x[NREG], pz[NREG];
-    double m = -INFINITY;
+    double x[NREG];
 #pragma unroll
-    for (int i = 0; i < NREG; ++i) {
-      const int g = lane + 64 * i;
-      x[i] = g < G ? row[g] : 0.0;
-      pz[i] = g < G ? a * x[i] + uu[i] : -INFINITY;
-      m = fmax(m, pz[i]);
+    for (int i = 0; i < NREG; ++i) x[i] = xn[i];
+    const double c = cn;
+    if (j + nw < E) {  // the next EC's row in flight under this one's arithmetic
+      dense_load_row<NREG>(Lt, j + nw, G, lane, xn);
+      cn = cvec[j + nw];
     }
-    m = wave_max(m);
+    double mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) mx = fmax(mx, fma(a, x[i], uu[i]));
+    const double m = (double)wave_max_f((float)mx);
     double Z = 0.0, hs = 0.0;
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
-      const int g = lane + 64 * i;
-      const double y = pz[i] - m;
-      const double pe = g < G ? exp(y) : 0.0;
-      hs += g < G ? pe * (x[i] - y) : 0.0;
-      pz[i] = pe;
+      const double y = fma(a, x[i], uu[i]) - m;
+      const double pe = exp(y);
+      hs += pe != 0.0 ? pe * (x[i] - y) : 0.0;  // (lanes past G, underflowed cells: y = -inf)
+      x[i] = pe;
       Z += pe;
     }
     Z = wave_sum(Z);
     hs = wave_sum(hs);
-    const double c = cvec[j];
     if (c != 0.0) {
       const double rj = c / Z;
       s_clogZ += c * log(Z);
       s_rH += rj * hs;
 #pragma unroll
-      for (int i = 0; i < NREG; ++i) acc[i] += rj * pz[i];
+      for (int i = 0; i < NREG; ++i) acc[i] = fma(rj, x[i], acc[i]);
     }
   }
 #pragma unroll

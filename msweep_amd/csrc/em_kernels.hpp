@@ -32,7 +32,11 @@ __global__ __launch_bounds__(1024) void k_em_init(Scalars *sc, int G, int n_lut,
 __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, int npartS,
                                                 const double *partS, const double *Nc,
                                                 const double *alpha0, double *u, double *theta,
-                                                const double *lut, double *e, TabDev X, TraceDev tr) {
+                                                const double *lut, double *e, TabDev X, TraceDev tr, float *e32) {
+  // e32 != nullptr: --emprecision float served by the fp32 sweep (em_f32_kernels.hpp): the log-likelihood is rounded
+  // to float before the stop rule sees it, theta, log theta and e_g are floats (kept as doubles of float value where
+  // fp64 kernels read them: k_redfin's e_g, the gamma kernels' u), e32 receives e_g for the next sweep
+  const bool f32 = e32 != nullptr;
   __shared__ double sh[16 * 4];
   const int tid = threadIdx.x, nt = blockDim.x;
   double q[4] = {0.0, 0.0, 0.0, 0.0};  // sum c log Z, sum r H, sum (alpha - 1), sum u Nc
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, 
   }
   block_sum_n<4>(q, sh);
   const double s_clogZ = q[0], s_rH = q[1], sa = q[2], su = q[3];
-  const double ll = (flavor == 0) ? s_clogZ + (s0.M + s0.tref) * csum : s_clogZ + s_rH + su;  // a = 1: Z carries exp(-tref)
+  const double ll_raw = (flavor == 0) ? s_clogZ + (s0.M + s0.tref) * csum : s_clogZ + s_rH + su;  // a = 1: Z carries exp(-tref)
+  const double ll = f32 ? (double)(float)ll_raw : ll_raw;
   const double denom = csum + sa;
   const int it = s0.iter;
   int done = 0;
@@ -94,10 +99,11 @@ __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, 
       if (g < G) {
         double t = (ml ? ncv[k] : ncv[k] + alv[k] - 1.0) / denom;
         t = t > 0.0 ? t : 0.0;
+        if (f32) t = (double)(float)t;
         if (stop_theta) dmax = fmax(dmax, fabs(t - (it > 0 ? theta[g] : t_first)));
         theta[g] = t;
         if (trace) tr.theta[(size_t)it * G + g] = t;
-        uv[k] = log(t);
+        uv[k] = f32 ? (double)logf((float)t) : log(t);
         u[g] = uv[k];
         m = fmax(m, uv[k]);
       }
@@ -140,7 +146,12 @@ __global__ __launch_bounds__(1024) void k_em_fin(Scalars *sc, int G, int n_lut, 
   for (int k = 0; k < kStepRegs; ++k) {
     const int g = tid + k * nt;
     if (g < G) {
-      const double eg = flush_denormal(exp(uv[k] - M));
+      double eg = flush_denormal(exp(uv[k] - M));
+      if (f32) {
+        const float ef = (float)eg;
+        e32[g] = ef;
+        eg = (double)ef;
+      }
       e[g] = eg;
       se += eg;
     }

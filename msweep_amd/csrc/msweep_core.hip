@@ -29,6 +29,7 @@
 #include "likelihood_kernels.hpp"
 #include "bootstrap_kernels.hpp"
 #include "em_kernels.hpp"
+#include "em_f32_kernels.hpp"
 #include "stream_kernels.hpp"
 
 using namespace msw;
@@ -65,6 +66,8 @@ struct msw_core {
   bool hybrid() const { return enc == kEncIndex; }
   RecDec dec() const { return RecDec{enc_shift, enc_mask, enc_bhi, enc_bhiA, enc_shiftH, enc_maskH}; }
   uint32_t long_row = kLongRow;                         // ECs with more cells go one per wavefront (reset_likelihood)
+  uint64_t rows_over8 = 0;                              // rows of the slices of more than 8 rows (finish_sell)
+  bool passB_rc8 = false;                               // pass B runs its short-slice instantiation (sweep_kernels.hpp, RC = 8)
   DevBuf<uint32_t> area_slot;
   DevBuf<double> lut_area;  // lut[area_slot[i]]: what the per-slot tables are built from, in their order
   DevBuf<int> tab_built;    // k_tables bookkeeping
@@ -88,7 +91,7 @@ struct msw_core {
   TabDev tabs() const { return TabDev{tabA.p, tabB.p}; }
   DevBuf<double> partA, partS, partAcc, partC, partR, totS;
   // EC-sharded solve: this handle holds one rank's block of ECs (comm.hpp)
-  size_t lds_attr[2][80] = {};  // dynamic-LDS limit already granted per sweep instantiation
+  size_t lds_attr[3][80] = {};  // dynamic-LDS limit already granted per sweep instantiation ([2]: pass B's short-slice ones)
   msw_comm *comm = nullptr;
   bool in_collective = false;  // a solve / sharded build is under way: a failure now strands the peers (guarded())
   DevBuf<double> commA, commB;  // 1 and G + 4 doubles
@@ -113,6 +116,8 @@ struct msw_core {
   SolveOpts opts;  // msw_core_set_option
   // EM state
   DevBuf<double> logth;
+  DevBuf<float> e32, tab32;  // --emprecision float: e_g and the slot table {x_i - p0} as floats (em_f32_kernels.hpp)
+  bool em_f32 = false;       // the EM run under way is served by the fp32 kernels (launch_passB)
 
   // ---- bootstrap -------------------------------------------------------------------------
   DevBuf<double> cp;
@@ -442,6 +447,19 @@ template <int ENC, int GM, bool TL>
 void launch_passB_t(msw_core *h) {
   const size_t lds = pass_lds_bytes(GM, h->n_tab_lds, h->G, false, ENC == kEncIndex);
   const bool ml = h->cls.s0[kSliceClasses - 1] > 0;
+  if constexpr (ENC == kEncNarrow) {
+    if (h->passB_rc8 && !ml) {  // (nearly) every slice at most 8 rows: 16 wavefronts per workgroup (finish_sell)
+      auto k8 = k_passB<ENC, GM, TL, false, 8>;
+      prepare_sweep(k8, lds, h->lds_attr[2][2 * GM + (TL ? 1 : 0)]);
+      const auto rg_of = [&](uint32_t g0) {
+        return GM == 4 ? RangeB{g0, std::min<uint32_t>(kRangeGroups, h->G - g0), g0 == 0 ? 1 : 0} : RangeB{0, 0, 1};
+      };
+      for (uint32_t g0 = 0; g0 < (GM == 4 ? h->G : 1u); g0 += kRangeGroups)
+        hipLaunchKernelGGL(k8, dim3(h->nblk), dim3(pass_threads_B<ENC, 8>()), lds, h->stream, h->sc.p, sell_view(h), h->e.p,
+                           h->tabB.p, h->partAcc.p, h->partS.p, h->Acc.p, rg_of(g0), h->guard_view());
+      return;
+    }
+  }
   auto k = ml ? k_passB<ENC, GM, TL, true> : k_passB<ENC, GM, TL, false>;
   prepare_sweep(k, lds, h->lds_attr[1][(ml ? 40 : 0) + ENC * 10 + 2 * GM + (TL ? 1 : 0)]);
   if (GM == 4) {  // one run per range of groups; the first also delivers the ELBO terms
@@ -560,13 +578,30 @@ void launch_passA(msw_core *h) {
   h->timing.passA_launches++;
 }
 
+// --emprecision float: the fp32 sweep of em_f32_kernels.hpp (run_em decides; one persistent workgroup per CU)
+bool em_f32_layout_ok(const msw_core *h) {
+  return kFx && h->flavor == 0 && h->enc == kEncNarrow && h->glds && h->tlds && !h->comm && h->n_tab_lds == h->n_area &&
+         h->G <= (uint32_t)(kStepRegs * 1024) && em_f32_lds_bytes(h->n_tab_lds, h->G) <= kLdsMax &&
+         !getenv("MSWEEP_EM_FLOAT_AS_DOUBLE");  // (developer switch: the fp64 kernels under MSW_PREC_FLOAT, as until round 4)
+}
+void launch_em_passB_f32(msw_core *h) {
+  const size_t lds = em_f32_lds_bytes(h->n_tab_lds, h->G);
+  const bool ml = h->cls.s0[kSliceClasses - 1] > 0;
+  auto k = ml ? k_em_passB_f32<true> : k_em_passB_f32<false>;
+  prepare_sweep(k, lds, h->lds_attr[2][30 + (ml ? 1 : 0)]);
+  hipLaunchKernelGGL(k, dim3(h->nblk), dim3(1024), lds, h->stream, h->sc.p, sell_view(h), h->e.p, h->e32.p, h->tab32.p,
+                     h->partAcc.p, h->partS.p, h->guard_view());
+}
+
 void launch_passB(msw_core *h) {
   std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
   if (h->profiling) {
     ev = &next_pair(h->evB, h->evB_used);
     MSW_HIP(hipEventRecord(ev->first, h->stream));
   }
-  if (h->flavor == 0) {
+  if (h->flavor == 0 && h->em_f32) {
+    launch_em_passB_f32(h);
+  } else if (h->flavor == 0) {
     if (h->gmodeB == 0) MSW_HIP(hipMemsetAsync(h->Acc.p, 0, ((size_t)h->G + kSentinels) * sizeof(double), h->stream));
     MSW_DISPATCH_B(launch_passB_t, h);
   } else {
@@ -576,9 +611,10 @@ void launch_passB(msw_core *h) {
   if (ev) MSW_HIP(hipEventRecord(ev->second, h->stream));
   h->timing.passB_launches++;
   // column sums across workgroups + N_g / lgamma / digamma, spread over G/16 workgroups
-  const bool partials = (h->flavor == 1) || h->gmodeB > 0;
+  const bool partials = (h->flavor == 1) || h->gmodeB > 0 || h->em_f32;
   const int nb = h->npart_rows();
-  const int fxrows = h->flavor == 0 ? 1 : 0;  // the CSR sweeps leave fixed-point integer rows (kFx)
+  // the CSR sweeps leave fixed-point integer rows (kFx); 2: the fp32 EM sweep's, without the per-group factor
+  const int fxrows = h->flavor == 0 ? (h->em_f32 ? 2 : 1) : 0;
   if (h->comm) {
     // EC-sharded: local column sums + ELBO terms -> one all-reduce -> k_redfin on the totals.  The
     // fixed-point column sums are all-reduced as INTEGERS: exact, so the totals -- and with them every
@@ -691,6 +727,7 @@ void begin_solve(msw_core *h, double tol, size_t max_iters) {
   const double *cpart = h->partC.p;
   int ncpart = kCvecBlocks;
   if (h->comm) {  // global sum of the EC counts (bound constant, theta normalisation)
+    h->comm->rendezvous();  // the ranks' calls may be seconds apart on the host: meet before the device-side waits
     hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(1024), 0, h->stream, h->sc.p, 0, kCvecBlocks, h->partC.p,
                        h->commA.p);
     h->comm->allreduce(h->commA.p, 1, h->stream);
@@ -707,6 +744,7 @@ void begin_solve(msw_core *h, double tol, size_t max_iters) {
 // iters_start > 0: the solve on the handle is continued (msw_core_continue) -- no initial evaluation
 void run_rcg(msw_core *h, size_t max_iters, size_t iters_start = 0) {
   const int G = (int)h->G, n_lut = h->n_tab_inline();
+  if (iters_start > 0 && h->comm) h->comm->rendezvous();  // msw_core_continue: as begin_solve
   if (iters_start == 0) {
     // initial update_N_k on gamma = log(1/G): the first slot's k_finstep finds it as Scalars::have_eval = 2
     hipLaunchKernelGGL(k_prepB, dim3(1), dim3(1024), 0, h->stream, h->sc.p, G, n_lut, h->u.p, h->lut_area.p,
@@ -985,6 +1023,8 @@ int msw_core_layout_info(msw_handle h, msw_layout_info *out) {
     li.n_slices = h->nslices;
     li.n_long_ecs = h->n_long;
     li.bank_scheduled = h->packed_scheduled ? 1 : 0;
+    li.passB_reg_cells = h->passB_rc8 ? 8 : kRegCells;
+    li.rows_over_8 = h->rows_over8;
     std::vector<uint32_t> off((size_t)h->nslices + 1);
     MSW_HIP(hipMemcpy(off.data(), h->slice_off.p, off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     li.rows = off[h->nslices];

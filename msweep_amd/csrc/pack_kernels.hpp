@@ -51,6 +51,17 @@ __global__ __launch_bounds__(256) void k_pack_keys(const uint32_t *rowptr, uint3
     if (mine[i]) atomicAdd(&counts[i], mine[i]);
 }
 
+// *out += rows of the slices of more than `limit` rows (finish_sell: which instantiation of pass B the layout gets)
+__global__ __launch_bounds__(256) void k_rows_over(const uint32_t *slice_off, uint32_t nslices, uint32_t limit,
+                                                  unsigned long long *out) {
+  unsigned long long mine = 0;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nslices; s += gridDim.x * blockDim.x) {
+    const uint32_t len = slice_off[s + 1] - slice_off[s];
+    if (len > limit) mine += len;
+  }
+  if (mine) atomicAdd(out, mine);
+}
+
 // out[i] = cells of the i-th long EC (i < n_long) / cells of slice i's first EC
 __global__ __launch_bounds__(256) void k_pack_lens(const uint32_t *rowptr, const uint32_t *perm, uint32_t n_long,
                                                   uint32_t nslices, int even, SliceClasses cls, uint32_t *long_len,

@@ -10,7 +10,10 @@
 // No grid-wide step: chunk c of every rank only talks to chunk c of the others.  Two slot sets alternate with the parity
 // of the sequence number: a source can be one message ahead of a receiver, never two (it needs the receiver's flag of the
 // message in between).  Every wait is bounded (MSWEEP_PEER_TIMEOUT_MS, default 2000): a rank that never arrives turns
-// into an error on the host, not a hung grid.
+// into an error on the host, not a hung grid.  The bound covers device-side skew only: the ranks meet on the host
+// (rendezvous(): one token through the set-up communicator) at the start of every sharded solve or continuation, so a
+// caller that comes back seconds after its peers costs them nothing; and once a wait has timed out every later
+// collective of the rank returns at once (the status word), so a dead peer costs ONE timeout, not one per queued kernel.
 //   * one process per GPU : inboxes are exchanged as hipIpc handles through the RCCL communicator that also keeps the
 //                           host all-gather and the abort path;
 //   * thread-ranks        : plain device pointers (peer access enabled between devices of the process).
@@ -38,6 +41,9 @@ __global__ __launch_bounds__(kPeerChunk) void k_peer_allreduce(PeerBoxes pb, int
   const size_t c = blockIdx.x, w = c * kPeerChunk + t, chunks = cap / kPeerChunk;
   const size_t par = (size_t)(seq & 1);
   const bool live = w < na + nb;
+  // a wait of this rank has already timed out (check() clears the word on the host): the solve is lost, its queued
+  // collectives drain without waiting again
+  if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
   unsigned long long v = 0;
   if (live) v = w < na ? a[w] : (unsigned long long)__double_as_longlong(b[w - na]);
   if (t == 0) s_bad = 0;
@@ -103,7 +109,7 @@ struct PeerComm final : msw_comm {
   PeerComm(std::unique_ptr<msw_comm> b, bool ipc_) : base(std::move(b)), ipc(ipc_) {
     if (base->size() > kPeerMaxRanks) throw HipError("MSWEEP_ALLREDUCE=peer: at most 16 ranks");
     const char *e = std::getenv("MSWEEP_PEER_TIMEOUT_MS");
-    const double ms = e && std::atof(e) > 0 ? std::atof(e) : 2000.0;
+    const double ms = e && std::atof(e) > 0 ? std::atof(e) : 30000.0;  // (ShmComm's host waits: 60 s; RCCL: none)
     timeout_ticks = (unsigned long long)(ms * 1e5);  // wall_clock64: 100 MHz
     if (const char *s = std::getenv("MSWEEP_PEER_TEST_SKIP_RANK")) skip_rank = std::atoi(s);
   }
@@ -112,6 +118,12 @@ struct PeerComm final : msw_comm {
   int size() const override { return base->size(); }
   void abort() override { base->abort(); }
   void allgather_host(const double *send, size_t cnt, double *recv) override { base->allgather_host(send, cnt, recv); }
+  void rendezvous() override {
+    if (dynamic_cast<LocalComm *>(base.get())) return;  // thread-ranks launch every collective together already (launch())
+    double token = 0.0;
+    std::vector<double> all((size_t)size());
+    base->allgather_host(&token, 1, all.data());
+  }
 
   void release() {
     for (void *p : opened) (void)hipIpcCloseMemHandle(p);
@@ -154,14 +166,13 @@ struct PeerComm final : msw_comm {
       hipIpcMemHandle_t hd;
       static_assert(sizeof(hd) <= 64, "hipIpcMemHandle_t is 64 bytes");
       if (hipIpcGetMemHandle(&hd, fresh) != hipSuccess) {
-        // a runtime that exports no handle for a fine-grained allocation: an ordinary one instead -- every access
-        // of the kernel is a system-scope atomic (write-through stores, cache-bypassing loads) either way
+        // (no ordinary allocation instead: coarse-grained memory is coherent for its OWNER only at kernel boundaries --
+        // a peer's xGMI store does not invalidate the owner's L2, so the waiting kernel could miss the flag, or see
+        // the flag with a stale payload)
         (void)hipGetLastError();
         (void)hipFree(fresh);
-        MSW_HIP(hipMalloc(reinterpret_cast<void **>(&fresh), total * 8));
-        MSW_HIP(hipMemsetAsync(fresh, 0, total * 8, stream));
-        MSW_HIP(hipStreamSynchronize(stream));
-        MSW_HIP(hipIpcGetMemHandle(&hd, fresh));
+        throw HipError("MSWEEP_ALLREDUCE=peer: this runtime cannot export fine-grained device memory over hipIpc; "
+                       "use MSWEEP_ALLREDUCE=rccl (the default)");
       }
       std::memcpy(rec, &hd, sizeof hd);
     } else {

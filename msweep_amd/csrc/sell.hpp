@@ -54,6 +54,14 @@ constexpr uint32_t kSentinels = 64;  // one sentinel group per lane: padding nev
 // length, so the classes are contiguous: class c = 0..6 <-> m = 64 >> c.  s0 / p0: first slice / first EC position
 // (within the sliced part of the permuted order) of every class.
 // ---------------------------------------------------------------------------------------
+// rows a slice lane holds at most = records per EC lane the sweeps keep in registers (sweep_kernels.hpp kRegCells).
+// 16 by default; 8 (a developer build, tools/ab_build.py) halves the sweeps' record buffers and kept values -- ECs of
+// 9..16 cells then take two lanes -- which is what 16 wavefronts per workgroup of pass B need to stay in registers.
+#ifndef MSW_REG_CELLS
+#define MSW_REG_CELLS 16
+#endif
+constexpr int kRowsPerLane = MSW_REG_CELLS;
+static_assert(kRowsPerLane == 16 || kRowsPerLane == 8, "slices of at most 16 or 8 rows");
 constexpr int kSliceClasses = 7;
 constexpr uint32_t kMaxLgm = kSliceClasses - 1;  // class c: 2^(kMaxLgm - c) lanes per EC
 struct SliceClasses {
@@ -64,7 +72,7 @@ struct SliceClasses {
 __host__ __device__ inline int slice_class_of(uint32_t len, bool multilane) {
   if (!multilane) return kSliceClasses - 1;
   uint32_t lgm = 0;
-  while (lgm < kMaxLgm && len > (16u << lgm)) ++lgm;
+  while (lgm < kMaxLgm && len > ((uint32_t)kRowsPerLane << lgm)) ++lgm;
   return (int)(kMaxLgm - lgm);
 }
 struct SliceGeo {
@@ -120,7 +128,7 @@ constexpr uint32_t kC8Escape = 255;
 #define MSW_W_XT 4
 #define MSW_W_E 2
 #endif
-constexpr int kLongRow = 1024;      // ECs with more cells than this take the wavefront-per-EC path (64 lanes x 16 rows)
+constexpr int kLongRow = 64 * kRowsPerLane;  // 1024: ECs with more cells than this take the wavefront-per-EC path (64 lanes x 16 rows)
 constexpr int kLongRowOneLane = 256;  // ... when every EC takes one lane (MSWEEP_MULTILANE=0: slices of up to 256 rows)
 #ifndef MSW_COLD_ROWS
 #define MSW_COLD_ROWS 2

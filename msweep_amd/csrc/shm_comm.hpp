@@ -20,7 +20,10 @@ namespace msw {
 struct ShmComm final : msw_comm {
   struct Hdr {
     std::atomic<uint32_t> magic, arrived, generation, failed;
+    std::atomic<int64_t> created_s;  // CLOCK_REALTIME seconds at which rank 0 initialised the segment
   };
+  static int64_t now_s() { return (int64_t)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count(); }
+  static constexpr int64_t kFreshSeconds = 120;  // ranks of one launch start within seconds of each other
   static constexpr size_t kRowBytes = 1u << 20;  // staging row per rank; longer messages go in pieces
   static constexpr uint32_t kMagic = 0x6d737763u;
   int r, n;
@@ -39,30 +42,49 @@ struct ShmComm final : msw_comm {
       (void)shm_unlink(name.c_str());
       fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
       if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) throw HipError("msw_comm_create_shm: cannot create " + name);
-    } else {
-      for (;;) {  // rank 0 creates the segment; the others wait for it and for its size
+    }
+    // rank 0 creates the segment; the others wait for it, for its size and for its header -- and refuse a segment of
+    // the same name that an earlier run left behind (it crashed between creating and unlinking the name): such a
+    // segment is initialised, possibly marked failed, and every rank that joined it would wait out its 60 s.  A
+    // segment is taken only if rank 0 stamped it within the last kFreshSeconds; an older one is dropped and the
+    // name polled again until rank 0 of THIS launch has replaced it (it unlinks the name first).
+    void *p = MAP_FAILED;
+    for (;;) {
+      if (r != 0) {
         fd = shm_open(name.c_str(), O_RDWR, 0600);
         struct stat st;
-        if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
-        if (fd >= 0) close(fd);
-        if (late()) throw HipError("msw_comm_create_shm: rank 0 did not create " + name);
-        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        if (!(fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes)) {
+          if (fd >= 0) close(fd);
+          if (late()) throw HipError("msw_comm_create_shm: rank 0 did not create " + name);
+          std::this_thread::sleep_for(std::chrono::milliseconds(2));
+          continue;
+        }
       }
-    }
-    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) throw HipError("msw_comm_create_shm: mmap failed");
-    hdr = static_cast<Hdr *>(p);
-    rows = static_cast<unsigned char *>(p) + 4096;
-    if (r == 0) {
-      hdr->arrived = 0, hdr->generation = 0, hdr->failed = 0;
-      hdr->magic.store(kMagic, std::memory_order_release);
-    } else {
-      while (hdr->magic.load(std::memory_order_acquire) != kMagic) {
-        if (late()) throw HipError("msw_comm_create_shm: the segment was never initialised");
+      p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if (p == MAP_FAILED) throw HipError("msw_comm_create_shm: mmap failed");
+      hdr = static_cast<Hdr *>(p);
+      if (r == 0) {
+        hdr->arrived = 0, hdr->generation = 0, hdr->failed = 0;
+        hdr->created_s.store(now_s());
+        hdr->magic.store(kMagic, std::memory_order_release);
+        break;
+      }
+      bool fresh = false;
+      while (!late()) {
+        if (hdr->magic.load(std::memory_order_acquire) == kMagic) {
+          fresh = now_s() - hdr->created_s.load() <= kFreshSeconds;
+          break;
+        }
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
       }
+      if (fresh) break;
+      munmap(p, bytes);
+      hdr = nullptr;
+      if (late()) throw HipError("msw_comm_create_shm: no freshly initialised segment " + name + " appeared (a stale one of an earlier run was ignored)");
+      std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
+    rows = reinterpret_cast<unsigned char *>(hdr) + 4096;
     barrier();  // every rank has mapped the segment: rank 0 may unlink the name
     if (r == 0) (void)shm_unlink(name.c_str());
   }

@@ -477,7 +477,8 @@ __global__ __launch_bounds__(kRedfinThreads) void k_redfin(const Scalars *sc, in
       // the same units and the same modular arithmetic: the sum, N_g itself, is below 2^62 units and comes
       // out right whatever its two parts wrapped to.  (2^K f_g p0 W < 2^83: split at 2^32 like the cells'
       // two-part adds; its fp64 rounding, 2^-53 of the background share, is what the guard bounds.)
-      const double fg = fx_factor(eg0, fx_expbits(s0.fx_shift));
+      // (fxrows == 2: the fp32 EM sweep's rows, em_f32_kernels.hpp -- no per-group factor, units of 2^-K reads)
+      const double fg = fxrows == 2 ? (eg0 > 0.0 ? eg0 : 1.0) : fx_factor(eg0, fx_expbits(s0.fx_shift));
       const double t1 = fg * (s0.p0 * W) * s0.fx_scale;
       const double th1 = floor(t1 * 0x1p-32), tl1 = fma(-th1, 0x1p32, t1);
       const unsigned long long b =

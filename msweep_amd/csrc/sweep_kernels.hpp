@@ -24,7 +24,7 @@
 
 namespace msw {
 
-constexpr int kRegCells = 16;  // cells per EC a wave keeps in registers (longer slices stream)
+constexpr int kRegCells = kRowsPerLane;  // 16: cells per EC a wave keeps in registers (longer slices stream; sell.hpp)
 #ifndef MSW_LONG_STEP
 #define MSW_LONG_STEP 8
 #endif
@@ -34,7 +34,7 @@ constexpr int kLongStep = MSW_LONG_STEP;  // records per lane and step on the wa
 #define MSW_REVERSE_B true
 #endif
 #ifndef MSW_B_KEEPN
-#define MSW_B_KEEPN 16
+#define MSW_B_KEEPN MSW_REG_CELLS
 #endif
 #ifndef MSW_PASSA_BATCH
 #define MSW_PASSA_BATCH 4
@@ -112,9 +112,9 @@ __device__ __forceinline__ double uniform_d(double v) {
 
 // One slice held in registers (<= kRegCells cells per EC): records, geometry and -- pass B -- the
 // EC's multiplicity.
-template <int ENC>
+template <int ENC, int RC = kRegCells>
 struct SliceBuf {
-  typename Rec<ENC>::T r[kRegCells];
+  typename Rec<ENC>::T r[RC];
   // index records (sell.hpp): the rows of the slice's cold segment; r then holds the hot rows only
   typename Rec<ENC>::T rc[ENC == kEncIndex ? kColdRows : 1];
   uint32_t sl, o, len, nhot;
@@ -126,11 +126,11 @@ struct SliceBuf {
 // rows at a time; a slice may have an odd number of rows (sell.hpp odd_slices: until round 3
 // every slice was padded in memory -- 5 % of cfg3's record stream, 10 % of cfg5's): its missing last row is the
 // lane's null record, made here instead of being read.
-template <int ENC>
+template <int ENC, int RC>
 __device__ __forceinline__ void load_slice(const uint32_t *rec, size_t base, uint32_t len,
-                                           typename Rec<ENC>::T (&r)[kRegCells], typename Rec<ENC>::T nullr) {
+                                           typename Rec<ENC>::T (&r)[RC], typename Rec<ENC>::T nullr) {
 #pragma unroll
-  for (int k = 0; k < kRegCells; k += 2) {
+  for (int k = 0; k < RC; k += 2) {
     if ((uint32_t)k < len) {
       r[k] = Rec<ENC>::load(rec, base + (size_t)k * 64);
       if constexpr (odd_slices(ENC)) {
@@ -179,8 +179,8 @@ template <int ENC>
 constexpr int pass_threads_A() {
   return ENC == kEncValue ? MSW_VAL_THREADS : (ENC == kEncIndex ? MSW_HYB_THREADS_A : kPassThreads);
 }
-template <int ENC>
-constexpr int pass_threads_B() { return ENC == kEncValue ? MSW_VAL_THREADS : kPassThreadsB; }
+template <int ENC, int RC = kRegCells>
+constexpr int pass_threads_B() { return ENC == kEncValue ? MSW_VAL_THREADS : (RC < kRegCells ? kPassThreadsB8 : kPassThreadsB); }
 
 // s_waitcnt vmcnt(0), leaving the other counters alone (gfx9 layout: vmcnt = imm[3:0] | imm[15:14] << 4)
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
@@ -203,7 +203,7 @@ __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70);
 #else
 #define MSW_REC_ROW(o) (o)
 #endif
-template <int ENC, bool REVERSE>
+template <int ENC, bool REVERSE, int RC = kRegCells>
 struct SliceStream {
   const SellDev &S;
   uint32_t s_first, nw, n_mine, lane;
@@ -248,7 +248,7 @@ struct SliceStream {
   }
   // j = position inside the current 64-slice chunk; j >= n_chunk fetches an empty slice
   template <class Issue>
-  __device__ __forceinline__ void fetch(uint32_t base, uint32_t j, SliceBuf<ENC> &b, Issue &issue) {
+  __device__ __forceinline__ void fetch(uint32_t base, uint32_t j, SliceBuf<ENC, RC> &b, Issue &issue) {
     typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const v2u_t lds_cu2_t;
     const v2u_t oe = *(lds_cu2_t *)(size_t)(geo + j * 8);
@@ -261,10 +261,10 @@ struct SliceStream {
       const uint32_t ox = uniform(oe.x);
       b.o = ox & ((1u << kGeoHotShift) - 1u);
       b.nhot = ox >> kGeoHotShift;
-      if (b.len <= (uint32_t)kRegCells) load_slice_split(S.rec, (size_t)b.o * 64 + lane, b.len, b.nhot, b.r, b.rc, nullr, nullr_hot);
+      if (b.len <= (uint32_t)RC) load_slice_split(S.rec, (size_t)b.o * 64 + lane, b.len, b.nhot, b.r, b.rc, nullr, nullr_hot);
     } else {
       b.o = uniform(oe.x);
-      if (b.len <= (uint32_t)kRegCells) load_slice<ENC>(S.rec, (size_t)MSW_REC_ROW(b.o) * 64 + lane, b.len, b.r, nullr);
+      if (b.len <= (uint32_t)RC) load_slice<ENC>(S.rec, (size_t)MSW_REC_ROW(b.o) * 64 + lane, b.len, b.r, nullr);
     }
     issue(b);
   }
@@ -276,7 +276,7 @@ struct SliceStream {
       if (base) gather_offs(base >> 6);
       commit_offs();
       const uint32_t n_chunk = n_mine > base ? (n_mine - base < 64u ? n_mine - base : 64u) : 0u;
-      SliceBuf<ENC> A = {}, B = {};
+      SliceBuf<ENC, RC> A = {}, B = {};
       uint32_t j = 0;
       fetch(base, 0, A, issue);
       for (;;) {
@@ -469,11 +469,13 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
         case 2: fixed(b, std::integral_constant<int, 2>{}, std::false_type{}); break;
         case 4: fixed(b, std::integral_constant<int, 4>{}, std::false_type{}); break;
         case 6: fixed(b, std::integral_constant<int, 6>{}, std::false_type{}); break;
+#if MSW_REG_CELLS == 16
         case 8: fixed(b, std::integral_constant<int, 8>{}, std::false_type{}); break;
         case 10: fixed(b, std::integral_constant<int, 10>{}, std::false_type{}); break;
         case 12: fixed(b, std::integral_constant<int, 12>{}, std::false_type{}); break;
         case 14: fixed(b, std::integral_constant<int, 14>{}, std::false_type{}); break;
-        default: fixed(b, std::integral_constant<int, 16>{}, std::false_type{}); break;
+#endif
+        default: fixed(b, std::integral_constant<int, kRegCells>{}, std::false_type{}); break;
       }
     };
     // a slice from memory, pair by pair (rare shapes only: no second copy of the per-count code)
@@ -678,8 +680,15 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
 // 0 = e_g / column sums in global memory; 1 = in LDS, column sums right behind e_g;
 // 2 = in LDS, column sums at the fixed distance kAccFixed (an instruction immediate: one VALU
 // operation less per scattered cell; needs 8 * Gp <= kAccFixed).
-template <int ENC, int GMODE, bool TLDS, bool ML>
-__global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
+// RC = records per slice lane kept in registers: 16 (kRegCells: every slice of the layout), or 8 -- the SHORT-SLICE
+// instantiation (round 5) for likelihoods whose slices have (nearly all) at most 8 rows: record buffers 32 -> 16
+// registers, kept values 32 -> 16, 117 instead of 144 registers per lane, so SIXTEEN wavefronts per workgroup fit
+// (four per SIMD instead of three) without the spills that sank the 14 / 16-wavefront builds of the 16-row kernel
+// (56 bytes of scratch per lane, reloaded in every slice).  Pass B is bound by LDS time and VALU issue in balance,
+// overlapped by the wavefronts of a SIMD: a fourth one is worth 16 % of the sweep at cfg5 (243 -> 204 us in one job).
+// Longer slices take the streaming branch in chunks of 8 rows (host: launch_passB_t picks RC by the rows they hold).
+template <int ENC, int GMODE, bool TLDS, bool ML, int RC = kRegCells>
+__global__ __launch_bounds__((pass_threads_B<ENC, RC>())) void k_passB(const Scalars *sc, SellDev S, const double *e_g,
                                                        const double2 *tabB_g, double *partAcc,
                                                        double *partS, double *accGlobal, RangeB rg, GuardDev GD) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -687,7 +696,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   using RT = typename R::T;
   constexpr bool HYB = ENC == kEncIndex;  // index records + hybrid slot area (see k_passA)
   constexpr bool VAL = ENC == kEncValue;  // value records: no table, exp per cell
-  constexpr int NT = pass_threads_B<ENC>();
+  constexpr int NT = pass_threads_B<ENC, RC>();
   static_assert(!((HYB || VAL) && TLDS), "index records go with the hybrid slot area, value records have no table");
   constexpr bool TL = TLDS || HYB;
   const RecDec D = rec_dec(S);
@@ -701,7 +710,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   const uint32_t acc_off = pass_acc_off(GMODE, G);
   const uint32_t scratch_off = (uint32_t)pass_scratch_off(GMODE, n_tab, G, false, HYB);
   double *sh = reinterpret_cast<double *>(smem + scratch_off);
-  SliceStream<ENC, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (NT / 64) + (tid >> 6)),
+  SliceStream<ENC, MSW_REVERSE_B, RC> stream(S, uniform(blockIdx.x * (NT / 64) + (tid >> 6)),
                               gridDim.x * (NT / 64), (uint32_t)lane,
                               scratch_off + 256u + uniform(tid >> 6) * kGeoStride);
   if (TL) {
@@ -813,13 +822,13 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
   stream.nullr = null_rec;
   if constexpr (HYB) stream.nullr_hot = R::make_h(G + (uint32_t)lane, 0u, D);
   else stream.nullr_hot = null_rec;
-  auto issue = [&](SliceBuf<ENC> &sb) {
+  auto issue = [&](SliceBuf<ENC, RC> &sb) {
     // (a byte per slice lane: the lanes of an EC that takes several hold the same one; lanes without an EC 0)
     const uint32_t q = sb.sl * 64 + lane;
     const uint32_t cj = S.c8s[q < n_lanes ? q : 0u];
     sb.c8 = q < n_lanes ? cj : 0u;
   };
-  auto process = [&](SliceBuf<ENC> &sb) {
+  auto process = [&](SliceBuf<ENC, RC> &sb) {
     const uint32_t o = sb.o, len = sb.len;
     double c = (double)sb.c8;
     // not a small integer: rare.  A wave-uniform branch with the wait for its load INSIDE: loads return in
@@ -836,11 +845,11 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
     // cells stays in registers for the scatter, any others are gathered a second time (with 16
     // wavefronts per workgroup all 16 would push the kernel into scratch, and a scratch reload
     // drains the record prefetch: hence 12 wavefronts, common.hpp).
-    constexpr int KEEPN = ENC == kEncWide ? 4 : MSW_B_KEEPN;  // 8-byte records take twice the registers
+    constexpr int KEEPN = ENC == kEncWide ? 4 : (MSW_B_KEEPN < RC ? MSW_B_KEEPN : RC);  // 8-byte records take twice the registers
     // (value records keep all 16: the alternative is a second exp per cell)
     double xv[KEEPN > 0 ? KEEPN : 1];
     // (ANY: the cells may refer to any entry of a hybrid slot area -- gathered from memory)
-    auto fixed = [&](RT(&b)[kRegCells], auto LEN, auto KEEP, auto ANY) {
+    auto fixed = [&](RT(&b)[RC], auto LEN, auto KEEP, auto ANY) {
       constexpr int L = decltype(LEN)::value;
       constexpr bool KP = decltype(KEEP)::value;
       constexpr int B = MSW_PASSB_BATCH;  // cells whose gathers are issued together
@@ -867,25 +876,30 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         }
       }
     };
-    auto cells = [&](RT(&b)[kRegCells], uint32_t n, auto KEEP) {
+    auto cells = [&](RT(&b)[RC], uint32_t n, auto KEEP) {
       n += n & 1;  // an odd slice's missing last row is a null record in the registers (load_slice)
+      // (RC = 8: the cases above 8 fold into the last one)
+      auto at_most = [&](auto N) {
+        constexpr int L = decltype(N)::value < RC ? decltype(N)::value : RC;
+        fixed(b, std::integral_constant<int, L>{}, KEEP, std::false_type{});
+      };
       switch (n) {
         case 0: break;
-        case 2: fixed(b, std::integral_constant<int, 2>{}, KEEP, std::false_type{}); break;
-        case 4: fixed(b, std::integral_constant<int, 4>{}, KEEP, std::false_type{}); break;
-        case 6: fixed(b, std::integral_constant<int, 6>{}, KEEP, std::false_type{}); break;
-        case 8: fixed(b, std::integral_constant<int, 8>{}, KEEP, std::false_type{}); break;
-        case 10: fixed(b, std::integral_constant<int, 10>{}, KEEP, std::false_type{}); break;
-        case 12: fixed(b, std::integral_constant<int, 12>{}, KEEP, std::false_type{}); break;
-        case 14: fixed(b, std::integral_constant<int, 14>{}, KEEP, std::false_type{}); break;
-        default: fixed(b, std::integral_constant<int, 16>{}, KEEP, std::false_type{}); break;
+        case 2: at_most(std::integral_constant<int, 2>{}); break;
+        case 4: at_most(std::integral_constant<int, 4>{}); break;
+        case 6: at_most(std::integral_constant<int, 6>{}); break;
+        case 8: at_most(std::integral_constant<int, 8>{}); break;
+        case 10: at_most(std::integral_constant<int, 10>{}); break;
+        case 12: at_most(std::integral_constant<int, 12>{}); break;
+        case 14: at_most(std::integral_constant<int, 14>{}); break;
+        default: at_most(std::integral_constant<int, 16>{}); break;
       }
     };
     // row sums of a slice from memory, pair by pair (rare shapes only: no second copy of the per-count code);
     // keeps nothing: the scatter gathers again
-    auto pairs_any = [&](RT(&b)[kRegCells], uint32_t n) {
+    auto pairs_any = [&](RT(&b)[RC], uint32_t n) {
 #pragma unroll
-      for (int k = 0; k < kRegCells; k += 2) {
+      for (int k = 0; k < RC; k += 2) {
         if ((uint32_t)k < n) {  // (n odd: the pair's second record is the lane's null record, load_slice)
           const double e0 = E_(b[k]), e1 = E_(b[k + 1]);
           const double2 t0 = XTg_(b[k]), t1 = XTg_(b[k + 1]);
@@ -896,14 +910,14 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         }
       }
     };
-    // scatter of up to kRegCells cells held in b; padding records point at the lane's own sentinel
+    // scatter of up to RC cells held in b; padding records point at the lane's own sentinel
     // group: no test, no shared address
     // (kFx: rj is 2^K * r_j, the kept values are f_g * (x - p0); WIDE_ADD: the two-part adds)
-    auto scatter = [&](RT(&b)[kRegCells], uint32_t n, double rj, auto KEPT, auto WIDE_ADD) {
+    auto scatter = [&](RT(&b)[RC], uint32_t n, double rj, auto KEPT, auto WIDE_ADD) {
       constexpr bool KP = decltype(KEPT)::value;
       constexpr bool WA = decltype(WIDE_ADD)::value;
 #pragma unroll
-      for (int k = 0; k < kRegCells; k += 2) {
+      for (int k = 0; k < RC; k += 2) {
         if ((uint32_t)k < n) {  // (n odd: the pair's second record is the lane's null record, load_slice)
           double x0, x1;
           // (KEPT rows: the slice's register rows with their kept values -- for index records a hot segment's rows)
@@ -928,7 +942,7 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         }
       }
     };
-    if (len <= (uint32_t)kRegCells) {
+    if (len <= (uint32_t)RC) {
       // index records: the slice is cut into a hot segment (rows in sb.r, LDS table) and a cold one of at most
       // kColdRows rows (sb.rc, table entries from memory: issued first, consumed after the hot rows) -- or,
       // with more cold cells than that, taken from memory as a whole (all rows in sb.r)
@@ -1046,17 +1060,17 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
       }
     } else {
       // more cells per EC than the registers hold (the stream has not fetched this slice): chunks of
-      // kRegCells records through the same registers -- once for the row sums, once more (from L2)
+      // RC records through the same registers -- once for the row sums, once more (from L2)
       // for the scatter; the other wavefronts of the workgroup cover each chunk's load latency
       // (registers of their own: see pass A)
       // (keeping the first chunk's f_g (x - p0) for the scatter, like a short slice's, was tried in round 3: the
       // values live across the chunk loops push every instantiation into 300 bytes of scratch)
       const size_t base = (size_t)o * 64 + lane;
-      RT t[kRegCells];
+      RT t[RC];
       uint32_t k0 = 0;
-      for (; k0 + (uint32_t)kRegCells <= len; k0 += kRegCells) {
-        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, kRegCells, t, null_rec);
-        fixed(t, std::integral_constant<int, kRegCells>{}, std::false_type{}, std::true_type{});
+      for (; k0 + (uint32_t)RC <= len; k0 += RC) {
+        load_slice<ENC>(S.rec, base + (size_t)k0 * 64, RC, t, null_rec);
+        fixed(t, std::integral_constant<int, RC>{}, std::false_type{}, std::true_type{});
       }
       if (k0 < len) {
         const uint32_t n = len - k0;
@@ -1073,8 +1087,8 @@ __global__ __launch_bounds__(pass_threads_B<ENC>()) void k_passB(const Scalars *
         s_W += rj;
         const double rs = kFx ? rj * fxs : rj;
         const bool narrow = !kFx || (fma(rj, zbase, c) < fxt1 && rj < fxt2);
-        for (k0 = 0; k0 < len; k0 += kRegCells) {
-          const uint32_t n = len - k0 < (uint32_t)kRegCells ? len - k0 : (uint32_t)kRegCells;
+        for (k0 = 0; k0 < len; k0 += RC) {
+          const uint32_t n = len - k0 < (uint32_t)RC ? len - k0 : (uint32_t)RC;
           load_slice<ENC>(S.rec, base + (size_t)k0 * 64, n, t, null_rec);
           if (narrow) scatter(t, n, rs, std::false_type{}, std::false_type{});
           else scatter(t, n, rs, std::false_type{}, std::true_type{});

@@ -41,6 +41,12 @@ typedef struct orc_rcg_opts {
                            * n > 1: tested only after iterations n, 2n, ... (every published
                            * iteration count is a multiple of 5, docs/gpubenchmarks.md:15-25 -- the verbose log
                            * prints every 5th iteration, and "checked on a 5-grid" is the other reading)  */
+  int    extended;        /* 0 = fp64 arithmetic as in rcgpar and in the HIP kernels (default); 1 = everything between
+                           * the fp64 state and the fp64 results in x87 extended precision (64-bit significand):
+                           * orc_rcg_optl_csr's exponentials, row sums, U - sum_nz differences, column sums;
+                           * orc_rcg_optl_dense's four G x E matrices.  The judge of tools/fuzz_parity.py on inputs
+                           * that amplify rounding (a Fletcher-Reeves factor ~ 100): the structured fp64 oracle drifted
+                           * 1e-6 there while the HIP path, whose column sums are exact integers, stayed at 1e-8. */
 } orc_rcg_opts;
 
 /* EM variants (rcgpar::em_torch is absent: [UPSTREAM-UNVERIFIED]; the alternatives are explicit) */
@@ -123,6 +129,11 @@ size_t orc_em_dense(const double *logl, size_t G, size_t E, const double *logc,
 size_t orc_em_dense_opts(const double *logl, size_t G, size_t E, const double *logc,
                          const double *alpha0, double tol, size_t max_iters, const orc_em_opts *opts,
                          double *gamma_out, double *theta_out, double *bound_out);
+/* em_torch with precision "float" (src/mSWEEP.cpp:129,202) restated: fp32 arithmetic, the log-likelihood rounded to
+ * float once per iteration for the stop rule (rcg_oracle.cpp).  theta_trace: n_trace x G or NULL. */
+size_t orc_em_dense_f32(const double *logl, size_t G, size_t E, const double *logc, const double *alpha0, double tol,
+                        size_t max_iters, const orc_em_opts *opts, double *theta_out, double *bound_out,
+                        double *theta_trace, size_t n_trace);
 
 /* ---- bootstrap (src/BootstrapSample.cpp:33-73) --------------------------------------- */
 /* libstdc++ types, exactly as the reference instantiates them.  One call = `n_reps`

@@ -25,7 +25,7 @@ def build(force=False):
 
 class _Opts(C.Structure):
     _fields_ = [("init_bound", C.c_double), ("weight_newnorm", C.c_int), ("max_trace", C.c_int),
-                ("check_every", C.c_int)]
+                ("check_every", C.c_int), ("extended", C.c_int)]
 
 
 class _EmOpts(C.Structure):
@@ -132,8 +132,8 @@ class Oracle:
         return out
 
     # ---- optimiser -----------------------------------------------------------------
-    def _opts_trace(self, G, trace, init_bound, weight_newnorm, check_every=1):
-        o = _Opts(init_bound, int(weight_newnorm), int(trace), int(check_every))
+    def _opts_trace(self, G, trace, init_bound, weight_newnorm, check_every=1, extended=False):
+        o = _Opts(init_bound, int(weight_newnorm), int(trace), int(check_every), int(bool(extended)))
         t = None
         arrs = None
         if trace:
@@ -144,12 +144,13 @@ class Oracle:
         return o, t, arrs
 
     def rcg_optl_dense(self, logl, logc, alpha0, tol=1e-6, max_iters=5000, trace=0,
-                       init_bound=-100000.0, weight_newnorm=0, check_every=1):
-        """rcgpar::rcg_optl_omp restated; logl is G x E (rows = groups)."""
+                       init_bound=-100000.0, weight_newnorm=0, check_every=1, extended=False):
+        """rcgpar::rcg_optl_omp restated; logl is G x E (rows = groups).  extended: the four G x E matrices and every
+        sum over them in x87 extended precision (orc_rcg_opts::extended)."""
         logl = np.ascontiguousarray(logl, np.float64)
         G, E = logl.shape
         gamma = np.empty((G, E))
-        o, t, arrs = self._opts_trace(G, trace, init_bound, weight_newnorm, check_every)
+        o, t, arrs = self._opts_trace(G, trace, init_bound, weight_newnorm, check_every, extended)
         b = C.c_double()
         it = self.lib.orc_rcg_optl_dense(logl, G, E, np.ascontiguousarray(logc, np.float64),
                                          np.ascontiguousarray(alpha0, np.float64), tol, max_iters,
@@ -158,12 +159,13 @@ class Oracle:
 
     def rcg_optl_csr(self, rowptr, grp, lutidx, lut, logzi, G, logc, alpha0, tol=1e-6,
                      max_iters=5000, trace=0, want_gamma=False, init_bound=-100000.0, weight_newnorm=0,
-                     check_every=1):
+                     check_every=1, extended=False):
+        """the structured restatement on CSR-of-ECs; extended: its sweeps in x87 extended precision (orc_rcg_opts)"""
         rowptr = np.ascontiguousarray(rowptr, np.uint64)
         E = len(rowptr) - 1
         theta = np.empty(G)
         gamma = np.empty((G, E)) if want_gamma else None
-        o, t, arrs = self._opts_trace(G, trace, init_bound, weight_newnorm, check_every)
+        o, t, arrs = self._opts_trace(G, trace, init_bound, weight_newnorm, check_every, extended)
         b = C.c_double()
         lut = np.ascontiguousarray(lut, np.float64).ravel()
         it = self.lib.orc_rcg_optl_csr(rowptr, np.ascontiguousarray(grp, np.uint32),
@@ -210,6 +212,22 @@ class Oracle:
                                         np.ascontiguousarray(alpha0, np.float64), tol, max_iters, C.byref(eo),
                                         gamma.ctypes.data if want_gamma else None, theta, C.byref(b))
         return dict(theta=theta, gamma=gamma, iters=it, bound=b.value)
+
+    def em_dense_f32(self, logl, logc, alpha0, tol=1e-6, max_iters=5000, prior="map", stop="gain", check_every=1, trace=0):
+        """em_torch with precision "float" restated (orc_em_dense_f32): theta, iterations, the float log-likelihood."""
+        logl = np.ascontiguousarray(logl, np.float64)
+        G, E = logl.shape
+        theta = np.empty(G)
+        tr = np.full((trace, G), np.nan) if trace else None
+        b = C.c_double()
+        eo = _EmOpts({"map": 0, "ml": 1}[prior], {"gain": 0, "theta": 1}[stop], int(check_every))
+        self.lib.orc_em_dense_f32.restype = C.c_size_t
+        self.lib.orc_em_dense_f32.argtypes = [_dp, C.c_size_t, C.c_size_t, _dp, _dp, C.c_double, C.c_size_t, C.c_void_p,
+                                              _dp, C.c_void_p, C.c_void_p, C.c_size_t]
+        it = self.lib.orc_em_dense_f32(logl, G, E, np.ascontiguousarray(logc, np.float64),
+                                       np.ascontiguousarray(alpha0, np.float64), tol, max_iters, C.addressof(eo), theta,
+                                       C.addressof(b), tr.ctypes.data if trace else None, int(trace))
+        return dict(theta=theta, iters=it, bound=b.value, theta_trace=tr)
 
     # ---- bootstrap -----------------------------------------------------------------
     def bootstrap_counts(self, weights, seed, bootstrap_count, n_reps, restated=False):

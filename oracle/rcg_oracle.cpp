@@ -39,6 +39,7 @@ void orc_default_opts(orc_rcg_opts *o) {
   o->weight_newnorm = 0;
   o->max_trace = 0;
   o->check_every = 1;
+  o->extended = 0;
 }
 namespace {
 // the stop rule is tested after iteration k (0-based) only on the grid of check_every (msweep_oracle.h)
@@ -81,7 +82,11 @@ inline double bound_const_of(const double *logc, size_t E, const double *alpha0,
 // parallel region; the inner `omp for schedule(static) nowait` gives every thread the same EC
 // range for every group, so no barrier is needed between groups (per-EC scratch is only touched
 // by its owner thread).  Same arithmetic per element as one region per group.
-struct Dense {
+// R = element type of the state matrices gamma / step / oldstep and of every sum over them: double (rcgpar's), or
+// long double (orc_rcg_opts::extended: the reference-shaped algorithm carried in x87 extended precision -- the arbiter
+// of tools/fuzz_parity.py where fp64 evaluation orders part ways)
+template <class R>
+struct DenseT {
   size_t G, E;
   const double *L;
   const double *logc;
@@ -103,14 +108,14 @@ struct Dense {
   }
 
   // rcgpar logsumexp(gamma_Z, m): m_j = logsumexp over groups; gamma -= m
-  void logsumexp(double *gamma, double *m) const {
+  void logsumexp(R *gamma, R *m) const {
 #pragma omp parallel
     {
 #pragma omp for schedule(static)
       for (size_t j = 0; j < E; ++j) {
-        double mx = -std::numeric_limits<double>::infinity();
+        R mx = -std::numeric_limits<R>::infinity();
         for (size_t g = 0; g < G; ++g) mx = std::max(mx, gamma[g * E + j]);
-        double s = 0.0;
+        R s = 0.0;
         for (size_t g = 0; g < G; ++g) s += std::exp(gamma[g * E + j] - mx);
         m[j] = mx + std::log(s);
       }
@@ -122,59 +127,59 @@ struct Dense {
   }
 
   // rcgpar mixt_negnatgrad: fills step (dL_dphi) and returns newnorm
-  double negnatgrad(const double *gamma, const double *N, double *step, int weighted) const {
-    std::vector<double> colsums(E, 0.0);
-    std::vector<double> dg(G);
+  double negnatgrad(const R *gamma, const double *N, R *step, int weighted) const {
+    std::vector<R> colsums(E, (R)0.0);
+    std::vector<R> dg(G);
     for (size_t g = 0; g < G; ++g) dg[g] = orc_digamma(N[g]) - 1.0;
-    double newnorm = 0.0;
-    std::vector<double> part(nthreads(), 0.0);
+    R newnorm = 0.0;
+    std::vector<R> part(nthreads(), (R)0.0);
 #pragma omp parallel
     {
       for (size_t g = 0; g < G; ++g) {
 #pragma omp for schedule(static) nowait
         for (size_t j = 0; j < E; ++j) {
-          double s = L[g * E + j];
+          R s = L[g * E + j];
           s += dg[g] - gamma[g * E + j];
           step[g * E + j] = s;
           colsums[j] += s * std::exp(gamma[g * E + j]);
         }
       }
-      double local = 0.0;
+      R local = 0.0;
       for (size_t g = 0; g < G; ++g) {
 #pragma omp for schedule(static) nowait
         for (size_t j = 0; j < E; ++j) {
-          double t = std::exp(gamma[g * E + j]) * (step[g * E + j] - colsums[j]) * step[g * E + j];
-          if (weighted) t *= std::exp(logc[j]);
+          R t = std::exp(gamma[g * E + j]) * (step[g * E + j] - colsums[j]) * step[g * E + j];
+          if (weighted) t *= std::exp((R)logc[j]);
           local += t;
         }
       }
       part[tid()] = local;
     }
     // combine the per-thread partial sums in thread order (run-to-run reproducible)
-    for (double v : part) newnorm += v;
-    return newnorm;
+    for (R v : part) newnorm += v;
+    return (double)newnorm;
   }
 
-  void update_N(const double *gamma, double *N) const {
+  void update_N(const R *gamma, double *N) const {
     const size_t nt = nthreads();
-    std::vector<double> part(nt * G, 0.0);
+    std::vector<R> part(nt * G, (R)0.0);
 #pragma omp parallel
     {
       for (size_t g = 0; g < G; ++g) {
-        double acc = 0.0;
+        R acc = 0.0;
 #pragma omp for schedule(static) nowait
-        for (size_t j = 0; j < E; ++j) acc += std::exp(gamma[g * E + j] + logc[j]);
+        for (size_t j = 0; j < E; ++j) acc += std::exp(gamma[g * E + j] + (R)logc[j]);
         part[tid() * G + g] = acc;
       }
     }
     for (size_t g = 0; g < G; ++g) {
-      double acc = 0.0;
+      R acc = 0.0;
       for (size_t t = 0; t < nt; ++t) acc += part[t * G + g];
-      N[g] = acc + alpha0[g];
+      N[g] = (double)(acc + (R)alpha0[g]);
     }
   }
 
-  long double elbo(const double *gamma, const double *N, long double bound_const) const {
+  long double elbo(const R *gamma, const double *N, long double bound_const) const {
     long double bound = bound_const;
     std::vector<long double> part(nthreads(), 0.0L);
 #pragma omp parallel
@@ -183,10 +188,10 @@ struct Dense {
       for (size_t g = 0; g < G; ++g) {
 #pragma omp for schedule(static) nowait
         for (size_t j = 0; j < E; ++j) {
-          const double gz = gamma[g * E + j];
-          const double w = std::exp(gz + logc[j]);
+          const R gz = gamma[g * E + j];
+          const R w = std::exp(gz + (R)logc[j]);
           // 0 * (finite) = 0 for zero-count ECs (logc = -inf in bootstrap replicates)
-          acc += (w == 0.0) ? 0.0 : w * (L[g * E + j] - gz);
+          acc += (w == 0.0) ? (R)0.0 : w * ((R)L[g * E + j] - gz);
         }
       }
       part[tid()] = acc;
@@ -213,18 +218,21 @@ inline void record(orc_rcg_trace *tr, const orc_rcg_opts *o, size_t k, double bo
 
 extern "C" {
 
-size_t orc_rcg_optl_dense(const double *logl, size_t G, size_t E, const double *logc,
-                          const double *alpha0, double tol, size_t max_iters,
-                          const orc_rcg_opts *opts_in, double *gamma, double *bound_out,
-                          orc_rcg_trace *trace) {
-  orc_rcg_opts opts;
-  if (opts_in) opts = *opts_in; else orc_default_opts(&opts);
-  Dense D{G, E, logl, logc, alpha0};
+}  // extern "C"
+
+namespace {
+template <class R>
+size_t dense_state_loop(const double *logl, size_t G, size_t E, const double *logc,
+                        const double *alpha0, double tol, size_t max_iters,
+                        const orc_rcg_opts &opts, R *gamma, double *bound_out,
+                        orc_rcg_trace *trace) {
+  DenseT<R> D{G, E, logl, logc, alpha0};
   const size_t n = G * E;
   // rcg_optl_omp: gamma_Z(n_groups, n_obs, log(1/n_groups))
-  const double init = std::log(1.0 / (double)G);
+  const R init = std::log((R)1.0 / (R)G);
   for (size_t i = 0; i < n; ++i) gamma[i] = init;
-  std::vector<double> step(n, 0.0), oldstep(n, 0.0), oldm(E, 0.0), N(G, 0.0);
+  std::vector<R> step(n, (R)0.0), oldstep(n, (R)0.0), oldm(E, (R)0.0);
+  std::vector<double> N(G, 0.0);
   const long double bound_const = bound_const_of(logc, E, alpha0, G);
   double csum = 0.0;
   for (size_t j = 0; j < E; ++j) csum += std::exp(logc[j]);
@@ -276,7 +284,7 @@ size_t orc_rcg_optl_dense(const double *logl, size_t G, size_t E, const double *
       D.update_N(gamma, N.data());
       bound = D.elbo(gamma, N.data(), bound_const);
     } else {
-      std::memcpy(oldstep.data(), step.data(), n * sizeof(double));
+      std::memcpy(oldstep.data(), step.data(), n * sizeof(R));
     }
     record(trace, &opts, k, (double)bound, newnorm, beta_FR, didreset, N.data(), alpha0, G, csum);
     if (bound - oldbound < tol && !didreset && on_check_grid(opts, k)) {
@@ -286,6 +294,24 @@ size_t orc_rcg_optl_dense(const double *logl, size_t G, size_t E, const double *
     }
   }
   if (bound_out) *bound_out = (double)bound;
+  return k;
+}
+}  // namespace
+
+extern "C" {
+
+size_t orc_rcg_optl_dense(const double *logl, size_t G, size_t E, const double *logc,
+                          const double *alpha0, double tol, size_t max_iters,
+                          const orc_rcg_opts *opts_in, double *gamma, double *bound_out,
+                          orc_rcg_trace *trace) {
+  orc_rcg_opts opts;
+  if (opts_in) opts = *opts_in; else orc_default_opts(&opts);
+  if (!opts.extended)
+    return dense_state_loop<double>(logl, G, E, logc, alpha0, tol, max_iters, opts, gamma, bound_out, trace);
+  // extended: the four matrices in long double (16 bytes per cell); gamma comes back rounded to fp64
+  std::vector<long double> gx(G * E);
+  const size_t k = dense_state_loop<long double>(logl, G, E, logc, alpha0, tol, max_iters, opts, gx.data(), bound_out, trace);
+  if (gamma) for (size_t i = 0; i < G * E; ++i) gamma[i] = (double)gx[i];
   return k;
 }
 
@@ -373,73 +399,82 @@ inline double tref_of(const CsrL &S, double a) {
 }
 
 // B pass on CSR: returns Nc_g (without alpha) and the bound's data terms.
-void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double *Nc,
-                long double *bound_data, double *lse_out /*E or null*/) {
+// R = working precision of everything between the state (a, u: fp64 on every side) and the sums handed back:
+// double -- the arithmetic the HIP kernels mirror, the full-size lock-step tests -- or long double (x87 extended,
+// 64-bit significand; orc_rcg_opts::extended): exponentials, row sums, U - sum_nz differences, quotients, column sums
+// and ELBO terms carry 11 more bits and are rounded to fp64 ONCE, where the state is updated.  The kernels' column sums
+// are exact integers (64-bit fixed point) where this file's double path adds 8192-EC chunks in fp64, so on problems
+// that amplify rounding (beta ~ 100) the HIP path used to be CLOSER to the dense-state algorithm than this oracle was
+// (tools/fuzz_parity.py, seed 1 case 517): the extended path is the judge there.
+template <class R>
+void csr_pass_B_t(const CsrL &S, const StructState &st, const double *cvec, double *Nc,
+                  long double *bound_data, double *lse_out /*E or null*/) {
   const size_t G = S.G, E = S.E;
   double M = -std::numeric_limits<double>::infinity();
   for (size_t g = 0; g < G; ++g) M = std::max(M, st.u[g]);
-  std::vector<double> e(G);
-  double U = 0.0;
-  for (size_t g = 0; g < G; ++g) { e[g] = std::exp(st.u[g] - M); U += e[g]; }
-  const double a = st.a;
-  const double tref = tref_of(S, a);
-  const double p0 = std::exp(a * (S.logzi - tref));
-  std::vector<double> xm(S.n_lut), xTm(S.n_lut);
+  std::vector<R> e(G);
+  R U = 0.0;
+  for (size_t g = 0; g < G; ++g) { e[g] = std::exp((R)st.u[g] - (R)M); U += e[g]; }
+  const R a = st.a;
+  const R tref = tref_of(S, st.a);
+  const R logzi = S.logzi;
+  const R p0 = std::exp(a * (logzi - tref));
+  std::vector<R> xm(S.n_lut), xTm(S.n_lut);
   for (size_t i = 0; i < S.n_lut; ++i) {
-    const double x = std::exp(a * (S.lut[i] - tref));
+    const R x = std::exp(a * ((R)S.lut[i] - tref));
     xm[i] = x - p0;
-    xTm[i] = x * S.lut[i] - p0 * S.logzi;
+    xTm[i] = x * (R)S.lut[i] - p0 * logzi;
   }
-  const double zbase = p0 * U, hbase = p0 * S.logzi * U;
+  const R zbase = p0 * U, hbase = p0 * logzi * U;
   const size_t nch = n_chunks_of(E);
-  std::vector<double> Apart(nch * G, 0.0), Wpart(nch, 0.0);
+  std::vector<R> Apart(nch * G, (R)0.0), Wpart(nch, (R)0.0);
   std::vector<long double> clogZ(nch, 0.0L), rH(nch, 0.0L);
 #pragma omp parallel for schedule(dynamic, 1)
   for (size_t ch = 0; ch < nch; ++ch) {
     size_t j0, j1;
     chunk_range(E, nch, ch, &j0, &j1);
-    double *A = Apart.data() + ch * G;
+    R *A = Apart.data() + ch * G;
     long double sum_clogZ = 0.0L, sum_rH = 0.0L;
-    double W = 0.0;
+    R W = 0.0;
     std::vector<uint64_t> mark;  // guarded ECs: mark[g] == j + 1 <=> EC j lists group g
     for (size_t j = j0; j < j1; ++j) {
-      double zs = 0.0, hs = 0.0;
+      R zs = 0.0, hs = 0.0;
       for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
-        const double eg = e[S.grp[k]];
+        const R eg = e[S.grp[k]];
         zs += eg * xm[S.lutidx[k]];
         hs += eg * xTm[S.lutidx[k]];
       }
-      const double c = cvec[j];
-      if (!(zbase + zs >= zbase * kGuardRatio)) {
+      const R c = cvec[j];
+      if (!(zbase + zs >= zbase * (R)kGuardRatio)) {
         // Guarded EC (SURVEY.md 7.3 ii): background and listed cells cancel.  No background trick:
         // Z = sum_listed e x + p0 * (sum of e over the groups not listed, one by one); every group's
         // share of c_j added directly; the EC stays out of W.
         if (mark.empty()) mark.assign(G, 0);
-        double z = 0.0, h = 0.0, r0 = 0.0;
+        R z = 0.0, h = 0.0, r0 = 0.0;
         for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
-          const double T = S.lut[S.lutidx[k]], q = e[S.grp[k]] * std::exp(a * (T - tref));
+          const R T = S.lut[S.lutidx[k]], q = e[S.grp[k]] * std::exp(a * (T - tref));
           mark[S.grp[k]] = j + 1;
           z += q;
           h += q * T;
         }
         for (size_t g = 0; g < G; ++g) if (mark[g] != j + 1) r0 += e[g];
-        const double Zg = z + p0 * r0, Hg = h + p0 * S.logzi * r0;
-        if (lse_out) lse_out[j] = M + std::log(Zg) + a * tref;
+        const R Zg = z + p0 * r0, Hg = h + p0 * logzi * r0;
+        if (lse_out) lse_out[j] = (double)((R)M + std::log(Zg) + a * tref);
         if (c != 0.0) {
-          const double rg = c / Zg;
+          const R rg = c / Zg;
           sum_clogZ += (long double)c * std::log(Zg);
           sum_rH += (long double)rg * Hg;
           // A holds sum_j r_j (x - p0) per group, N_g = e_g (p0 W + A_g): a share s_g enters as s_g / e_g
           for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k)
-            A[S.grp[k]] += rg * std::exp(a * (S.lut[S.lutidx[k]] - tref));
+            A[S.grp[k]] += rg * std::exp(a * ((R)S.lut[S.lutidx[k]] - tref));
           for (size_t g = 0; g < G; ++g) if (mark[g] != j + 1) A[g] += rg * p0;
         }
         continue;
       }
-      const double Z = zbase + zs;
-      const double H = hbase + hs;
-      const double r = c / Z;
-      if (lse_out) lse_out[j] = M + std::log(Z) + a * tref;
+      const R Z = zbase + zs;
+      const R H = hbase + hs;
+      const R r = c / Z;
+      if (lse_out) lse_out[j] = (double)((R)M + std::log(Z) + a * tref);
       if (c != 0.0) {
         sum_clogZ += (long double)c * std::log(Z);
         sum_rH += (long double)r * H;
@@ -452,53 +487,61 @@ void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double
     Wpart[ch] = W;
   }
   long double sum_clogZ = 0.0L, sum_rH = 0.0L;
-  double W = 0.0;
+  R W = 0.0;
   for (size_t ch = 0; ch < nch; ++ch) { sum_clogZ += clogZ[ch]; sum_rH += rH[ch]; W += Wpart[ch]; }
   long double mu = 0.0L;
   for (size_t g = 0; g < G; ++g) {
-    double A = 0.0;
+    R A = 0.0;
     for (size_t ch = 0; ch < nch; ++ch) A += Apart[ch * G + g];
-    Nc[g] = e[g] * (p0 * W + A);
-    mu += (long double)(M - st.u[g]) * Nc[g];
+    const R nc = e[g] * (p0 * W + A);
+    Nc[g] = (double)nc;
+    mu += (long double)((R)M - (R)st.u[g]) * (long double)nc;
   }
   long double csum = 0.0L;
   for (size_t j = 0; j < E; ++j) csum += cvec[j];
-  *bound_data = sum_clogZ + (long double)(1.0 - a) * sum_rH + mu + (long double)(a * tref) * csum;
+  *bound_data = sum_clogZ + (long double)((R)1.0 - a) * sum_rH + mu + (long double)(a * tref) * csum;
+}
+void csr_pass_B(const CsrL &S, const StructState &st, const double *cvec, double *Nc,
+                long double *bound_data, double *lse_out, bool extended = false) {
+  if (extended) csr_pass_B_t<long double>(S, st, cvec, Nc, bound_data, lse_out);
+  else csr_pass_B_t<double>(S, st, cvec, Nc, bound_data, lse_out);
 }
 
-double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
+template <class R>
+double csr_pass_A_t(const CsrL &S, const StructState &st, const double *w) {
   const size_t G = S.G, E = S.E;
   double M = -std::numeric_limits<double>::infinity();
   for (size_t g = 0; g < G; ++g) M = std::max(M, st.u[g]);
-  const double a = st.a, oma = 1.0 - a;
-  const double tref = tref_of(S, a);
-  const double p0 = std::exp(a * (S.logzi - tref));
-  std::vector<double> e(G);
-  double U = 0.0;
+  const R a = st.a, oma = (R)1.0 - a;
+  const R tref = tref_of(S, st.a);
+  const R logzi = S.logzi;
+  const R p0 = std::exp(a * (logzi - tref));
+  std::vector<R> e(G);
+  R U = 0.0;
   for (size_t g = 0; g < G; ++g) {
-    e[g] = std::exp(st.u[g] - M);
+    e[g] = std::exp((R)st.u[g] - (R)M);
     U += e[g];
   }
   // centre the step values with the lagged constant (see StructState::kappa).  Step values are
   // taken relative to the background cell of the same EC (a per-EC shift by (1-a)*logzi, which
   // the variance ignores): s = D_i + wc_g on a listed cell, s0 = wc_g elsewhere.
-  const double kappa = st.kappa;
-  double V1c = 0.0, V2c = 0.0;
-  std::vector<double> wc(G);
+  const R kappa = st.kappa;
+  R V1c = 0.0, V2c = 0.0;
+  std::vector<R> wc(G);
   for (size_t g = 0; g < G; ++g) {
-    wc[g] = w[g] - kappa;
-    const double s0c = wc[g];
+    wc[g] = (R)w[g] - kappa;
+    const R s0c = wc[g];
     V1c += e[g] * s0c;
     V2c += e[g] * s0c * s0c;
   }
-  st.kappa = kappa + V1c / U;
-  std::vector<double> x(S.n_lut), D(S.n_lut);
+  st.kappa = (double)(kappa + V1c / U);
+  std::vector<R> x(S.n_lut), D(S.n_lut);
   for (size_t i = 0; i < S.n_lut; ++i) {
-    const double T = S.lut[i];
+    const R T = S.lut[i];
     x[i] = std::exp(a * (T - tref));
-    D[i] = oma * (T - S.logzi);
+    D[i] = oma * (T - logzi);
   }
-  const double zbase = p0 * U, b1 = p0 * V1c, b2 = p0 * V2c;
+  const R zbase = p0 * U, b1 = p0 * V1c, b2 = p0 * V2c;
   const size_t nch = n_chunks_of(E);
   std::vector<long double> part(nch, 0.0L);
 #pragma omp parallel for schedule(dynamic, 1)
@@ -508,23 +551,23 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
     long double nn = 0.0L;
     std::vector<uint64_t> mark;
     for (size_t j = j0; j < j1; ++j) {
-      double zs = 0.0, t1 = 0.0, t2 = 0.0;
+      R zs = 0.0, t1 = 0.0, t2 = 0.0;
       for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
         const uint32_t g = S.grp[k], i = S.lutidx[k];
-        const double eg = e[g], wg = wc[g];
-        const double xm = x[i] - p0;
-        const double xD = x[i] * D[i];
-        const double wx = wg * xm;
+        const R eg = e[g], wg = wc[g];
+        const R xm = x[i] - p0;
+        const R xD = x[i] * D[i];
+        const R wx = wg * xm;
         zs += eg * xm;
         t1 += eg * (xD + wx);
-        t2 += eg * (xD * D[i] + wg * (2.0 * xD + wx));
+        t2 += eg * (xD * D[i] + wg * ((R)2.0 * xD + wx));
       }
-      if (!(zbase + zs >= zbase * kGuardRatio)) {  // guarded EC: every group visited (see csr_pass_B)
+      if (!(zbase + zs >= zbase * (R)kGuardRatio)) {  // guarded EC: every group visited (see csr_pass_B)
         if (mark.empty()) mark.assign(G, 0);
-        double z = 0.0, u1 = 0.0, u2 = 0.0;
+        R z = 0.0, u1 = 0.0, u2 = 0.0;
         for (uint64_t k = S.rowptr[j]; k < S.rowptr[j + 1]; ++k) {
           const uint32_t g = S.grp[k], i = S.lutidx[k];
-          const double q = e[g] * x[i], sv = D[i] + wc[g];
+          const R q = e[g] * x[i], sv = D[i] + wc[g];
           mark[g] = j + 1;
           z += q;
           u1 += q * sv;
@@ -532,18 +575,18 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
         }
         for (size_t g = 0; g < G; ++g)
           if (mark[g] != j + 1) {
-            const double q = e[g] * p0;
+            const R q = e[g] * p0;
             z += q;
             u1 += q * wc[g];
             u2 += q * wc[g] * wc[g];
           }
-        const double S1 = u1 / z, S2 = u2 / z;
+        const R S1 = u1 / z, S2 = u2 / z;
         nn += (long double)(S2 - S1 * S1);
         continue;
       }
-      const double iZ = 1.0 / (zbase + zs);
-      const double S1 = (b1 + t1) * iZ;
-      const double S2 = (b2 + t2) * iZ;
+      const R iZ = (R)1.0 / (zbase + zs);
+      const R S1 = (b1 + t1) * iZ;
+      const R S2 = (b2 + t2) * iZ;
       nn += (long double)(S2 - S1 * S1);
     }
     part[ch] = nn;
@@ -551,6 +594,9 @@ double csr_pass_A(const CsrL &S, const StructState &st, const double *w) {
   long double newnorm = 0.0L;
   for (size_t ch = 0; ch < nch; ++ch) newnorm += part[ch];
   return (double)newnorm;
+}
+double csr_pass_A(const CsrL &S, const StructState &st, const double *w, bool extended = false) {
+  return extended ? csr_pass_A_t<long double>(S, st, w) : csr_pass_A_t<double>(S, st, w);
 }
 
 // dense-L structured passes (rows = groups, G x E)
@@ -712,9 +758,10 @@ size_t orc_rcg_optl_csr(const uint64_t *rowptr, const uint32_t *grp, const uint3
   if (opts_in) opts = *opts_in; else orc_default_opts(&opts);
   CsrL S{rowptr, grp, lutidx, lut, n_lut, logzi, G, E};
   StructState st;
-  auto pA = [&](const StructState &s, const double *w) { return csr_pass_A(S, s, w); };
+  const bool ext = opts.extended != 0;
+  auto pA = [&](const StructState &s, const double *w) { return csr_pass_A(S, s, w, ext); };
   auto pB = [&](const StructState &s, const double *c, double *Nc, long double *bd) {
-    csr_pass_B(S, s, c, Nc, bd, nullptr);
+    csr_pass_B(S, s, c, Nc, bd, nullptr, ext);
   };
   size_t it = structured_loop(G, E, logc, alpha0, tol, max_iters, opts, pA, pB, st, theta_out,
                               bound_out, trace);
@@ -722,7 +769,7 @@ size_t orc_rcg_optl_csr(const uint64_t *rowptr, const uint32_t *grp, const uint3
     std::vector<double> lse(E), cvec(E), Nc(G);
     for (size_t j = 0; j < E; ++j) cvec[j] = std::exp(logc[j]);
     long double bd;
-    csr_pass_B(S, st, cvec.data(), Nc.data(), &bd, lse.data());
+    csr_pass_B(S, st, cvec.data(), Nc.data(), &bd, lse.data(), ext);
     for (size_t g = 0; g < G; ++g)
       for (size_t j = 0; j < E; ++j) gamma_out[g * E + j] = st.a * logzi + st.u[g] - lse[j];
     for (size_t j = 0; j < E; ++j)
@@ -816,6 +863,63 @@ size_t orc_em_dense_opts(const double *L, size_t G, size_t E, const double *logc
       for (size_t g = 0; g < G; ++g) gamma_out[g * E + j] = std::log(theta[g]) + L[g * E + j] - lse;
     }
   }
+  return k;
+}
+
+// rcgpar::em_torch with precision "float" restated [UPSTREAM-UNVERIFIED] (src/mSWEEP.cpp:129,200-203: the tensors of the
+// LibTorch implementation are then float32).  The reading the HIP path mirrors (msweep_amd/csrc/em_f32_kernels.hpp):
+//   * likelihood values, weights theta, log theta, the responsibilities' numerators, the per-EC sums Z_j and the
+//     quotients c_j / Z_j are floats (every operation below rounds to float where a float tensor would);
+//   * c_j * (m_j + log Z_j) is formed in float per EC and accumulated over the ECs in double (a blocked float
+//     reduction of 10^7 terms carries about that much; the stop rule is decided by the next point in any case);
+//   * the log-likelihood is ROUNDED TO FLOAT once per iteration and the stop rule compares two floats: near 1e8 a
+//     float moves in steps of 8, so a float run stops as soon as an iteration gains less than a few units -- after a
+//     few hundred iterations where the double run reaches --max-iters (docs/gpubenchmarks.md:20-22: 335 against the
+//     5000 cap).  Same MAP / ML and stop-rule variants as orc_em_dense_opts.
+//   * the per-group sums of r_j p_gj are accumulated in double from float products (the HIP path's are exact integers).
+size_t orc_em_dense_f32(const double *L, size_t G, size_t E, const double *logc,
+                        const double *alpha0, double tol, size_t max_iters, const orc_em_opts *opts_in,
+                        double *theta_out, double *bound_out, double *theta_trace, size_t n_trace) {
+  orc_em_opts eo = {0, 0, 1};
+  if (opts_in) eo = *opts_in;
+  const bool ml = eo.prior_mode == 1;
+  std::vector<float> theta(G, 1.0f / (float)G), logth(G), c(E), y(G);
+  std::vector<double> acc(G);
+  double csum = 0.0, asum = 0.0;
+  for (size_t j = 0; j < E; ++j) { c[j] = (float)std::exp(logc[j]); csum += (double)c[j]; }
+  if (!ml) for (size_t g = 0; g < G; ++g) asum += alpha0[g] - 1.0;
+  float ll = -std::numeric_limits<float>::infinity();
+  size_t k = 0;
+  for (; k < max_iters; ++k) {
+    for (size_t g = 0; g < G; ++g) { logth[g] = std::log(theta[g]); acc[g] = 0.0; }
+    double newll = 0.0;
+    for (size_t j = 0; j < E; ++j) {
+      float m = -std::numeric_limits<float>::infinity();
+      for (size_t g = 0; g < G; ++g) { y[g] = logth[g] + (float)L[g * E + j]; m = std::max(m, y[g]); }
+      float Z = 0.0f;
+      for (size_t g = 0; g < G; ++g) { y[g] = std::exp(y[g] - m); Z += y[g]; }
+      if (c[j] != 0.0f) newll += (double)(c[j] * (m + std::log(Z)));
+      const float r = c[j] / Z;
+      for (size_t g = 0; g < G; ++g) acc[g] += (double)(r * y[g]);
+    }
+    double dmax = 0.0;
+    for (size_t g = 0; g < G; ++g) {
+      double t = ml ? acc[g] / csum : (acc[g] + alpha0[g] - 1.0) / (csum + asum);
+      t = t > 0.0 ? t : 0.0;
+      const float tf = (float)t;
+      dmax = std::max(dmax, (double)std::fabs(tf - theta[g]));
+      theta[g] = tf;
+      if (theta_trace && k < n_trace) theta_trace[k * G + g] = (double)tf;
+    }
+    const float newllf = (float)newll;
+    const double gain = (double)newllf - (double)ll;
+    ll = newllf;
+    const bool grid = eo.check_every <= 1 || (k + 1) % (size_t)eo.check_every == 0;
+    const bool small = eo.stop_rule == 1 ? dmax < tol : gain < tol;
+    if (k > 0 && small && grid) { ++k; break; }
+  }
+  if (theta_out) for (size_t g = 0; g < G; ++g) theta_out[g] = (double)theta[g];
+  if (bound_out) *bound_out = (double)ll;
   return k;
 }
 

@@ -151,6 +151,12 @@ int main(int argc, char **argv) {
           if (L(g, j) > -4.0) L(g, j) -= 0.25;
       print("theta_changed", estimate(logc, nullptr));
       std::printf("uploads_after_change %zu\n", rcgpar::likelihood_cache_stats().first);
+      // ONE cell edited in place (a position no sample of 65 536 cells is likely to hold): the full hash sees it
+      L(G / 2, (E * 2) / 3 + 1) -= 1e-3;
+      estimate(logc, nullptr);
+      std::printf("uploads_after_one_cell %zu\n", rcgpar::likelihood_cache_stats().first);
+      estimate(logc, nullptr);  // and nothing changed since: served from the resident likelihood again
+      std::printf("uploads_after_no_change %zu\n", rcgpar::likelihood_cache_stats().first);
       rcgpar::forget_likelihood();
     }
   } catch (std::exception &e) {

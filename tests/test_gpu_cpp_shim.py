@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, load_golden
+from msweep_amd.core import MswError
 from test_gpu_rcg import assert_theta
 
 pytestmark = pytest.mark.gpu
@@ -134,6 +135,9 @@ def test_reference_calls_keep_the_likelihood_resident_over_the_bootstrap_loop(re
     print({k: v for k, v in out.items() if not k.startswith("theta")})
     assert int(out["uploads"]) == 1 and int(out["hits"]) == B
     assert int(out["uploads_after_change"]) == 2
+    # a single cell edited in place IS caught (the key hashes every cell up to 2^27 cells), and an unchanged matrix
+    # is not uploaded again
+    assert int(out["uploads_after_one_cell"]) == 3 and int(out["uploads_after_no_change"]) == 3
     first, later, solve = float(out["first_ms"]), float(out["later_ms"]), float(out["later_solve_ms"])
     assert later < 0.6 * first, (first, later)          # the host copy + upload + device compression are paid once
     # the answers: the estimate, replicate 1 (log counts rotated by one) and the rewritten matrix, against the Python
@@ -171,5 +175,24 @@ def test_python_mirror_keeps_the_dense_likelihood_resident(gpu_core):
     assert rcgpar.likelihood_cache_stats()[0] == u0 + 2 and d.core is not first_core
     assert first_core._h is None             # the handle it replaced was closed, not leaked
     assert np.max(np.abs(d.theta - a.theta)) > 1e-6
+    # ONE cell edited in place: caught (the key is an xxh3 over every cell up to 2^27 cells)
+    L[17, L.shape[1] // 3 + 5] -= 1e-3
+    e = rcgpar.rcg_optl("rcgcpu", L, logc, alpha0)
+    assert rcgpar.likelihood_cache_stats()[0] == u0 + 3 and e.core is not d.core
+    # gamma() belongs to the call that returned it: after ANOTHER solve on the shared handle it raises instead of
+    # handing out the later call's matrix ...
+    f = rcgpar.rcg_optl("rcgcpu", L, np.roll(logc, -1), alpha0)
+    assert f.core is e.core
+    g_f = f.gamma()
+    assert g_f.shape == L.shape
+    with pytest.raises(MswError, match="solved again"):
+        e.gamma()
+    # ... unless the caller asked for it to be kept
+    k1 = rcgpar.rcg_optl("rcgcpu", L, logc, alpha0, keep_gamma=True)
+    k2 = rcgpar.rcg_optl("rcgcpu", L, np.roll(logc, -1), alpha0, keep_gamma=True)
+    np.testing.assert_array_equal(k2.gamma(), g_f)
+    assert np.max(np.abs(k1.gamma() - k2.gamma())) > 1e-9
     rcgpar.forget_likelihood()
     assert d.core._h is None
+    with pytest.raises(MswError, match="closed"):
+        f.gamma()

@@ -331,6 +331,71 @@ def test_record_formats_agree_with_oracle(gpu_core, oracle, monkeypatch, nbytes)
     np.testing.assert_array_equal(L[:, :200], dense_from_csr(p, lut)[:, :200])
 
 
+@pytest.mark.parametrize("shape", ["all_short", "few_long", "forced_on_long", "forced_off"])
+def test_passB_short_slice_instantiation(oracle, monkeypatch, shape):
+    """Pass B's short-slice instantiation (8 records per lane in registers, 16 wavefronts per workgroup; sweep_kernels.hpp
+    RC = 8) is picked when slices of more than 8 rows hold at most a twentieth of the rows.  all_short: ECs of 1..8
+    cells; few_long: a handful of ECs of 9..16 cells among them (their slices go through the 8-row kernel's streaming
+    branch in two chunks, odd lengths included); forced_on_long: MSWEEP_PASSB_RC=8 on ECs of up to 16 cells (half the
+    slices stream); forced_off: MSWEEP_PASSB_RC=16 on the short input.  Every one in lock-step with the oracle; the other
+    instantiation on the same layout agrees to rounding (the column sums are integers and the row sums are formed in the
+    same order, but W = sum r_j meets over 16 instead of 12 wavefronts); zero counts, the escape byte and an EM run
+    included."""
+    if shape == "forced_on_long":
+        monkeypatch.setenv("MSWEEP_PASSB_RC", "8")
+    elif shape == "forced_off":
+        monkeypatch.setenv("MSWEEP_PASSB_RC", "16")
+    else:
+        monkeypatch.delenv("MSWEEP_PASSB_RC", raising=False)
+    rng = np.random.default_rng(41)
+    G, E = 900, 30000
+    sizes = (1 + rng.poisson(6, G)).astype(np.uint64)
+    lens = rng.integers(1, 9, E)
+    if shape == "few_long":
+        lens[rng.choice(E, 200, replace=False)] = rng.integers(9, 17, 200)
+    elif shape == "forced_on_long":
+        lens = rng.integers(1, 17, E)
+    rowptr, grp, cnt, lut = _ragged_problem(rng, E, G, sizes, lens)
+    c = rng.integers(1, 20, E).astype(float)
+    c[rng.random(E) < 0.2] = 0.0           # a bootstrap replicate's zeros
+    c[rng.random(E) < 0.02] = 300.5        # the escape byte
+    with np.errstate(divide="ignore"):
+        logc = np.log(c)
+    alpha0 = rng.uniform(0.5, 2.0, G)
+    lutidx = (grp * lut.shape[1] + cnt).astype(np.uint32)
+    with Core(0) as core:
+        core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
+        li = core.layout_info()
+        want = {"all_short": 8, "few_long": 8, "forced_on_long": 8, "forced_off": 16}[shape]
+        assert li["passB_reg_cells"] == want, li
+        assert (li["rows_over_8"] == 0) == (shape in ("all_short", "forced_off")), li
+        if shape == "few_long":
+            assert 0 < 20 * li["rows_over_8"] <= li["rows"]
+        core.set_trace_theta(15)
+        res = core.solve(logc, alpha0)
+        tr = core.trace(15, with_theta=True)
+        em = core.solve(logc, np.maximum(alpha0, 1.0), tol=-1.0, max_iters=25, algo=1)
+        h8 = core.layout_hash()
+    ref = oracle.rcg_optl_csr(rowptr, grp, lutidx, lut, np.log(0.01), G, logc, alpha0, trace=15)
+    lockstep(tr, ref["trace"], 15)
+    assert res["iters"] == ref["iters"]
+    assert_theta(res["theta"], ref["theta"])
+    # the other instantiation on the same layout
+    monkeypatch.setenv("MSWEEP_PASSB_RC", "16" if want == 8 else "8")
+    with Core(0) as core:
+        core.set_csr(rowptr, grp, cnt, lut, np.log(0.01), G)
+        assert core.layout_info()["passB_reg_cells"] == (16 if want == 8 else 8) and core.layout_hash() == h8
+        core.set_trace_theta(15)
+        res2 = core.solve(logc, alpha0)
+        tr2 = core.trace(15, with_theta=True)
+        em2 = core.solve(logc, np.maximum(alpha0, 1.0), tol=-1.0, max_iters=25, algo=1)
+    lockstep(tr2, ref["trace"], 15)
+    np.testing.assert_allclose(tr2["theta"][:15], tr["theta"][:15], rtol=1e-11, atol=1e-18)
+    assert abs(res2["iters"] - res["iters"]) <= 1
+    assert_theta(res2["theta"], res["theta"])
+    np.testing.assert_allclose(em2["theta"], em["theta"], rtol=1e-11, atol=1e-18)
+
+
 def test_fractional_and_large_multiplicities(gpu_core, oracle):
     """Pass B streams the EC multiplicities as bytes and escapes to the fp64 vector for anything
     that is not a small integer: fractional weights, counts >= 255, zeros (bootstrap) in one input."""

@@ -157,3 +157,51 @@ def test_em_variant_knobs(oracle):
     np.testing.assert_allclose(t["theta"], m1["theta"], atol=1e-6)
     g5 = oracle.em_dense(L, logc, one, tol=1e-9, check_every=5)
     assert g5["iters"] % 5 == 0 and m1["iters"] <= g5["iters"] < m1["iters"] + 5
+
+
+@pytest.mark.parametrize("name,max_apart", [("seed1_case517", 5e-8), ("seed7_case292", 1e-9), ("seed99_case247", 1e-9)])
+def test_extended_oracles_agree_where_the_fp64_ones_drift(oracle, name, max_apart):
+    """orc_rcg_opts::extended (round 5): on the inputs of tools/fuzz_parity.py that amplify rounding (a Fletcher-Reeves
+    factor ~ 100; tests/golden/fuzz/) the structured and the dense-state restatement carried in x87 extended precision
+    agree with each other to 1e-10 .. 3e-8 over twelve iterations, while the fp64 structured oracle is 2e-7 .. 4e-5 away
+    from both: the extended pair is the judge of the HIP path there (tests/test_gpu_fuzz.py)."""
+    import os
+    from conftest import ROOT
+    d = np.load(os.path.join(ROOT, "tests", "golden", "fuzz", name + ".npz"))
+    G, E, n = len(d["alpha0"]), len(d["rowptr"]) - 1, 12
+    lutidx = (d["grp"] * d["lut"].shape[1] + d["cnt"]).astype(np.uint32)
+    L = np.full((G, E), np.log(0.01))
+    L[d["grp"], np.repeat(np.arange(E), np.diff(d["rowptr"].astype(np.int64)))] = d["lut"][d["grp"], d["cnt"]]
+    run_s = lambda ext: oracle.rcg_optl_csr(d["rowptr"], d["grp"], lutidx, d["lut"], np.log(0.01), G, d["logc"], d["alpha0"],  # noqa: E731
+                                            tol=-1.0, max_iters=n, trace=n, extended=ext)["trace"]
+    s64, s80 = run_s(False), run_s(True)
+    d80 = oracle.rcg_optl_dense(L, d["logc"], d["alpha0"], tol=-1.0, max_iters=n, trace=n, extended=True)["trace"]
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300) * (np.abs(b) >= 1e-12)))  # noqa: E731
+    assert s80["didreset"].tolist() == d80["didreset"].tolist() == s64["didreset"].tolist()
+    apart, drift = rel(s80["theta"], d80["theta"]), rel(s64["theta"], s80["theta"])
+    assert apart < max_apart, apart
+    assert drift > 4 * apart and drift > 1e-7, (drift, apart)      # (what the fp64 oracle cost the sweep as a judge)
+
+
+def test_extended_option_changes_nothing_on_a_tame_problem(oracle):
+    """Same trajectory over the first ten iterations to 1e-9 where rounding is not amplified (the recursion still
+    multiplies differences ~10 x per 10-20 iterations, SURVEY.md 7.3b: 1e-6 over thirty); identical accept / reject
+    decisions and stop."""
+    p = synth.make_csr_problem(20000, 150, seed=3, max_other=8)
+    lut = precalc_lls(p["group_sizes"])
+    logc = np.log(p["ec_counts"].astype(float))
+    a0 = np.ones(150)
+    r = [oracle.rcg_optl_csr(p["rowptr"], p["grp"], lutidx_of(p, lut), lut, np.log(0.01), 150, logc, a0, trace=30,
+                             extended=e) for e in (False, True)]
+    assert r[0]["iters"] == r[1]["iters"]
+    assert r[0]["trace"]["didreset"].tolist() == r[1]["trace"]["didreset"].tolist()
+    L = dense_from_csr(p, lut)
+    dd = [oracle.rcg_optl_dense(L, logc, a0, trace=30, extended=e) for e in (False, True)]
+    for a, b in ((r[0], r[1]), (dd[0], dd[1]), (dd[1], r[1])):
+        np.testing.assert_allclose(a["trace"]["theta"][:10], b["trace"]["theta"][:10], rtol=1e-9, atol=1e-16)
+        np.testing.assert_allclose(a["trace"]["theta"][:30], b["trace"]["theta"][:30], rtol=1e-6, atol=1e-12)
+    # the two extended formulations stay closer to each other than either fp64 one stays to its extended twin
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12)))  # noqa: E731
+    th = lambda x: x["trace"]["theta"][:30]  # noqa: E731
+    assert rel(th(dd[1]), th(r[1])) <= max(rel(th(dd[0]), th(dd[1])), rel(th(r[0]), th(r[1])))
+    np.testing.assert_allclose(dd[0]["gamma"], dd[1]["gamma"], rtol=0, atol=1e-5)

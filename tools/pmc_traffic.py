@@ -13,7 +13,7 @@ def main(d, out):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name") or row.get("Kernel Name")
-            if not k or ("k_pass" not in k and "k_redfin" not in k):
+            if not k or ("pass" not in k and "k_redfin" not in k and "k_finstep" not in k and "k_em_fin" not in k):
                 continue
             k = k.split("(")[0]
             vals[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
