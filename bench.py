@@ -956,7 +956,7 @@ def main():
         # library's communicator on the device (a one-word all-reduce, synchronised before it returns): every
         # rank's GPU is idle when the last rank arrives.  With one rank there is nothing to wait for.
         if multi:
-            comm.allreduce([], [0.0])
+            comm.allreduce([0], [0.0])      # (one integer + one double: the shape the sharded solve's all-reduce has)
 
     def max_over_ranks(x):
         return float(comm.allgather(np.array([x])).max()) if multi else x
