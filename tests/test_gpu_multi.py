@@ -107,3 +107,26 @@ def test_bench_with_two_ranks_on_one_gpu(mode, transport):
         assert d["shard_split_ms_per_step"]["allreduce"] == "peer" and d["shard_split_ms_per_step"]["collectives_per_step"] >= 2
     else:
         assert d["bootstrap_cfg4"]["replicates"] == 2 * d["bootstrap_cfg4"]["per_rank"]
+
+
+def test_bench_under_torchrun_with_two_ranks_on_one_gpu():
+    """The way the driver launches N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- rehearsed with two ranks on ONE GPU (MSWEEP_BENCH_ONE_GPU=1: a
+    functional check, not a measurement).  The rank processes read RANK / WORLD_SIZE / MASTER_PORT from the environment,
+    meet through their own unix socket (named after their common parent, the launcher's agent) and never import torch
+    (bench.py asserts so at the end of every rank): round 4's two-ROCm-runtimes hazard is out of the path."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MSWEEP_BENCH_ONE_GPU="1", GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--no-cpu-baseline", "--reads", "300000", "--groups", "300"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and "rehearsal" in d["rccl_ranks"]
+    assert len(d["ms_per_step_runs"]) == 5 and d["bootstrap_cfg4"]["replicates"] == 2 * d["bootstrap_cfg4"]["per_rank"]
