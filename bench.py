@@ -1156,8 +1156,14 @@ def main():
         # what bounds the dominant kernel: the record stream is NOT it where the counters say that LDS (gathers, integer
         # atomics, half of the cycles bank conflicts) and VALU issue are both busy and overlap only in part
         bound = "hbm"
-        if busy is not None and max(busy["lds_busy_frac"], busy["valu_busy_frac"]) >= 0.4:
-            bound = "lds+valu (hbm frac reported)"
+        if busy is not None:
+            lb, vb = busy["lds_busy_frac"], busy["valu_busy_frac"]
+            if vb >= 0.75 and lb < 0.3:
+                bound = "valu (hbm frac reported)"          # the dense sweeps: one fp64 exp per cell
+            elif lb >= 0.75 and vb < 0.3:
+                bound = "lds (hbm frac reported)"
+            elif max(lb, vb) >= 0.4:
+                bound = "lds+valu (hbm frac reported)"
         gb = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         sharding = "single solve" if n_gpus == 1 else (
             f"one solve, ECs sharded over {n_gpus} GPUs, {os.environ.get('MSWEEP_ALLREDUCE', 'rccl')} all-reduce of 1 double and "

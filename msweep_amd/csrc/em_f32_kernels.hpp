@@ -109,6 +109,18 @@ __global__ __launch_bounds__(1024) void k_em_passB_f32(const Scalars *sc, SellDe
   double *sh = reinterpret_cast<double *>(smem + scratch_off);
   SliceStream<ENC, MSW_REVERSE_B> stream(S, uniform(blockIdx.x * (NT / 64) + (tid >> 6)), gridDim.x * (NT / 64),
                                          (uint32_t)lane, scratch_off + 64 * 8 + uniform(tid >> 6) * kGeoStride);
+  // (the first slice's records in flight under the LDS fill: SliceStream::prime)
+  const uint32_t n_lanes = S.nslices * 64u;
+  const uint32_t null_rec = R::make(G + (uint32_t)lane, 0u, D);  // the lane's own sentinel group: e = 0
+  stream.nullr = null_rec;
+  stream.nullr_hot = null_rec;
+  auto issue = [&](SliceBuf<ENC> &sb) {
+    const uint32_t q = sb.sl * 64 + lane;
+    const uint32_t cj = S.c8s[q < n_lanes ? q : 0u];
+    sb.c8 = q < n_lanes ? cj : 0u;
+  };
+  SliceBuf<ENC> first = {};
+  stream.prime(first, issue);
   {
     float *t = reinterpret_cast<float *>(smem);
     for (uint32_t i = tid; i < n_tab; i += NT) t[i] = tab32_g[i];
@@ -155,15 +167,6 @@ __global__ __launch_bounds__(1024) void k_em_passB_f32(const Scalars *sc, SellDe
   if (tid == 0) *(lds_u32_t *)(size_t)gcnt_off = 0u;
   __syncthreads();
 
-  const uint32_t n_lanes = S.nslices * 64u;
-  const uint32_t null_rec = R::make(G + (uint32_t)lane, 0u, D);  // the lane's own sentinel group: e = 0
-  stream.nullr = null_rec;
-  stream.nullr_hot = null_rec;
-  auto issue = [&](SliceBuf<ENC> &sb) {
-    const uint32_t q = sb.sl * 64 + lane;
-    const uint32_t cj = S.c8s[q < n_lanes ? q : 0u];
-    sb.c8 = q < n_lanes ? cj : 0u;
-  };
   // Z, r, the EC's log-likelihood term and W for one EC whose row sum is zs; returns r (0: nothing to scatter)
   auto epilogue = [&](float zs, float c, bool spoke, uint32_t pos) -> float {
     const float Z = zbase + zs;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(1024) void k_em_passB_f32(const Scalars *sc, SellDe
         }
     }
   };
-  stream.run(issue, process, [] {});
+  stream.run(issue, process, [] {}, &first);
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step
   for (uint32_t r = stream.s_first; r < S.n_long; r += stream.nw) {
     const uint32_t k0 = S.long_ptr[r], k1 = S.long_ptr[r + 1];

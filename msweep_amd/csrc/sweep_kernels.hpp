@@ -268,17 +268,28 @@ struct SliceStream {
     }
     issue(b);
   }
+  // The wavefront's FIRST slice requested at the head of the kernel, before the workgroup fills its LDS image and
+  // meets at the barrier behind it (round 5): the geometry a wavefront parks in LDS is its own (no barrier between
+  // its write and its read), so the first records' trip to HBM runs under the fill instead of after it -- every
+  // sweep used to open with that round trip exposed.  `first` is handed to run().
+  template <class Issue>
+  __device__ __forceinline__ void prime(SliceBuf<ENC, RC> &first, Issue &issue) {
+    commit_offs();
+    fetch(0, 0, first, issue);
+  }
   // issue(buf): further loads of a slice; process(buf): its arithmetic; chunk_end(): every 64 slices
-  // (the geometry is renewed there, with the stream drained)
+  // (the geometry is renewed there, with the stream drained); primed: the buffer prime() filled, or null
   template <class Issue, class Process, class ChunkEnd>
-  __device__ __forceinline__ void run(Issue issue, Process process, ChunkEnd chunk_end) {
+  __device__ __forceinline__ void run(Issue issue, Process process, ChunkEnd chunk_end,
+                                      const SliceBuf<ENC, RC> *primed = nullptr) {
+    SliceBuf<ENC, RC> A = {}, B = {};
+    if (primed) A = *primed;  // (copied once, here: the caller's buffer is dead from now on)
     for (uint32_t base = 0; base == 0 || base < n_mine; base += 64) {
       if (base) gather_offs(base >> 6);
-      commit_offs();
+      if (base || !primed) commit_offs();
       const uint32_t n_chunk = n_mine > base ? (n_mine - base < 64u ? n_mine - base : 64u) : 0u;
-      SliceBuf<ENC, RC> A = {}, B = {};
       uint32_t j = 0;
-      fetch(base, 0, A, issue);
+      if (base || !primed) fetch(base, 0, A, issue);
       for (;;) {
         if (j >= n_chunk) break;
         wait_vm0();  // A has landed
@@ -372,6 +383,18 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   // summing for themselves cost pass A 2.5 us: 33 MB of L2 reads at the head of the sweep.  Until round 4 k_fin
   // summed them into the scalar state and pass A had to wait for its verdict: k_finstep.)
   // (eight pairs per lane in flight at a time -- 512 workgroups of k_redfin, 8192 groups -- not one round trip each)
+  // (lanes past the end of a long EC, and the missing last row of an odd slice, take a record of the lane's own
+  // sentinel group)
+  [[maybe_unused]] const double vlogzi0 = uniform_d(sc->logzi);
+  const RT null_rec = null_record<ENC>(S.n_groups + (uint32_t)lane, D, vlogzi0);
+  stream.nullr = null_rec;
+  if constexpr (HYB) stream.nullr_hot = R::make_h(S.n_groups + (uint32_t)lane, 0u, D);
+  else stream.nullr_hot = null_rec;
+  auto issue = [&](SliceBuf<ENC> &) {};
+  SliceBuf<ENC> first = {};
+#ifndef MSW_NO_PRIME
+  stream.prime(first, issue);  // the first slice's records are in flight under the LDS fill
+#endif
   double m1 = 0.0, m2 = 0.0;
   for (int b0 = 0; tid < 64 && b0 < npartR; b0 += 512) {
     double t1[8], t2[8];
@@ -431,13 +454,6 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 0, 1);
   const double b1 = p0 * uniform_d(sh[18]), b2 = p0 * uniform_d(sh[19]);
 
-  // (lanes past the end of a long EC, and the missing last row of an odd slice, take a record of the lane's own
-  // sentinel group)
-  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
-  stream.nullr = null_rec;
-  if constexpr (HYB) stream.nullr_hot = R::make_h(G + (uint32_t)lane, 0u, D);
-  else stream.nullr_hot = null_rec;
-  auto issue = [&](SliceBuf<ENC> &) {};
   auto process = [&](SliceBuf<ENC> &sb) {
     const uint32_t len = sb.len;
     AccA c = {0.0, 0.0, 0.0};
@@ -554,7 +570,11 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
       }
     }
   };
+#ifndef MSW_NO_PRIME
+  stream.run(issue, process, [] {}, &first);
+#else
   stream.run(issue, process, [] {});
+#endif
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step -- the groups of one EC are
   // distinct, so the gathers of a step never meet on an address, and the three sums are wave
   // reductions (no barrier)
@@ -713,6 +733,24 @@ __global__ __launch_bounds__((pass_threads_B<ENC, RC>())) void k_passB(const Sca
   SliceStream<ENC, MSW_REVERSE_B, RC> stream(S, uniform(blockIdx.x * (NT / 64) + (tid >> 6)),
                               gridDim.x * (NT / 64), (uint32_t)lane,
                               scratch_off + 256u + uniform(tid >> 6) * kGeoStride);
+  // the lane's null record and the multiplicity bytes of a slice (issue): needed by the first fetch, which is
+  // requested here, before the LDS fill (SliceStream::prime)
+  [[maybe_unused]] const double vlogzi0 = uniform_d(sc->logzi);
+  const uint32_t n_lanes = S.nslices * 64u;
+  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi0);
+  stream.nullr = null_rec;
+  if constexpr (HYB) stream.nullr_hot = R::make_h(G + (uint32_t)lane, 0u, D);
+  else stream.nullr_hot = null_rec;
+  auto issue = [&](SliceBuf<ENC, RC> &sb) {
+    // (a byte per slice lane: the lanes of an EC that takes several hold the same one; lanes without an EC 0)
+    const uint32_t q = sb.sl * 64 + lane;
+    const uint32_t cj = S.c8s[q < n_lanes ? q : 0u];
+    sb.c8 = q < n_lanes ? cj : 0u;
+  };
+  SliceBuf<ENC, RC> first = {};
+#ifndef MSW_NO_PRIME
+  stream.prime(first, issue);
+#endif
   if (TL) {
     double2 *t = reinterpret_cast<double2 *>(smem);
     for (uint32_t i = tid; i < n_tab; i += NT) t[i] = tabB_g[i];
@@ -817,17 +855,6 @@ __global__ __launch_bounds__((pass_threads_B<ENC, RC>())) void k_passB(const Sca
   __syncthreads();
   if (tid == 0 && blockIdx.x == 0) MSW_STAMP(sc->iter, 2, 1);
 
-  const uint32_t n_lanes = S.nslices * 64u;
-  const RT null_rec = null_record<ENC>(G + (uint32_t)lane, D, vlogzi);
-  stream.nullr = null_rec;
-  if constexpr (HYB) stream.nullr_hot = R::make_h(G + (uint32_t)lane, 0u, D);
-  else stream.nullr_hot = null_rec;
-  auto issue = [&](SliceBuf<ENC, RC> &sb) {
-    // (a byte per slice lane: the lanes of an EC that takes several hold the same one; lanes without an EC 0)
-    const uint32_t q = sb.sl * 64 + lane;
-    const uint32_t cj = S.c8s[q < n_lanes ? q : 0u];
-    sb.c8 = q < n_lanes ? cj : 0u;
-  };
   auto process = [&](SliceBuf<ENC, RC> &sb) {
     const uint32_t o = sb.o, len = sb.len;
     double c = (double)sb.c8;
@@ -1096,7 +1123,11 @@ __global__ __launch_bounds__((pass_threads_B<ENC, RC>())) void k_passB(const Sca
       }
     }
   };
+#ifndef MSW_NO_PRIME
+  stream.run(issue, process, flush_logs, &first);
+#else
   stream.run(issue, process, flush_logs);
+#endif
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step (see pass A)
   // The current EC's first kLongStep * 64 records stay in registers for the scatter (one reload less: 10 % on
   // ECs of 300..1000 cells), and the next EC's first ones are fetched before the current one is
