@@ -10,5 +10,11 @@ else
   for s in 31337 1234; do run tools/fuzz_parity.py 300 $s; done
   run tools/fuzz_build.py 300 5
   run tools/fuzz_bootstrap.py 100 5
+  # the sweeps with the residual correction of the c / z division (1 ulp instead of 2; tools/ab_build.py divcorrect
+  # "-DMSW_DIV_CORRECT=1"): kept alive by one short sweep per round (advisor, round 4)
+  if [ -f build_ab/lib_divcorrect.so ]; then
+    echo "== MSWEEP_CORE_LIB=build_ab/lib_divcorrect.so (-DMSW_DIV_CORRECT=1)" >> $out
+    MSWEEP_CORE_LIB=build_ab/lib_divcorrect.so run tools/fuzz_parity.py 150 11
+  fi
 fi
 cat $out
