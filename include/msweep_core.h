@@ -299,6 +299,11 @@ int msw_alignment_read(const char *const *paths, size_t n_paths, size_t n_target
 int msw_alignment_shape(msw_alignment_t a, size_t *n_ecs, size_t *n_reads, size_t *n_hits, size_t *n_aligned);
 int msw_alignment_export(msw_alignment_t a, uint64_t *ec_tptr, uint32_t *ec_targets, uint64_t *ec_counts,
                          uint64_t *ec_rptr, uint32_t *ec_reads);
+/* The same five arrays WITHOUT a copy: pointers into the handle's own storage, valid until msw_alignment_destroy (round 5:
+ * the export of cfg3's alignment -- 0.9 GB into freshly mapped memory, on one thread -- was a fifth of the whole
+ * text-to-abundances time).  Any output pointer may be NULL.  msw_alignment_export copies on the reader's threads. */
+int msw_alignment_view(msw_alignment_t a, const uint64_t **ec_tptr, const uint32_t **ec_targets, const uint64_t **ec_counts,
+                       const uint64_t **ec_rptr, const uint32_t **ec_reads);
 void msw_alignment_destroy(msw_alignment_t a);
 /* error text of the last failed msw_alignment_read of this thread (the reference's messages) */
 const char *msw_alignment_last_error(void);

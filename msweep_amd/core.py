@@ -24,7 +24,7 @@ EXPORTS = [
     "msw_core_create", "msw_core_destroy", "msw_last_error", "msw_core_version",
     "msw_core_set_dense_logl", "msw_core_set_csr", "msw_core_build_likelihood",
     "msw_core_get_dense_logl", "msw_core_layout_hash", "msw_core_shape", "msw_alignment_read",
-    "msw_alignment_shape", "msw_alignment_export", "msw_alignment_destroy", "msw_alignment_last_error", "msw_core_solve", "msw_core_prepare", "msw_core_run",
+    "msw_alignment_shape", "msw_alignment_export", "msw_alignment_view", "msw_alignment_destroy", "msw_alignment_last_error", "msw_core_solve", "msw_core_prepare", "msw_core_run",
     "msw_core_gamma",
     "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
@@ -151,6 +151,7 @@ def load_library():
     L.msw_comm_last_error.restype = C.c_char_p
     L.msw_alignment_read.argtypes = [C.POINTER(C.c_char_p), sz, sz, C.c_int, C.POINTER(vp)]
     L.msw_alignment_shape.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    L.msw_alignment_view.argtypes = [vp] + [C.POINTER(vp)] * 5
     L.msw_alignment_export.argtypes = [vp, vp, vp, vp, vp, vp]
     L.msw_alignment_destroy.argtypes = [vp]
     L.msw_alignment_destroy.restype = None
@@ -159,10 +160,27 @@ def load_library():
     return L
 
 
-def read_alignment(paths, n_targets, merge_mode="intersection"):
+class _AlignmentOwner:
+    """Keeps a native alignment handle alive for as long as an array that views its storage is."""
+
+    def __init__(self, L, h):
+        self._L, self._h = L, h
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.msw_alignment_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def read_alignment(paths, n_targets, merge_mode="intersection", copy=False):
     """Native Themisto plaintext reader + EC collapse (msw_alignment_*, host code of the library):
     dict(ec_tptr, ec_targets, ec_counts, ec_rptr, ec_reads, n_reads).  Errors carry the reference's
-    messages (include/mSWEEP_alignment.hpp:84-91, :131)."""
+    messages (include/mSWEEP_alignment.hpp:84-91, :131).  The arrays are read-only VIEWS of the native handle's own
+    storage (msw_alignment_view: no 0.9 GB copy at cfg3), which lives as long as any of them does; copy=True gives
+    ordinary writable arrays (msw_alignment_export)."""
     L = load_library()
     if merge_mode not in ("intersection", "union"):
         raise MswError(f"Unrecognized option `{merge_mode}` for --themisto-mode")
@@ -170,17 +188,31 @@ def read_alignment(paths, n_targets, merge_mode="intersection"):
     h = C.c_void_p()
     if L.msw_alignment_read(arr, len(paths), int(n_targets), 0 if merge_mode == "intersection" else 1, C.byref(h)):
         raise MswError(L.msw_alignment_last_error().decode())
-    try:
-        ne, nr, nh, na = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
-        L.msw_alignment_shape(h, C.byref(ne), C.byref(nr), C.byref(nh), C.byref(na))
+    owner = _AlignmentOwner(L, h)
+    ne, nr, nh, na = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    L.msw_alignment_shape(h, C.byref(ne), C.byref(nr), C.byref(nh), C.byref(na))
+    if copy:
         out = dict(ec_tptr=np.empty(ne.value + 1, np.uint64), ec_targets=np.empty(nh.value, np.uint32),
                    ec_counts=np.empty(ne.value, np.uint64), ec_rptr=np.empty(ne.value + 1, np.uint64),
                    ec_reads=np.empty(na.value, np.uint32), n_reads=int(nr.value))
-        L.msw_alignment_export(h, _ptr(out["ec_tptr"]), _ptr(out["ec_targets"]), _ptr(out["ec_counts"]),
-                               _ptr(out["ec_rptr"]), _ptr(out["ec_reads"]))
+        if L.msw_alignment_export(h, _ptr(out["ec_tptr"]), _ptr(out["ec_targets"]), _ptr(out["ec_counts"]),
+                                  _ptr(out["ec_rptr"]), _ptr(out["ec_reads"])):
+            raise MswError("msw_alignment_export failed")
         return out
-    finally:
-        L.msw_alignment_destroy(h)
+    p = [C.c_void_p() for _ in range(5)]
+    L.msw_alignment_view(h, *[C.byref(x) for x in p])
+
+    def view(ptr, n, ctype, dtype):
+        if n == 0 or not ptr.value:
+            return np.empty(0, dtype)
+        buf = (ctype * n).from_address(ptr.value)
+        buf._owner = owner               # array -> ctypes buffer -> owner -> handle
+        a = np.frombuffer(buf, dtype=dtype)
+        a.flags.writeable = False
+        return a
+    return dict(ec_tptr=view(p[0], ne.value + 1, C.c_uint64, np.uint64), ec_targets=view(p[1], nh.value, C.c_uint32, np.uint32),
+                ec_counts=view(p[2], ne.value, C.c_uint64, np.uint64), ec_rptr=view(p[3], ne.value + 1, C.c_uint64, np.uint64),
+                ec_reads=view(p[4], na.value, C.c_uint32, np.uint32), n_reads=int(nr.value))
 
 
 def _ptr(a):

@@ -39,6 +39,12 @@ constexpr int kLongStep = MSW_LONG_STEP;  // records per lane and step on the wa
 #ifndef MSW_PASSA_BATCH
 #define MSW_PASSA_BATCH 4
 #endif
+// the first slice of every wavefront requested before the LDS fill (SliceStream::prime); MSW_NO_PRIME: A/B builds
+#ifdef MSW_NO_PRIME
+constexpr bool kPrimeFirstSlice = false;
+#else
+constexpr bool kPrimeFirstSlice = true;
+#endif
 #ifndef MSW_PASSB_BATCH
 #define MSW_PASSB_BATCH 4
 #endif
@@ -391,10 +397,11 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   if constexpr (HYB) stream.nullr_hot = R::make_h(S.n_groups + (uint32_t)lane, 0u, D);
   else stream.nullr_hot = null_rec;
   auto issue = [&](SliceBuf<ENC> &) {};
+  // (offset records only: with the 8-byte, index and value records the primed buffer costs the kernels 100-300 bytes
+  // of scratch per lane -- cfg2's value-record sweeps went from 30 to 44 us -- and they open as before)
+  constexpr bool PRIME = kPrimeFirstSlice && ENC == kEncNarrow;
   SliceBuf<ENC> first = {};
-#ifndef MSW_NO_PRIME
-  stream.prime(first, issue);  // the first slice's records are in flight under the LDS fill
-#endif
+  if constexpr (PRIME) stream.prime(first, issue);  // the first slice's records are in flight under the LDS fill
   double m1 = 0.0, m2 = 0.0;
   for (int b0 = 0; tid < 64 && b0 < npartR; b0 += 512) {
     double t1[8], t2[8];
@@ -570,11 +577,8 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
       }
     }
   };
-#ifndef MSW_NO_PRIME
-  stream.run(issue, process, [] {}, &first);
-#else
-  stream.run(issue, process, [] {});
-#endif
+  if constexpr (PRIME) stream.run(issue, process, [] {}, &first);
+  else stream.run(issue, process, [] {});
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step -- the groups of one EC are
   // distinct, so the gathers of a step never meet on an address, and the three sums are wave
   // reductions (no barrier)
@@ -747,10 +751,10 @@ __global__ __launch_bounds__((pass_threads_B<ENC, RC>())) void k_passB(const Sca
     const uint32_t cj = S.c8s[q < n_lanes ? q : 0u];
     sb.c8 = q < n_lanes ? cj : 0u;
   };
+  // (see pass A; modes 0 and 3 -- e_g gathered from memory -- sit at the register limit: 16 bytes of scratch with it)
+  constexpr bool PRIME = kPrimeFirstSlice && ENC == kEncNarrow && GMODE != 0 && GMODE != 3;
   SliceBuf<ENC, RC> first = {};
-#ifndef MSW_NO_PRIME
-  stream.prime(first, issue);
-#endif
+  if constexpr (PRIME) stream.prime(first, issue);
   if (TL) {
     double2 *t = reinterpret_cast<double2 *>(smem);
     for (uint32_t i = tid; i < n_tab; i += NT) t[i] = tabB_g[i];
@@ -1123,11 +1127,8 @@ __global__ __launch_bounds__((pass_threads_B<ENC, RC>())) void k_passB(const Sca
       }
     }
   };
-#ifndef MSW_NO_PRIME
-  stream.run(issue, process, flush_logs, &first);
-#else
-  stream.run(issue, process, flush_logs);
-#endif
+  if constexpr (PRIME) stream.run(issue, process, flush_logs, &first);
+  else stream.run(issue, process, flush_logs);
   // long ECs (plain CSR): one wavefront per EC, a cell per lane and step (see pass A)
   // The current EC's first kLongStep * 64 records stay in registers for the scatter (one reload less: 10 % on
   // ECs of 300..1000 cells), and the next EC's first ones are fetched before the current one is

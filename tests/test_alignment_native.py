@@ -167,3 +167,28 @@ def test_gzip_input_equals_plaintext(tmp_path):
     bad.write_bytes(gz.read_bytes()[:-20])
     with pytest.raises(MswError, match="gzip"):
         read_alignment([str(bad)], n_targets)
+
+
+def test_views_outlive_the_call_and_equal_the_copy(tmp_path):
+    """read_alignment returns read-only VIEWS of the native handle's storage (msw_alignment_view: no copy of the EC ->
+    target lists); the handle lives as long as any of the arrays; copy=True (msw_alignment_export, on the reader's
+    threads) gives ordinary writable arrays with the same contents."""
+    import gc
+    rng = np.random.default_rng(8)
+    p = tmp_path / "s.txt"
+    _write_strand(p, rng, 5000, 300)
+    v = read_alignment([str(p)], 300)
+    c = read_alignment([str(p)], 300, copy=True)
+    for k in ("ec_tptr", "ec_targets", "ec_counts", "ec_rptr", "ec_reads"):
+        np.testing.assert_array_equal(v[k], c[k])
+        assert not v[k].flags.writeable and c[k].flags.writeable
+    assert v["n_reads"] == c["n_reads"]
+    targets = v["ec_targets"]
+    want = c["ec_targets"].copy()
+    del v
+    gc.collect()
+    junk = [np.full(100_000, 7, np.uint32) for _ in range(20)]   # (memory churn: a freed handle would be overwritten)
+    np.testing.assert_array_equal(targets, want)
+    del junk
+    with pytest.raises(ValueError):
+        targets[0] = 1
