@@ -431,7 +431,7 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
   [[maybe_unused]] const double va = uniform_d(sc->a), vtref = uniform_d(sc->tref), vlogzi = uniform_d(sc->logzi);
   [[maybe_unused]] const double voma = 1.0 - va;
   auto XTg_ = [&](RT r) -> double2 {   // any entry (hybrid: from memory)
-    if constexpr (VAL) return make_double2(exp(va * (r.t - vtref)), voma * (r.t - vlogzi));
+    if constexpr (VAL) return make_double2(exp_le0(va * (r.t - vtref)), voma * (r.t - vlogzi));
     else return tab16<TLDS>(xt_b, R::t_off(r, D));
   };
   auto XT_ = [&](RT r) -> double2 {    // hybrid: hot entries only, from a hot segment's row (16 * entry ready-made)
@@ -777,7 +777,7 @@ __global__ __launch_bounds__((pass_threads_B<ENC, RC>())) void k_passB(const Sca
   [[maybe_unused]] const double vp0 = uniform_d(sc->p0), vp0l = vp0 * vlogzi;
   auto XTg_ = [&](RT r) -> double2 {   // any entry (hybrid: from memory)
     if constexpr (VAL) {
-      const double x = exp(va * (r.t - vtref));
+      const double x = exp_le0(va * (r.t - vtref));
       return make_double2(x - vp0, fma(x, r.t, -vp0l));
     } else {
       return tab16<TLDS>(xt_b, R::t_off(r, D));
@@ -788,11 +788,11 @@ __global__ __launch_bounds__((pass_threads_B<ENC, RC>())) void k_passB(const Sca
     else return tab16<TL>(xt_b, rec_t_off<ENC, true>(r, D));
   };
   auto XMg_ = [&](RT r) -> double {
-    if constexpr (VAL) return exp(va * (r.t - vtref)) - vp0;
+    if constexpr (VAL) return exp_le0(va * (r.t - vtref)) - vp0;
     else return tab8<TLDS>(xt_b, R::t_off(r, D));
   };
   auto XMgh_ = [&](RT r) -> double {   // the same for a hot segment's row
-    if constexpr (VAL) return exp(va * (r.t - vtref)) - vp0;
+    if constexpr (VAL) return exp_le0(va * (r.t - vtref)) - vp0;
     else return tab8<TLDS>(xt_b, rec_t_off<ENC, true>(r, D));
   };
   typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
