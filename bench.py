@@ -566,7 +566,7 @@ def run_e2e(a):
     from msweep_amd import synth
     from msweep_amd.alignment import Alignment
     from msweep_amd.core import Core, read_alignment
-    from msweep_amd.likelihood import from_alignment
+    from msweep_amd.likelihood import from_alignment, from_device_alignment
     from msweep_amd.sample import PlainSample
     G, R = a.groups, a.reads
     tmp = tempfile.mkdtemp(prefix="msweep_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
@@ -594,33 +594,48 @@ def run_e2e(a):
         core = Core(0)
         stages = {}
         best = None
-        for rep in range(2):            # (the first pass also warms the page cache and the allocator)
+        def one_pass(device_reader):
             t1 = time.perf_counter()
-            al = read_alignment([f1, f2], n_targets, "intersection")
-            t2 = time.perf_counter()
-            lik = from_alignment(core, al["ec_tptr"], al["ec_targets"], target_group, sizes, al["ec_counts"],
-                                 download_log_counts=False)
+            if device_reader:
+                al = core.read_alignment([f1, f2], n_targets, "intersection")
+                t2 = time.perf_counter()
+                lik = from_device_alignment(core, al, target_group, sizes)
+                n_reads, n_aligned, n_ecs, n_hits = al.n_reads, al.n_aligned, al.n_ecs, al.n_hits
+            else:
+                al = read_alignment([f1, f2], n_targets, "intersection")
+                t2 = time.perf_counter()
+                lik = from_alignment(core, al["ec_tptr"], al["ec_targets"], target_group, sizes, al["ec_counts"],
+                                     download_log_counts=False)
+                n_reads, n_aligned, n_ecs, n_hits = al["n_reads"], len(al["ec_reads"]), len(al["ec_counts"]), len(al["ec_targets"])
             t3 = time.perf_counter()
             res = core.solve(None, np.ones(lik.n_groups))
             t4 = time.perf_counter()
             out = io.StringIO()
-            smp = PlainSample(al["n_reads"], int(al["ec_counts"].sum()))
+            smp = PlainSample(n_reads, n_aligned)
             smp.store_abundances(res["theta"])
             smp.write_abundances(names, out)
             with open(os.path.join(tmp, "e2e_abundances.txt"), "w") as f:
                 f.write(out.getvalue())
             t5 = time.perf_counter()
             cur = {"read_collapse_s": t2 - t1, "build_likelihood_s": t3 - t2, "solve_s": t4 - t3, "write_abundances_s": t5 - t4,
-                   "total_s": t5 - t1, "iters": int(res["iters"]), "ecs": int(len(al["ec_counts"])),
-                   "target_hits": int(len(al["ec_targets"]))}
-            log(f"e2e pass {rep}: " + ", ".join(f"{k} {v:.3f}" if isinstance(v, float) else f"{k} {v}" for k, v in cur.items()))
-            if best is None or cur["total_s"] < best["total_s"]:
-                best = cur
+                   "total_s": t5 - t1, "iters": int(res["iters"]), "ecs": int(n_ecs), "target_hits": int(n_hits)}
             # (a few ECs fewer than the generator made: the reference keys reads by a 64-bit XOR-shift hash of their
             # target set alone and merges what collides -- include/mSWEEP_alignment.hpp:152-156,186 -- as this reader does)
             assert E - 64 <= cur["ecs"] <= E and abs(res["theta"].sum() - 1.0) < 1e-9
-            del al
-        stages = best
+            return cur, out.getvalue()
+
+        both = {}
+        for device_reader in (False, True):
+            best = None
+            for rep in range(2 if not device_reader else 3):  # (the first pass also warms the page cache and the allocator)
+                cur, text = one_pass(device_reader)
+                log(f"e2e pass {rep} ({'device' if device_reader else 'host'} reader): " +
+                    ", ".join(f"{k} {v:.3f}" if isinstance(v, float) else f"{k} {v}" for k, v in cur.items()))
+                if best is None or cur["total_s"] < best["total_s"]:
+                    best = cur
+            both[device_reader] = (best, text)
+        assert both[False][1] == both[True][1], "abundances.txt differs between the host and the device reader"
+        stages, stages_host = both[True][0], both[False][0]
         threads = int(os.environ.get("MSWEEP_READER_THREADS", "0")) or min(16, cpu_share())
         # the Python mirror of the reference's reader on a prefix of the same files
         n_py = min(R, 100_000)
@@ -655,14 +670,21 @@ def run_e2e(a):
             "metric": "e2e: Themisto plaintext -> abundances.txt, 10M reads x 5k groups (reads/s of the whole pipeline)",
             "value": R / stages["total_s"], "unit": "reads/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
             "config": {"workload": f"cfg3's {R} reads x {G} groups as two Themisto plaintext strands ({nbytes / 1e9:.2f} GB of "
-                                   "text, --themisto-mode intersection), msw_alignment_read -> msw_core_build_likelihood -> "
+                                   "text, --themisto-mode intersection), msw_alignment_read_device -> msw_core_build_likelihood_aln -> "
                                    "msw_core_solve(--tol 1e-6) -> abundances.txt", "reads": R, "groups": G, "seed": a.seed},
             "stages_s": stages,
-            "reader": {"threads": threads, "text_MB_per_s": nbytes / 1e6 / stages["read_collapse_s"],
-                       "reads_per_s": R / stages["read_collapse_s"], "text_bytes": nbytes,
-                       "what": "msw_alignment_read: mmap, chunk-parallel parse, rows by read id, paired-end intersection, "
-                               "the reference's 64-bit hash, parallel merge sort, equivalence classes (host_alignment.inc) + "
-                               "export into NumPy arrays"},
+            "reader": {"text_MB_per_s": nbytes / 1e6 / stages["read_collapse_s"],
+                       "reads_per_s": R / stages["read_collapse_s"], "text_bytes": nbytes, "host_threads": threads,
+                       "what": "msw_alignment_read_device: pread into pinned staging on the host threads, the text to HBM "
+                               "two chunks in flight, then kernels -- tokens, rows by read id, sorted sets, paired-end "
+                               "intersection, the reference's 64-bit hash, radix sort, equivalence classes "
+                               "(host_reader.inc); the classes stay in device memory for msw_core_build_likelihood_aln"},
+            "host_reader": {"stages_s": stages_host, "threads": threads,
+                            "text_MB_per_s": nbytes / 1e6 / stages_host["read_collapse_s"],
+                            "reads_per_s": R / stages_host["read_collapse_s"],
+                            "what": "the same files through msw_alignment_read (host_alignment.inc: mmap, chunk-parallel "
+                                    "parse, parallel merge sort) + msw_core_build_likelihood from host arrays: the same "
+                                    "abundances.txt, byte for byte"},
             "python_mirror": {"reads": n_py, "seconds": t_py, "text_MB_per_s": py_bytes / 1e6 / t_py, "reads_per_s": n_py / t_py,
                               "what": "msweep_amd/alignment.py Alignment.read + collapse (the mirror of include/"
                                       "mSWEEP_alignment.hpp:54-215) on the first lines of the same files: the stated baseline"},

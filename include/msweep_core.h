@@ -305,6 +305,21 @@ int msw_alignment_export(msw_alignment_t a, uint64_t *ec_tptr, uint32_t *ec_targ
 int msw_alignment_view(msw_alignment_t a, const uint64_t **ec_tptr, const uint32_t **ec_targets, const uint64_t **ec_counts,
                        const uint64_t **ec_rptr, const uint32_t **ec_reads);
 void msw_alignment_destroy(msw_alignment_t a);
+/* The same reader ON THE DEVICE of handle h (round 5; msweep_amd/csrc/host_reader.inc): the text goes to device memory
+ * as it is read and the parse, the rows by read id, the paired-end merge, the reference's hash, the sort and the
+ * classes are kernels; the five arrays stay in device memory (msw_core_build_likelihood_aln consumes them there) and
+ * msw_alignment_view / _export copy them out on first use.  Same outcome as msw_alignment_read, array for array.
+ * Text the host parser would not take silently (anything but digits, blanks and line ends, ids beyond 32 bits,
+ * target ids out of range) is handed to msw_alignment_read, whose result or error message stands
+ * (msw_alignment_last_error / msw_last_error). */
+int msw_alignment_read_device(msw_handle h, const char *const *paths, size_t n_paths, size_t n_targets, int merge_mode,
+                              msw_alignment_t *out);
+/* msw_core_build_likelihood on an alignment handle: arrays resident on h's device are read where they lie (no copy
+ * through the host); any other handle goes through its host arrays.  ec_counts = the classes' read counts. */
+int msw_core_build_likelihood_aln(msw_handle h, msw_alignment_t a, const uint32_t *target_group, size_t n_targets,
+                                  const uint64_t *group_sizes, size_t n_groups, double q, double e,
+                                  double zero_inflation, size_t min_hits, size_t *n_groups_out, uint8_t *mask_out,
+                                  double *logc_out);
 /* error text of the last failed msw_alignment_read of this thread (the reference's messages) */
 const char *msw_alignment_last_error(void);
 

@@ -24,7 +24,8 @@ EXPORTS = [
     "msw_core_create", "msw_core_destroy", "msw_last_error", "msw_core_version",
     "msw_core_set_dense_logl", "msw_core_set_csr", "msw_core_build_likelihood",
     "msw_core_get_dense_logl", "msw_core_layout_hash", "msw_core_shape", "msw_alignment_read",
-    "msw_alignment_shape", "msw_alignment_export", "msw_alignment_view", "msw_alignment_destroy", "msw_alignment_last_error", "msw_core_solve", "msw_core_prepare", "msw_core_run",
+    "msw_alignment_shape", "msw_alignment_export", "msw_alignment_view", "msw_alignment_destroy", "msw_alignment_last_error",
+    "msw_alignment_read_device", "msw_core_build_likelihood_aln", "msw_core_solve", "msw_core_prepare", "msw_core_run",
     "msw_core_gamma",
     "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
@@ -154,6 +155,9 @@ def load_library():
     L.msw_alignment_view.argtypes = [vp] + [C.POINTER(vp)] * 5
     L.msw_alignment_export.argtypes = [vp, vp, vp, vp, vp, vp]
     L.msw_alignment_destroy.argtypes = [vp]
+    L.msw_alignment_read_device.argtypes = [vp, C.POINTER(C.c_char_p), sz, sz, C.c_int, C.POINTER(vp)]
+    L.msw_core_build_likelihood_aln.argtypes = [vp, vp, vp, sz, vp, sz, C.c_double, C.c_double, C.c_double, sz,
+                                                C.POINTER(sz), vp, vp]
     L.msw_alignment_destroy.restype = None
     L.msw_alignment_last_error.restype = C.c_char_p
     _lib = L
@@ -199,8 +203,32 @@ def read_alignment(paths, n_targets, merge_mode="intersection", copy=False):
                                   _ptr(out["ec_rptr"]), _ptr(out["ec_reads"])):
             raise MswError("msw_alignment_export failed")
         return out
+    return _alignment_views(L, h, owner, ne.value, nh.value, na.value, nr.value)
+
+
+class DeviceAlignment:
+    """An alignment read by msw_alignment_read_device: its arrays live in the memory of the GPU that parsed the text
+    (Core.read_alignment).  Core.build_likelihood_aln consumes them there; arrays() copies them out on first use
+    (the dict read_alignment returns, as read-only views)."""
+
+    def __init__(self, L, h):
+        self._L, self._h = L, h
+        self._owner = _AlignmentOwner(L, h)
+        ne, nr, nh, na = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        L.msw_alignment_shape(h, C.byref(ne), C.byref(nr), C.byref(nh), C.byref(na))
+        self.n_ecs, self.n_reads, self.n_hits, self.n_aligned = ne.value, nr.value, nh.value, na.value
+        self._arrays = None
+
+    def arrays(self):
+        if self._arrays is None:
+            self._arrays = _alignment_views(self._L, self._h, self._owner, self.n_ecs, self.n_hits, self.n_aligned, self.n_reads)
+        return self._arrays
+
+
+def _alignment_views(L, h, owner, n_ecs, n_hits, n_aligned, n_reads):
     p = [C.c_void_p() for _ in range(5)]
-    L.msw_alignment_view(h, *[C.byref(x) for x in p])
+    if L.msw_alignment_view(h, *[C.byref(x) for x in p]):
+        raise MswError("msw_alignment_view failed")
 
     def view(ptr, n, ctype, dtype):
         if n == 0 or not ptr.value:
@@ -210,9 +238,9 @@ def read_alignment(paths, n_targets, merge_mode="intersection", copy=False):
         a = np.frombuffer(buf, dtype=dtype)
         a.flags.writeable = False
         return a
-    return dict(ec_tptr=view(p[0], ne.value + 1, C.c_uint64, np.uint64), ec_targets=view(p[1], nh.value, C.c_uint32, np.uint32),
-                ec_counts=view(p[2], ne.value, C.c_uint64, np.uint64), ec_rptr=view(p[3], ne.value + 1, C.c_uint64, np.uint64),
-                ec_reads=view(p[4], na.value, C.c_uint32, np.uint32), n_reads=int(nr.value))
+    return dict(ec_tptr=view(p[0], n_ecs + 1, C.c_uint64, np.uint64), ec_targets=view(p[1], n_hits, C.c_uint32, np.uint32),
+                ec_counts=view(p[2], n_ecs, C.c_uint64, np.uint64), ec_rptr=view(p[3], n_ecs + 1, C.c_uint64, np.uint64),
+                ec_reads=view(p[4], n_aligned, C.c_uint32, np.uint32), n_reads=int(n_reads))
 
 
 def _ptr(a):
@@ -299,6 +327,35 @@ class Core:
             self._h, _ptr(ec_tptr), _ptr(ec_targets), E, _ptr(target_group), len(target_group),
             _ptr(group_sizes), G, _ptr(ec_counts), q, e, zero_inflation, int(min_hits), C.byref(n_out),
             _ptr(mask), _ptr(logc)))
+        return n_out.value, mask.astype(bool), logc
+
+    def read_alignment(self, paths, n_targets, merge_mode="intersection"):
+        """The Themisto plaintext reader ON THIS GPU (msw_alignment_read_device): the text goes to device memory as it
+        is read; parse, rows by read id, paired-end merge, the reference's hash, sort and classes are kernels.  Returns
+        a DeviceAlignment (build_likelihood_aln reads it where it lies; .arrays() = what read_alignment() returns).
+        Errors carry the reference's messages: text the kernels do not judge goes to the host reader."""
+        if merge_mode not in ("intersection", "union"):
+            raise MswError(f"Unrecognized option `{merge_mode}` for --themisto-mode")
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        h = C.c_void_p()
+        if self._L.msw_alignment_read_device(self._h, arr, len(paths), int(n_targets),
+                                             0 if merge_mode == "intersection" else 1, C.byref(h)):
+            raise MswError(self._L.msw_alignment_last_error().decode())
+        return DeviceAlignment(self._L, h)
+
+    def build_likelihood_aln(self, aln, target_group, group_sizes, q=0.65, e=0.01, zero_inflation=0.01, min_hits=0,
+                             want_logc=True):
+        """build_likelihood on a DeviceAlignment: its classes, targets and read counts are read in device memory.
+        Returns (n_groups_kept, mask[G] bool, logc[E] or None)."""
+        target_group = _arr(target_group, np.uint32)
+        group_sizes = _arr(group_sizes, np.uint64)
+        G = len(group_sizes)
+        n_out = C.c_size_t()
+        mask = np.zeros(G, np.uint8)
+        logc = np.empty(aln.n_ecs, np.float64) if want_logc else None
+        self._check(self._L.msw_core_build_likelihood_aln(
+            self._h, aln._h, _ptr(target_group), len(target_group), _ptr(group_sizes), G, q, e, zero_inflation,
+            int(min_hits), C.byref(n_out), _ptr(mask), _ptr(logc)))
         return n_out.value, mask.astype(bool), logc
 
     def shape(self):

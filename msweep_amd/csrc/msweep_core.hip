@@ -19,6 +19,8 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "kernels.hpp"
 #include "pack_kernels.hpp"
@@ -31,6 +33,7 @@
 #include "em_kernels.hpp"
 #include "em_f32_kernels.hpp"
 #include "stream_kernels.hpp"
+#include "reader_kernels.hpp"
 
 using namespace msw;
 
@@ -45,6 +48,7 @@ struct msw_core {
   int n_cu = 256;
   hipStream_t stream = nullptr;
   std::string err;
+  TextStager text_stage;  // pinned staging of msw_alignment_read_device (host_reader.inc)
 
   // ---- resident likelihood -----------------------------------------------------------
   int flavor = -1;  // -1 none, 0 CSR-of-ECs, 1 dense
@@ -930,6 +934,7 @@ struct StageTimer {
 #include "host_build.inc"
 #include "host_compress.inc"
 #include "host_alignment.inc"
+#include "host_reader.inc"
 
 // =========================================================================================
 // C ABI
@@ -1004,8 +1009,51 @@ int msw_core_build_likelihood(msw_handle h, const uint64_t *ec_tptr, const uint3
   return guarded(h, [&] {
     build_likelihood_impl(h, ec_tptr, ec_targets, n_ecs, target_group, n_targets, group_sizes,
                           n_groups, ec_counts, q, e, zero_inflation, min_hits, n_groups_out, mask_out,
-                          logc_out);
+                          logc_out, false, 0);
   });
+}
+
+int msw_core_build_likelihood_aln(msw_handle h, msw_alignment_t a, const uint32_t *target_group, size_t n_targets,
+                                  const uint64_t *group_sizes, size_t n_groups, double q, double e,
+                                  double zero_inflation, size_t min_hits, size_t *n_groups_out, uint8_t *mask_out,
+                                  double *logc_out) {
+  return guarded(h, [&] {
+    if (!a) throw Fail("msw_core_build_likelihood_aln: null alignment");
+    if (a->on_device && a->device == h->device) {
+      // the reader's arrays are consumed where they lie (same device; the reader ran on this handle's stream or
+      // has synchronised its own)
+      build_likelihood_impl(h, a->d_tptr.p, a->d_targets.p, a->E, target_group, n_targets, group_sizes, n_groups,
+                            a->d_counts.p, q, e, zero_inflation, min_hits, n_groups_out, mask_out, logc_out, true, a->H);
+    } else {
+      a->to_host();
+      build_likelihood_impl(h, a->ec_tptr.data(), a->ec_targets.data(), a->ec_counts.size(), target_group, n_targets,
+                            group_sizes, n_groups, a->ec_counts.data(), q, e, zero_inflation, min_hits, n_groups_out,
+                            mask_out, logc_out, false, 0);
+    }
+  });
+}
+
+int msw_alignment_read_device(msw_handle h, const char *const *paths, size_t n_paths, size_t n_targets, int merge_mode,
+                              msw_alignment_t *out) {
+  if (out) *out = nullptr;
+  const int rc = guarded(h, [&] {
+    check_reader_args(paths, out, n_paths, n_targets, merge_mode);
+    std::unique_ptr<msw_alignment> a(new msw_alignment);
+    a->device = h->device;
+    ReaderCtx cx{h->stream, h->n_cu, &h->text_stage};
+    try {
+      read_alignment_device(paths, n_paths, n_targets, merge_mode, cx, *a);
+    } catch (const ReaderFallback &) {
+      // text the kernels do not judge: the host reader's outcome -- a result or the reference's message -- stands
+      msw_alignment_t host = nullptr;
+      if (msw_alignment_read(paths, n_paths, n_targets, merge_mode, &host) != 0) throw Fail(msw_alignment_last_error());
+      *out = host;
+      return;
+    }
+    *out = a.release();
+  });
+  if (rc != 0 && h) g_aln_error = msw_last_error(h);
+  return rc;
 }
 
 int msw_core_layout_info(msw_handle h, msw_layout_info *out) {

@@ -1,0 +1,395 @@
+// reader_kernels.hpp -- device side of the Themisto plaintext reader (round 5): the text of a
+// pseudoalignment file is parsed, collapsed into equivalence classes and handed to the likelihood build without
+// leaving HBM.  Same outcome as the host reader (host_alignment.inc), array for array; reference:
+// include/mSWEEP_alignment.hpp:54-94 (line parser), :97-135 (paired-end merge), :137-215 (collapse).
+//
+// Byte work: every kernel here is a streaming pass (text: 1 byte per character, twice; tokens: 4 bytes each) or a
+// gather over rows of ~16 integers; nothing is shaped for the matrix cores.
+//
+// Text -> tokens.  A TOKEN is a maximal run of digits; a line is `read_id target target ...`.  The text is cut into
+// tiles of kTileBytes; pass 1 counts tokens and newlines per tile and checks the bytes (anything the host parser
+// would not take silently raises a flag, and the caller hands the file to the host parser, whose word is final);
+// the tile counts are scanned; pass 2 converts every token and writes
+//   tokens[k]          value of the k-th token of the file
+//   line_first[l]      index of the first token (the read id) of line l; line_first[n_lines] = n_tokens.
+#pragma once
+#include "common.hpp"
+
+namespace msw {
+
+constexpr int kSegBytes = 16;                             // bytes of text per thread
+constexpr int kTileThreads = 256;
+constexpr int kTileBytes = kSegBytes * kTileThreads;      // 4 KB per workgroup
+// what the text checks report (ReaderCtr::flags)
+constexpr uint32_t kTxtBadChar = 1u;      // a byte that is no digit, blank, line feed or carriage return
+constexpr uint32_t kTxtBadCr = 2u;        // a carriage return that does not end its line
+constexpr uint32_t kTxtBadLineStart = 4u; // a line that does not start with a digit (empty lines too)
+constexpr uint32_t kTxtOverflow = 8u;     // a token of more than 10 digits or beyond 2^32 - 1
+constexpr uint32_t kTxtBadTarget = 16u;   // a target id >= n_targets
+
+struct ReaderCtr {
+  uint32_t flags;
+  uint32_t max_id;      // largest read id
+  uint32_t unsorted;    // rows whose targets do not ascend strictly
+  uint32_t shrunk;      // rows that lost duplicates
+};
+
+// the 16 bytes of a thread's segment as bit masks: digits, line feeds; `bad` collects the byte checks
+struct SegMasks {
+  uint32_t dig, nl, cr, blank;
+};
+__device__ __forceinline__ SegMasks seg_masks(const unsigned char (&c)[kSegBytes], uint32_t valid) {
+  SegMasks m = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < kSegBytes; ++i) {
+    const uint32_t b = c[i];
+    m.dig |= (uint32_t)(b - '0' <= 9u) << i;
+    m.nl |= (uint32_t)(b == '\n') << i;
+    m.cr |= (uint32_t)(b == '\r') << i;
+    m.blank |= (uint32_t)(b == ' ') << i;
+  }
+  m.dig &= valid, m.nl &= valid, m.cr &= valid, m.blank &= valid;
+  return m;
+}
+__device__ __forceinline__ void load_seg(const unsigned char *txt, uint64_t at, unsigned char (&c)[kSegBytes]) {
+  const uint4 v = *reinterpret_cast<const uint4 *>(txt + at);  // (the buffer is padded to a multiple of the tile)
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < kSegBytes; ++i) c[i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o));
+  return v;
+}
+// inclusive scan of v over the 256 threads of a workgroup (sh: 4 words); returns the inclusive value, *total = the sum
+__device__ __forceinline__ uint32_t tile_scan_incl(uint32_t v, uint32_t *sh, uint32_t *total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(v, o);
+    if (lane >= o) v += u;
+  }
+  if (lane == 63) sh[w] = v;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kTileThreads / 64; ++k) {
+    const uint32_t s = sh[k];
+    if (k < w) base += s;
+    tot += s;
+  }
+  *total = tot;
+  return v + base;
+}
+
+// Pass 1 over the text: tokens and line feeds per tile, byte checks.
+// cnt_tok[tile] = tokens that START in the tile, cnt_nl[tile] = line feeds.
+__global__ __launch_bounds__(kTileThreads) void k_text_count(const unsigned char *txt, uint64_t n, uint32_t *cnt_tok,
+                                                              uint32_t *cnt_nl, ReaderCtr *ctr) {
+  __shared__ uint32_t sh[8];
+  const uint64_t at = ((uint64_t)blockIdx.x * kTileThreads + threadIdx.x) * kSegBytes;
+  uint32_t ntok = 0, nnl = 0, bad = 0;
+  if (at < n) {
+    unsigned char c[kSegBytes];
+    load_seg(txt, at, c);
+    const uint32_t valid = n - at >= (uint64_t)kSegBytes ? 0xffffu : (1u << (uint32_t)(n - at)) - 1u;
+    const SegMasks m = seg_masks(c, valid);
+    const unsigned char prev = at ? txt[at - 1] : (unsigned char)'\n';
+    const bool have_next = at + kSegBytes < n;
+    const unsigned char next = have_next ? txt[at + kSegBytes] : (unsigned char)'\n';
+    const uint32_t pdig = (m.dig << 1 | (uint32_t)(prev - '0' <= 9u)) & 0xffffu;   // digit in front of byte i
+    const uint32_t pnl = (m.nl << 1 | (uint32_t)(prev == '\n')) & 0xffffu;         // line feed in front of byte i
+    const uint32_t starts = m.dig & ~pdig;
+    ntok = __popc(starts);
+    nnl = __popc(m.nl);
+    if ((m.dig | m.nl | m.cr | m.blank) != valid) bad |= kTxtBadChar;
+    // a carriage return ends its line: the next byte is a line feed (or the text ends there)
+    const uint32_t nl_after = (m.nl >> 1) | ((have_next ? (uint32_t)(next == '\n') : 1u) << (kSegBytes - 1));
+    // (inside a last, partial segment the byte after the last valid one is the end of the text)
+    const uint32_t end_after = valid != 0xffffu ? (valid + 1u) >> 1 : 0u;
+    if (m.cr & ~(nl_after | end_after)) bad |= kTxtBadCr;
+    // every line starts with a digit: the byte behind a line feed (and the first byte of the text)
+    if (pnl & valid & ~m.dig) bad |= kTxtBadLineStart;
+  }
+  // block sums
+  uint32_t tot = 0;
+  const uint32_t packed = ntok | nnl << 16;  // (<= 8 tokens and 16 line feeds per thread, 4096 per tile)
+  (void)tile_scan_incl(packed, sh, &tot);
+  bad = wave_or(bad);
+  if (threadIdx.x == 0) {
+    cnt_tok[blockIdx.x] = tot & 0xffffu;
+    cnt_nl[blockIdx.x] = tot >> 16;
+  }
+  if (bad && (threadIdx.x & 63) == 0) atomicOr(&ctr->flags, bad);
+}
+
+// Pass 2: the tokens' values and the lines' first tokens.  base_tok[tile], base_nl[tile] = tokens / line feeds in
+// front of the tile (exclusive scans of pass 1's counts).
+__global__ __launch_bounds__(kTileThreads) void k_text_parse(const unsigned char *txt, uint64_t n, const uint64_t *base_tok,
+                                                              const uint64_t *base_nl, uint32_t n_targets, uint32_t *tokens,
+                                                              uint64_t *line_first, ReaderCtr *ctr) {
+  __shared__ uint32_t sh[8];
+  const uint64_t at = ((uint64_t)blockIdx.x * kTileThreads + threadIdx.x) * kSegBytes;
+  uint32_t starts = 0, nls = 0, pnl = 0;
+  uint64_t W[4] = {0, 0, 0, 0};  // the segment and the 16 bytes behind it (a token that starts at byte 15 ends by byte 25)
+  if (at < n) {
+    unsigned char a[kSegBytes];
+    load_seg(txt, at, a);
+    // (the buffer is padded with line feeds beyond the text: the bytes behind the last segment end a token like
+    // the end of the text does)
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(txt + at), v1 = *reinterpret_cast<const uint4 *>(txt + at + kSegBytes);
+    W[0] = (uint64_t)v0.y << 32 | v0.x, W[1] = (uint64_t)v0.w << 32 | v0.z;
+    W[2] = (uint64_t)v1.y << 32 | v1.x, W[3] = (uint64_t)v1.w << 32 | v1.z;
+    const uint32_t valid = n - at >= (uint64_t)kSegBytes ? 0xffffu : (1u << (uint32_t)(n - at)) - 1u;
+    const SegMasks m = seg_masks(a, valid);
+    const unsigned char prev = at ? txt[at - 1] : (unsigned char)'\n';
+    const uint32_t pdig = (m.dig << 1 | (uint32_t)(prev - '0' <= 9u)) & 0xffffu;
+    pnl = (m.nl << 1 | (uint32_t)(prev == '\n')) & 0xffffu;
+    starts = m.dig & ~pdig;
+    nls = m.nl;
+  }
+  uint32_t tot = 0;
+  const uint32_t mine = (uint32_t)__popc(starts) | (uint32_t)__popc(nls) << 16;
+  const uint32_t incl = tile_scan_incl(mine, sh, &tot);
+  const uint32_t excl = incl - mine;
+  uint64_t tk = base_tok[blockIdx.x] + (excl & 0xffffu);
+  const uint64_t l0 = base_nl[blockIdx.x] + (excl >> 16);
+  uint32_t bad = 0, max_id = 0;
+  // tokens: at most 10 digits, the byte behind them in hand (a token that starts at byte 15 ends by byte 25)
+  uint32_t s = starts;
+  const uint64_t tk0 = tk;
+  while (s) {
+    const int i = __ffs(s) - 1;
+    s &= s - 1;
+    // the 16 bytes from byte i on, by shifts (no indexed register array)
+    const bool up = i >= 8;
+    const uint32_t shb = (uint32_t)(i & 7) * 8u;
+    const uint64_t A = up ? W[1] : W[0], B = up ? W[2] : W[1], C = up ? W[3] : W[2];
+    const uint64_t lo = shb ? A >> shb | B << (64u - shb) : A, hi = shb ? B >> shb | C << (64u - shb) : B;
+    uint64_t v = 0;
+    int k = 0;
+#pragma unroll
+    for (int d = 0; d < 11; ++d) {
+      const uint32_t ch = (uint32_t)((d < 8 ? lo >> (8 * d) : hi >> (8 * (d - 8))) & 0xffu);
+      if (k == d && ch - '0' <= 9u) {
+        v = v * 10 + (ch - '0');
+        ++k;
+      }
+    }
+    if (k > 10 || v > 0xffffffffull) bad |= kTxtOverflow;
+    if ((pnl >> i) & 1u) max_id = max(max_id, (uint32_t)v);   // the line's first token: its read id
+    else if (v >= n_targets) bad |= kTxtBadTarget;
+    tokens[tk++] = (uint32_t)v;
+  }
+  // line l + 1 starts behind the l-th line feed: its first token is the next one to start
+  uint32_t q = nls, ln = 0;
+  while (q) {
+    const int i = __ffs(q) - 1;
+    q &= q - 1;
+    line_first[l0 + ln + 1] = tk0 + (uint32_t)__popc(starts & ((1u << i) - 1u));
+    ++ln;
+  }
+  bad = wave_or(bad);
+  max_id = wave_umax(max_id);
+  if ((threadIdx.x & 63) == 0) {
+    if (bad) atomicOr(&ctr->flags, bad);
+    if (max_id) atomicMax(&ctr->max_id, max_id);
+  }
+}
+
+// ---- rows by read id ------------------------------------------------------------------------------------------------
+// A read is the SET of targets of all lines that carry its id (include/mSWEEP_alignment.hpp:62-90: every line sets bits
+// of its read's row); ids at or beyond n_ids (= min(largest id + 1, lines)) never take part (:148).
+__global__ void k_row_count(const uint32_t *tokens, const uint64_t *line_first, uint64_t n_lines, uint64_t n_ids,
+                            uint32_t *cnt) {
+  for (uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n_lines; l += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t f = line_first[l];
+    const uint32_t len = (uint32_t)(line_first[l + 1] - f - 1);
+    const uint32_t rid = tokens[f];
+    if (rid < n_ids && len) atomicAdd(&cnt[rid], len);
+  }
+}
+__global__ void k_row_fill(const uint32_t *tokens, const uint64_t *line_first, uint64_t n_lines, uint64_t n_ids,
+                           const uint64_t *ptr, uint32_t *cur, uint32_t *raw) {
+  for (uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n_lines; l += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t f = line_first[l];
+    const uint32_t len = (uint32_t)(line_first[l + 1] - f - 1);
+    const uint32_t rid = tokens[f];
+    if (rid < n_ids && len) {
+      const uint32_t off = atomicAdd(&cur[rid], len);
+      uint32_t *dst = raw + ptr[rid] + off;
+      const uint32_t *src = tokens + f + 1;
+      for (uint32_t j = 0; j < len; ++j) dst[j] = src[j];
+    }
+  }
+}
+// rows whose targets do not ascend strictly (Themisto promises no order): flen[r] = the row's length, 0 for rows in order
+__global__ void k_row_check(const uint64_t *ptr, const uint32_t *raw, uint64_t n_ids, uint32_t *flen, ReaderCtr *ctr) {
+  uint32_t mine = 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_ids; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t b = ptr[r], e = ptr[r + 1];
+    bool asc = true;
+    for (uint64_t k = b; k + 1 < e; ++k) asc = asc && raw[k] < raw[k + 1];
+    flen[r] = asc ? 0u : (uint32_t)(e - b);
+    mine += !asc;
+  }
+  if (mine) atomicAdd(&ctr->unsorted, mine);
+}
+// the rows out of order as 64-bit keys (row, target): sorted as a whole, every row comes back ascending
+__global__ void k_row_keys(const uint64_t *ptr, const uint32_t *raw, uint64_t n_ids, const uint32_t *flen,
+                           const uint64_t *foff, uint64_t *keys) {
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_ids; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t len = flen[r];
+    if (!len) continue;
+    const uint32_t *src = raw + ptr[r];
+    uint64_t *dst = keys + foff[r];
+    for (uint32_t j = 0; j < len; ++j) dst[j] = r << 32 | src[j];
+  }
+}
+// keep[k] = the sorted key differs from its predecessor (duplicates of a target inside a row go)
+__global__ void k_keys_keep(const uint64_t *keys, uint64_t m, uint32_t *keep) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += (uint64_t)gridDim.x * blockDim.x)
+    keep[k] = k == 0 || keys[k] != keys[k - 1];
+}
+// the rows written back in order, without duplicates; cnt[r] = the row's new length
+__global__ void k_rows_sorted_back(const uint64_t *keys, const uint32_t *keep, const uint64_t *kidx, const uint64_t *ptr,
+                                   const uint32_t *flen, const uint64_t *foff, uint64_t n_ids, uint64_t m, uint32_t *raw,
+                                   uint32_t *cnt, ReaderCtr *ctr) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = i; k < m; k += step) {
+    if (!keep[k]) continue;
+    const uint64_t r = keys[k] >> 32;
+    raw[ptr[r] + (kidx[k] - kidx[foff[r]])] = (uint32_t)keys[k];
+  }
+  uint32_t lost = 0;
+  for (uint64_t r = i; r < n_ids; r += step) {
+    const uint32_t len = flen[r];
+    if (!len) continue;
+    const uint32_t kept = (uint32_t)(kidx[foff[r] + len] - kidx[foff[r]]);
+    cnt[r] = kept;
+    lost += kept != len;
+  }
+  if (lost) atomicAdd(&ctr->shrunk, lost);
+}
+__global__ void k_rows_compact(const uint64_t *ptr, const uint32_t *raw, const uint32_t *cnt, const uint64_t *nptr,
+                               uint64_t n_ids, uint32_t *out) {
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_ids; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t *src = raw + ptr[r];
+    uint32_t *dst = out + nptr[r];
+    const uint32_t len = cnt[r];
+    for (uint32_t j = 0; j < len; ++j) dst[j] = src[j];
+  }
+}
+
+// ---- paired-end merge (include/mSWEEP_alignment.hpp:123-133): intersection / union of the two strands' rows ----------
+// WRITE = false: len[i] = length of read i's merged row; true: the row written at optr[i]
+template <bool WRITE>
+__global__ void k_merge_rows(const uint64_t *aptr, const uint32_t *atgt, uint64_t na, const uint64_t *bptr,
+                             const uint32_t *btgt, uint64_t nb, uint64_t n, int intersect, uint32_t *len,
+                             const uint64_t *optr, uint32_t *out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t a = 0, ae = 0, b = 0, be = 0;
+    if (i < na) a = aptr[i], ae = aptr[i + 1];
+    if (i < nb) b = bptr[i], be = bptr[i + 1];
+    uint32_t *dst = WRITE ? out + optr[i] : nullptr;
+    uint32_t k = 0;
+    while (a < ae && b < be) {
+      const uint32_t x = atgt[a], y = btgt[b];
+      if (x == y) {
+        if (WRITE) dst[k] = x;
+        ++k, ++a, ++b;
+      } else if (x < y) {
+        if (!intersect) {
+          if (WRITE) dst[k] = x;
+          ++k;
+        }
+        ++a;
+      } else {
+        if (!intersect) {
+          if (WRITE) dst[k] = y;
+          ++k;
+        }
+        ++b;
+      }
+    }
+    if (!intersect) {
+      for (; a < ae; ++a, ++k)
+        if (WRITE) dst[k] = atgt[a];
+      for (; b < be; ++b, ++k)
+        if (WRITE) dst[k] = btgt[b];
+    }
+    if (!WRITE) len[i] = k;
+  }
+}
+
+// ---- collapse (include/mSWEEP_alignment.hpp:137-215) --------------------------------------------------------------------
+__global__ void k_flag_aligned(const uint64_t *ptr, uint64_t n, uint32_t *flag) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    flag[i] = ptr[i + 1] != ptr[i];
+}
+// the aligned reads keyed by the reference's hash of their ascending target ids (:152-156)
+__global__ void k_hash_reads(const uint64_t *ptr, const uint32_t *tgt, uint64_t n, const uint64_t *idx, uint64_t *keys,
+                             uint32_t *ids) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t b = ptr[i], e = ptr[i + 1];
+    if (b == e) continue;
+    uint64_t h = 0;
+    for (uint64_t k = b; k < e; ++k) h ^= (uint64_t)tgt[k] + 0x517cc1b727220a95ull + (h << 6) + (h >> 2);
+    keys[idx[i]] = h;
+    ids[idx[i]] = (uint32_t)i;
+  }
+}
+__global__ void k_ec_heads(const uint64_t *keys, uint64_t K, uint32_t *head) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < K; k += (uint64_t)gridDim.x * blockDim.x)
+    head[k] = k == 0 || keys[k] != keys[k - 1];
+}
+// per class: where its reads start, the length of its representative's row (the first read of the class, :199-203)
+__global__ void k_ec_meta(const uint32_t *head, const uint64_t *eidx, const uint32_t *ids, const uint64_t *ptr, uint64_t K,
+                          uint64_t *rptr, uint32_t *tlen) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < K; k += (uint64_t)gridDim.x * blockDim.x) {
+    if (!head[k]) continue;
+    const uint64_t e = eidx[k];
+    const uint32_t rep = ids[k];
+    rptr[e] = k;
+    tlen[e] = (uint32_t)(ptr[rep + 1] - ptr[rep]);
+  }
+}
+__global__ void k_ec_rows(const uint64_t *rptr, const uint32_t *ids, const uint64_t *ptr, const uint32_t *tgt,
+                          const uint64_t *tptr, uint64_t E, uint64_t *counts, uint32_t *out) {
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (uint64_t)gridDim.x * blockDim.x) {
+    counts[e] = rptr[e + 1] - rptr[e];
+    const uint32_t rep = ids[rptr[e]];
+    const uint32_t *src = tgt + ptr[rep];
+    uint32_t *dst = out + tptr[e];
+    const uint32_t len = (uint32_t)(tptr[e + 1] - tptr[e]);
+    for (uint32_t j = 0; j < len; ++j) dst[j] = src[j];
+  }
+}
+
+// ---- host: pinned staging of the text on its way to the device (host_reader.inc) ------------------------------------------
+// two pinned staging buffers + their events: owned by the handle (pinning 2 x 64 MB costs ~20 ms: once per handle)
+struct TextStager {
+  static constexpr size_t kChunk = 64u << 20;
+  void *buf[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  void ready() {
+    for (int i = 0; i < 2; ++i) {
+      if (!buf[i]) MSW_HIP(hipHostMalloc(&buf[i], kChunk, hipHostMallocDefault));
+      if (!ev[i]) MSW_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    }
+  }
+  ~TextStager() {
+    for (int i = 0; i < 2; ++i) {
+      if (buf[i]) (void)hipHostFree(buf[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+  }
+};
+
+}  // namespace msw

@@ -90,6 +90,26 @@ def from_alignment(core: Core, ec_tptr, ec_targets, target_group, group_sizes, e
     return Likelihood(core, logc, mask, n_kept, len(ec_tptr) - 1, ec_counts=None if download_log_counts else ec_counts)
 
 
+class _LazyCounts:
+    """ec_counts of a DeviceAlignment, copied out of device memory only if log_counts() is asked for on the host"""
+
+    def __init__(self, aln):
+        self._aln = aln
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._aln.arrays()["ec_counts"]
+        return a.astype(dtype) if dtype is not None else a
+
+
+def from_device_alignment(core: Core, aln, target_group, group_sizes, q=0.65, e=0.01, zero_inflation=0.01, min_hits=0,
+                          download_log_counts=False):
+    """from_alignment on a DeviceAlignment (Core.read_alignment): classes, targets and read counts are consumed in
+    device memory (msw_core_build_likelihood_aln); nothing of the pseudoalignment crosses PCIe twice."""
+    n_kept, mask, logc = core.build_likelihood_aln(aln, target_group, group_sizes, q, e, zero_inflation, min_hits,
+                                                   want_logc=download_log_counts)
+    return Likelihood(core, logc, mask, n_kept, aln.n_ecs, ec_counts=None if download_log_counts else _LazyCounts(aln))
+
+
 def from_dense(core: Core, logl, log_counts):
     """--read-likelihood path (include/Likelihood.hpp:224-253): arbitrary dense G x E matrix."""
     logl = np.asarray(logl, np.float64)

@@ -1,0 +1,180 @@
+"""The Themisto reader on the device (msw_alignment_read_device, msweep_amd/csrc/host_reader.inc + reader_kernels.hpp)
+against the host reader (msw_alignment_read, itself held against the Python mirror of mSWEEP::Alignment in
+test_alignment_native.py): the five arrays equal, element for element, on single- and paired-end inputs, lines in any
+order, targets in any order and repeated, read ids repeated and out of range, CRLF, trailing blanks, no final line
+feed, empty files, gzip; text the kernels do not judge goes to the host parser and carries its messages; the likelihood
+built from the device-resident arrays is the one built from the host arrays."""
+import gzip
+
+import numpy as np
+import pytest
+
+from msweep_amd.core import Core, MswError, read_alignment
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("ec_tptr", "ec_targets", "ec_counts", "ec_rptr", "ec_reads")
+
+
+def _equal(dev, host):
+    assert dev["n_reads"] == host["n_reads"]
+    for k in KEYS:
+        np.testing.assert_array_equal(dev[k], host[k], err_msg=k)
+
+
+def _lines(rng, n_reads, n_targets, p_unaligned=0.2, max_k=7, sort_targets=False, dup_targets=False, dup_lines=True,
+           shuffle=True, big_row_every=0):
+    lines = []
+    for r in range(n_reads):
+        if rng.random() < p_unaligned:
+            lines.append(f"{r}")
+            continue
+        k = int(rng.integers(1, max_k))
+        if big_row_every and r % big_row_every == 0:
+            k = min(n_targets, 900)
+        t = rng.choice(n_targets, k, replace=False)
+        if sort_targets:
+            t = np.sort(t)
+        t = [int(x) for x in t]
+        if dup_targets and rng.random() < 0.3:
+            t = t + [t[0]] + t[-1:]
+        lines.append(f"{r} " + " ".join(map(str, t)))
+    if dup_lines:
+        for r in rng.choice(n_reads, max(1, n_reads // 20), replace=False):
+            lines.append(f"{int(r)} {int(rng.integers(0, n_targets))}")
+    if shuffle:
+        rng.shuffle(lines)
+    return lines
+
+
+@pytest.fixture(scope="module")
+def core():
+    with Core(0) as c:
+        yield c
+
+
+@pytest.mark.parametrize("mode,n_strands", [("intersection", 1), ("intersection", 2), ("union", 2), ("union", 3)])
+@pytest.mark.parametrize("flavour", ["sorted", "any-order", "dup-targets"])
+def test_device_reader_equals_host_reader(core, tmp_path, mode, n_strands, flavour):
+    rng = np.random.default_rng([len(mode), n_strands, len(flavour)])
+    n_targets, n_reads = 211, 5000
+    paths = []
+    for s in range(n_strands):
+        p = tmp_path / f"s{s}.txt"
+        lines = _lines(rng, n_reads + 17 * s, n_targets, sort_targets=flavour == "sorted", dup_targets=flavour == "dup-targets",
+                       dup_lines=flavour != "sorted", shuffle=flavour != "sorted", big_row_every=1500 if flavour == "any-order" else 0)
+        p.write_text("\n".join(lines) + "\n")
+        paths.append(str(p))
+    host = read_alignment(paths, n_targets, mode)
+    dev = core.read_alignment(paths, n_targets, mode)
+    assert (dev.n_ecs, dev.n_hits, dev.n_aligned, dev.n_reads) == (len(host["ec_counts"]), len(host["ec_targets"]),
+                                                                  len(host["ec_reads"]), host["n_reads"])
+    _equal(dev.arrays(), host)
+
+
+def test_text_shapes_the_parser_takes(core, tmp_path):
+    """CRLF, blanks at line ends, several blanks, no final line feed, a read id at and beyond the line count, tokens that
+    straddle segment (16-byte) and tile (4096-byte) boundaries."""
+    n_targets = 100000
+    cases = {
+        "crlf": "0 1 2\r\n1 3\r\n2\r\n",
+        "trailing-blank": "0 1 2 \n1 3 \n",
+        "two-blanks": "0 1  2\n1   3\n",
+        "no-final-lf": "0 1 2\n1 3",
+        "no-final-lf-cr": "0 1 2\n1 3\r",
+        "id-at-line-count": "0 5\n2 6\n1 7\n7 8\n",
+        "one-line": "0 99999",
+        "only-ids": "0\n1\n2\n",
+        "straddle": "".join(f"{i} " + " ".join(str(99000 + (i * 7 + j) % 999) for j in range(1 + i % 9)) + "\n" for i in range(3000)),
+    }
+    for name, text in cases.items():
+        p = tmp_path / f"{name}.txt"
+        p.write_bytes(text.encode())
+        host = read_alignment([str(p)], n_targets)
+        dev = core.read_alignment([str(p)], n_targets).arrays()
+        _equal(dev, host)
+
+
+def test_empty_and_unaligned_files(core, tmp_path):
+    e = tmp_path / "empty.txt"
+    e.write_text("")
+    u = tmp_path / "unaligned.txt"
+    u.write_text("0\n1\n2\n")
+    a = tmp_path / "a.txt"
+    a.write_text("0 1\n1 2\n2 1\n")
+    for paths, mode in (([e], "intersection"), ([u], "intersection"), ([a, u], "intersection"), ([a, u], "union"),
+                        ([a, e], "union"), ([e, a], "union"), ([a, e], "intersection")):
+        host = read_alignment([str(x) for x in paths], 5, mode)
+        dev = core.read_alignment([str(x) for x in paths], 5, mode).arrays()
+        _equal(dev, host)
+
+
+def test_text_the_kernels_do_not_judge_goes_to_the_host_parser(core, tmp_path):
+    good = tmp_path / "good.txt"
+    good.write_text("0 1 2\n1 3\n")
+    bad = tmp_path / "bad.txt"
+    bad.write_text("0 1 2\n1 x3\n")
+    with pytest.raises(MswError, match="File format not supported on line 2 with content: 1 x3"):
+        core.read_alignment([str(bad)], 10)
+    with pytest.raises(MswError, match="more target sequences than expected"):
+        core.read_alignment([str(good)], 3)
+    empty_line = tmp_path / "empty_line.txt"
+    empty_line.write_text("0 1\n\n1 2\n")
+    with pytest.raises(MswError, match="File format not supported on line 2"):
+        core.read_alignment([str(empty_line)], 10)
+    compact = tmp_path / "compact.txt"
+    compact.write_text("3,5,query,target\n0 1\n")
+    with pytest.raises(MswError, match="compact"):
+        core.read_alignment([str(compact)], 10)
+    with pytest.raises(MswError, match="cannot open"):
+        core.read_alignment([str(tmp_path / "missing.txt")], 10)
+    # accepted by the host parser although the kernels hand it over: leading zeros beyond ten digits
+    zeros = tmp_path / "zeros.txt"
+    zeros.write_text("0 00000000003 1\n1 2\n")
+    _equal(core.read_alignment([str(zeros)], 10).arrays(), read_alignment([str(zeros)], 10))
+    with pytest.raises(MswError, match="themisto-mode"):
+        core.read_alignment([str(good)], 10, "both")
+
+
+def test_gzip_input(core, tmp_path):
+    rng = np.random.default_rng(5)
+    lines = _lines(rng, 3000, 97)
+    plain = tmp_path / "p.txt"
+    plain.write_text("\n".join(lines) + "\n")
+    gz = tmp_path / "p.txt.gz"
+    with gzip.open(gz, "wt") as f:
+        f.write("\n".join(lines) + "\n")
+    _equal(core.read_alignment([str(gz)], 97).arrays(), read_alignment([str(plain)], 97))
+
+
+def test_more_than_one_staging_chunk_and_likelihood_from_device_arrays(core, tmp_path):
+    """~150 MB of text per strand (three 64 MB staging chunks), then msw_core_build_likelihood_aln on the resident
+    arrays against msw_core_build_likelihood on the host reader's: the same layout, bit for bit."""
+    rng = np.random.default_rng(11)
+    n_targets, n_groups, n_reads = 3000, 60, 1_500_000
+    k = rng.integers(6, 22, n_reads)
+    base = rng.integers(0, n_targets - 50, n_reads)
+    paths = []
+    for s in range(2):
+        p = tmp_path / f"big{s}.txt"
+        with open(p, "w") as f:
+            step = 100000
+            for r0 in range(0, n_reads, step):
+                rows = []
+                for r in range(r0, min(n_reads, r0 + step)):
+                    t = base[r] + np.arange(k[r]) * 2 + s * (r % 3 == 0)
+                    rows.append(f"{r} " + " ".join(map(str, t.tolist())))
+                f.write("\n".join(rows) + "\n")
+        paths.append(str(p))
+    host = read_alignment(paths, n_targets, "intersection")
+    aln = core.read_alignment(paths, n_targets, "intersection")
+    _equal(aln.arrays(), host)
+    target_group = (np.arange(n_targets) % n_groups).astype(np.uint32)
+    group_sizes = np.bincount(target_group, minlength=n_groups).astype(np.uint64)
+    g1, m1, logc1 = core.build_likelihood_aln(aln, target_group, group_sizes, min_hits=1)
+    h1 = core.layout_hash()
+    shape1 = core.shape()
+    g2, m2, logc2 = core.build_likelihood(host["ec_tptr"], host["ec_targets"], target_group, group_sizes, host["ec_counts"], min_hits=1)
+    assert (g1, shape1, h1) == (g2, core.shape(), core.layout_hash())
+    np.testing.assert_array_equal(m1, m2)
+    np.testing.assert_array_equal(logc1, logc2)
