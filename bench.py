@@ -554,10 +554,12 @@ def launch_selftest(a, rank, world):
 
 # ---- end to end from Themisto text ---------------------------------------------------------------
 def run_e2e(a):
-    """cfg3's reads as two Themisto plaintext strands -> msw_alignment_read (parse, paired-end intersection, collapse
-    into equivalence classes) -> msw_core_build_likelihood -> solve to --tol 1e-6 -> abundances.txt.  One GPU.  Beside
-    it: the same files through the Python mirror of include/mSWEEP_alignment.hpp (msweep_amd/alignment.py) on a bounded
-    prefix, and a gzip pair (single-threaded zlib inflate in front of the same parser)."""
+    """cfg3's reads as two Themisto plaintext strands -> msw_alignment_read_device (text to HBM; parse, paired-end
+    intersection, collapse into equivalence classes as kernels) -> msw_core_build_likelihood_aln -> solve to --tol 1e-6
+    -> abundances.txt.  One GPU.  Beside it: the same files through the host reader (msw_alignment_read +
+    msw_core_build_likelihood: the same abundances.txt, byte for byte), through the Python mirror of
+    include/mSWEEP_alignment.hpp (msweep_amd/alignment.py) on a bounded prefix, and a gzip pair (single-threaded zlib
+    inflate in front of the host parser)."""
     import gzip
     import io
     import shutil
@@ -624,11 +626,12 @@ def run_e2e(a):
             assert E - 64 <= cur["ecs"] <= E and abs(res["theta"].sum() - 1.0) < 1e-9
             return cur, out.getvalue()
 
-        both = {}
+        both, first = {}, {}
         for device_reader in (False, True):
             best = None
             for rep in range(2 if not device_reader else 3):  # (the first pass also warms the page cache and the allocator)
                 cur, text = one_pass(device_reader)
+                first.setdefault(device_reader, cur)
                 log(f"e2e pass {rep} ({'device' if device_reader else 'host'} reader): " +
                     ", ".join(f"{k} {v:.3f}" if isinstance(v, float) else f"{k} {v}" for k, v in cur.items()))
                 if best is None or cur["total_s"] < best["total_s"]:
@@ -673,6 +676,11 @@ def run_e2e(a):
                                    "text, --themisto-mode intersection), msw_alignment_read_device -> msw_core_build_likelihood_aln -> "
                                    "msw_core_solve(--tol 1e-6) -> abundances.txt", "reads": R, "groups": G, "seed": a.seed},
             "stages_s": stages,
+            "stages_first_pass_s": first[True],
+            "stages_what": "stages_s: the best of three passes on one handle (from the second pass on the reader's device "
+                           "memory comes from the handle's pool: no allocation); stages_first_pass_s: the first pass of "
+                           "the device reader in this process -- what a single run of the drivers pays (page cache warm "
+                           "from the host reader's passes)",
             "reader": {"text_MB_per_s": nbytes / 1e6 / stages["read_collapse_s"],
                        "reads_per_s": R / stages["read_collapse_s"], "text_bytes": nbytes, "host_threads": threads,
                        "what": "msw_alignment_read_device: pread into pinned staging on the host threads, the text to HBM "

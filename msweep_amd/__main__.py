@@ -7,9 +7,8 @@ import sys
 import numpy as np
 
 from . import parallel
-from .alignment import Alignment
 from .core import ALGO_EM, ALGO_RCG, PREC_DOUBLE, PREC_FLOAT, Core, MswError
-from .likelihood import from_alignment, from_dense
+from .likelihood import from_device_alignment, from_dense
 from .reference import read_reference
 from .sample import BootstrapSample, PlainSample
 
@@ -104,15 +103,21 @@ def main(argv=None):
     a = parse(sys.argv[1:] if argv is None else argv)
     aln = None
     try:
+        core = Core(a.device)
+    except MswError as ex:
+        sys.stderr.write(f"Initialising the GPU failed:\n  {ex}\nexiting\n")
+        return 1
+    try:
         with open(a.indicators) as f:
             grouping = read_reference(f)
         if not a.read_likelihood:
             files = a.themisto.split(",") if a.themisto else [x for x in (a.themisto_1, a.themisto_2) if x]
             if not files:
                 raise RuntimeError("no pseudoalignment files given")
-            aln = Alignment(len(grouping.group_indicators))
-            aln.read_files(a.themisto_mode, files)   # native reader + collapse (msw_alignment_read)
-    except (RuntimeError, OSError) as ex:
+            # the reader on the device (msw_alignment_read_device): text -> equivalence classes in HBM, consumed there
+            # by the likelihood build; the reference's messages for text it does not take
+            aln = core.read_alignment(files, len(grouping.group_indicators), a.themisto_mode)
+    except (RuntimeError, OSError, MswError) as ex:
         sys.stderr.write(f"Reading the pseudoalignments failed:\n  {ex}\nexiting\n")
         return 1
     if a.algorithm == "rcgcpu":
@@ -125,7 +130,6 @@ def main(argv=None):
     # (--emprecision float: fp32 kernels where the layout allows, msweep_amd/csrc/em_f32_kernels.hpp; the library
     # reports which through msw_timing::em_float_kernels)
     try:
-        core = Core(a.device)
         # ordering the cells for the LDS banks pays from about the 1 000th iteration on: bootstrap runs (msw_core_set_pack_schedule)
         core.set_pack_schedule(a.iters >= 5)
         if a.read_likelihood:
@@ -134,10 +138,12 @@ def main(argv=None):
             lik = from_dense(core, L, np.log(ec_counts.astype(np.float64)))
             n_reads = total_reads = int(ec_counts.sum())
         else:
-            lik = from_alignment(core, aln.ec_tptr, aln.ec_targets, grouping.group_indicators, grouping.get_sizes(),
-                                 aln.ec_counts, a.q, a.e, a.zero_inflation, a.min_hits)
-            ec_counts = aln.ec_counts
-            n_reads = aln.n_reads()
+            if aln.n_ecs == 0:
+                raise RuntimeError("no read aligned against the reference")
+            lik = from_device_alignment(core, aln, grouping.group_indicators, grouping.get_sizes(), a.q, a.e,
+                                        a.zero_inflation, a.min_hits)
+            ec_counts = aln.ec_counts()
+            n_reads = aln.n_reads
     except (MswError, RuntimeError, OSError, ValueError) as ex:
         sys.stderr.write(f"Building the log-likelihood array failed:\n  {ex}\nexiting\n")
         return 1

@@ -25,7 +25,7 @@ EXPORTS = [
     "msw_core_set_dense_logl", "msw_core_set_csr", "msw_core_build_likelihood",
     "msw_core_get_dense_logl", "msw_core_layout_hash", "msw_core_shape", "msw_alignment_read",
     "msw_alignment_shape", "msw_alignment_export", "msw_alignment_view", "msw_alignment_destroy", "msw_alignment_last_error",
-    "msw_alignment_read_device", "msw_core_build_likelihood_aln", "msw_core_solve", "msw_core_prepare", "msw_core_run",
+    "msw_alignment_read_device", "msw_core_build_likelihood_aln", "msw_core_trim", "msw_core_solve", "msw_core_prepare", "msw_core_run",
     "msw_core_gamma",
     "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
@@ -155,6 +155,7 @@ def load_library():
     L.msw_alignment_view.argtypes = [vp] + [C.POINTER(vp)] * 5
     L.msw_alignment_export.argtypes = [vp, vp, vp, vp, vp, vp]
     L.msw_alignment_destroy.argtypes = [vp]
+    L.msw_core_trim.argtypes = [vp]
     L.msw_alignment_read_device.argtypes = [vp, C.POINTER(C.c_char_p), sz, sz, C.c_int, C.POINTER(vp)]
     L.msw_core_build_likelihood_aln.argtypes = [vp, vp, vp, sz, vp, sz, C.c_double, C.c_double, C.c_double, sz,
                                                 C.POINTER(sz), vp, vp]
@@ -218,6 +219,16 @@ class DeviceAlignment:
         L.msw_alignment_shape(h, C.byref(ne), C.byref(nr), C.byref(nh), C.byref(na))
         self.n_ecs, self.n_reads, self.n_hits, self.n_aligned = ne.value, nr.value, nh.value, na.value
         self._arrays = None
+        self._counts = None
+
+    def ec_counts(self):
+        """reads per class (uint64): the one array the drivers need on the host -- 8 bytes per class leave the device"""
+        if self._counts is None:
+            out = np.empty(self.n_ecs, np.uint64)
+            if self._L.msw_alignment_export(self._h, None, None, _ptr(out), None, None):
+                raise MswError("msw_alignment_export failed")
+            self._counts = out
+        return self._counts
 
     def arrays(self):
         if self._arrays is None:
@@ -342,6 +353,10 @@ class Core:
                                              0 if merge_mode == "intersection" else 1, C.byref(h)):
             raise MswError(self._L.msw_alignment_last_error().decode())
         return DeviceAlignment(self._L, h)
+
+    def trim(self):
+        """Gives the device temporaries of read_alignment back (kept on the handle between calls: msw_core_trim)."""
+        self._check(self._L.msw_core_trim(self._h))
 
     def build_likelihood_aln(self, aln, target_group, group_sizes, q=0.65, e=0.01, zero_inflation=0.01, min_hits=0,
                              want_logc=True):

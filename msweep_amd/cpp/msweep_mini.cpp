@@ -1,6 +1,6 @@
 // msweep_mini.cpp -- the estimation path of mSWEEP's main() (src/mSWEEP.cpp:258-551) as a native
 // host program over the C ABI: group indicators (-i, include/Reference.hpp / Grouping.hpp), Themisto
-// plaintext pseudoalignments (native reader: msw_alignment_read), likelihood built and kept on the
+// plaintext pseudoalignments (the reader on the device: msw_alignment_read_device), likelihood built and kept on the
 // GPU (msw_core_build_likelihood), RCG / EM abundances (--algorithm rcggpu|emgpu), bootstrap
 // (--iters / --seed / --bootstrap-count, src/mSWEEP.cpp:496-518) and abundances.txt in the format of
 // PlainSample / BootstrapSample::write_abundances[2] (src/PlainSample.cpp:32-71,
@@ -228,11 +228,14 @@ int main(int argc, char **argv) {
   }
   Grouping grouping;
   std::vector<uint64_t> ec_counts;
-  // (the EC -> target lists stay in the reader's handle and are handed to the likelihood build as they are:
-  // msw_alignment_view, no 0.7 GB copy at 10 M reads)
+  // The reader runs ON THE DEVICE (msw_alignment_read_device: text -> equivalence classes in HBM) and the likelihood
+  // build consumes its arrays there (msw_core_build_likelihood_aln); only the classes' read counts come to the host.
+  msw_handle h = nullptr;
+  if (msw_core_create(a.gpu, &h) != 0) {
+    std::cerr << "Initialising the GPU failed:\n  " << msw_last_error(nullptr) << "\nexiting\n";
+    return 1;
+  }
   msw_alignment_t aln_keep = nullptr;
-  const uint64_t *ec_tptr = nullptr;
-  const uint32_t *ec_targets = nullptr;
   size_t n_ecs = 0, n_reads = 0, n_hits = 0, n_aligned = 0;
   try {
     grouping = read_grouping(a.indicators);
@@ -243,17 +246,17 @@ int main(int argc, char **argv) {
       std::vector<const char *> paths;
       for (auto &p : a.themisto) paths.push_back(p.c_str());
       msw_alignment_t aln = nullptr;
-      if (msw_alignment_read(paths.data(), paths.size(), grouping.indicators.size(),
-                             a.mode == "union" ? MSW_MERGE_UNION : MSW_MERGE_INTERSECTION, &aln))
+      if (msw_alignment_read_device(h, paths.data(), paths.size(), grouping.indicators.size(),
+                                    a.mode == "union" ? MSW_MERGE_UNION : MSW_MERGE_INTERSECTION, &aln))
         throw std::runtime_error(msw_alignment_last_error());
       msw_alignment_shape(aln, &n_ecs, &n_reads, &n_hits, &n_aligned);
       ec_counts.resize(n_ecs);
       msw_alignment_export(aln, nullptr, nullptr, ec_counts.data(), nullptr, nullptr);
-      msw_alignment_view(aln, &ec_tptr, &ec_targets, nullptr, nullptr, nullptr);
       aln_keep = aln;
     }
   } catch (const std::exception &ex) {
     std::cerr << "Reading the pseudoalignments failed:\n  " << ex.what() << "\nexiting\n";
+    msw_core_destroy(h);
     return 1;
   }
   if (a.algorithm == "rcgcpu" && a.verbose)  // the reference's default: the same RCG algorithm on the host; no CPU path here
@@ -262,12 +265,10 @@ int main(int argc, char **argv) {
   const int prec = a.emprecision == "float" ? MSW_PREC_FLOAT : MSW_PREC_DOUBLE;
   // (--emprecision float: fp32 kernels where the layout allows, msweep_amd/csrc/em_f32_kernels.hpp)
   const size_t G = grouping.names.size();
-  msw_handle h = nullptr;
   size_t n_kept = 0;
   std::vector<uint8_t> mask(G, 1);
   std::vector<double> logc_file;  // --read-likelihood: the log counts of the file (the build leaves its own on the device)
   try {
-    if (msw_core_create(a.gpu, &h) != 0) throw std::runtime_error(msw_last_error(nullptr));
     // ordering the cells for the LDS banks pays from about the 1 000th iteration on: bootstrap runs
     check(h, msw_core_set_pack_schedule(h, a.iters >= 5 ? 1 : 0));
     if (!a.read_likelihood.empty()) {
@@ -284,11 +285,11 @@ int main(int argc, char **argv) {
       }
     } else {
       if (n_ecs == 0) throw std::runtime_error("no read aligned against the reference");
-      check(h, msw_core_build_likelihood(h, ec_tptr, ec_targets, n_ecs, grouping.indicators.data(),
-                                         grouping.indicators.size(), grouping.sizes.data(), G, ec_counts.data(), a.q,
-                                         a.e, a.zero_inflation, a.min_hits, &n_kept, mask.data(), nullptr));
-      msw_alignment_destroy(aln_keep);  // the likelihood is resident: the pseudoalignment can go
-      aln_keep = nullptr;
+      check(h, msw_core_build_likelihood_aln(h, aln_keep, grouping.indicators.data(), grouping.indicators.size(),
+                                             grouping.sizes.data(), G, a.q, a.e, a.zero_inflation, a.min_hits, &n_kept,
+                                             mask.data(), nullptr));
+      // (the likelihood is resident and the pseudoalignment could go -- but device memory given back is scrubbed before
+      // it is handed out again, and the solver state is allocated next: it goes at the end)
     }
     if (a.write_likelihood) {
       // --write-likelihood (include/Likelihood.hpp:255-273; the file: src/OutfileDesignator.cpp:67-74)
@@ -378,6 +379,7 @@ int main(int argc, char **argv) {
     msw_core_destroy(h);
     return 1;
   }
+  msw_alignment_destroy(aln_keep);
   msw_core_destroy(h);
 
   // ---- abundances (default ostream formatting = 6 significant digits, as the reference) ----------

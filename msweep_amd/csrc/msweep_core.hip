@@ -49,6 +49,7 @@ struct msw_core {
   hipStream_t stream = nullptr;
   std::string err;
   TextStager text_stage;  // pinned staging of msw_alignment_read_device (host_reader.inc)
+  ReaderPool reader_pool;  // ... and its device memory, kept between calls (reader_kernels.hpp)
 
   // ---- resident likelihood -----------------------------------------------------------
   int flavor = -1;  // -1 none, 0 CSR-of-ECs, 1 dense
@@ -1025,11 +1026,18 @@ int msw_core_build_likelihood_aln(msw_handle h, msw_alignment_t a, const uint32_
       build_likelihood_impl(h, a->d_tptr.p, a->d_targets.p, a->E, target_group, n_targets, group_sizes, n_groups,
                             a->d_counts.p, q, e, zero_inflation, min_hits, n_groups_out, mask_out, logc_out, true, a->H);
     } else {
-      a->to_host();
+      a->to_host(msw_alignment::kAlnTptr | msw_alignment::kAlnTargets | msw_alignment::kAlnCounts);
       build_likelihood_impl(h, a->ec_tptr.data(), a->ec_targets.data(), a->ec_counts.size(), target_group, n_targets,
                             group_sizes, n_groups, a->ec_counts.data(), q, e, zero_inflation, min_hits, n_groups_out,
                             mask_out, logc_out, false, 0);
     }
+  });
+}
+
+int msw_core_trim(msw_handle h) {
+  return guarded(h, [&] {
+    MSW_HIP(hipStreamSynchronize(h->stream));
+    h->reader_pool.trim();
   });
 }
 
@@ -1040,7 +1048,9 @@ int msw_alignment_read_device(msw_handle h, const char *const *paths, size_t n_p
     check_reader_args(paths, out, n_paths, n_targets, merge_mode);
     std::unique_ptr<msw_alignment> a(new msw_alignment);
     a->device = h->device;
-    ReaderCtx cx{h->stream, h->n_cu, &h->text_stage};
+    MSW_HIP(hipStreamSynchronize(h->stream));
+    h->reader_pool.recycle();  // (blocks the previous read handed back: nothing of it is in flight any more)
+    ReaderCtx cx(h->stream, h->n_cu, &h->text_stage, &h->reader_pool, h->device);
     try {
       read_alignment_device(paths, n_paths, n_targets, merge_mode, cx, *a);
     } catch (const ReaderFallback &) {

@@ -15,6 +15,10 @@
 #pragma once
 #include "common.hpp"
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
 namespace msw {
 
 constexpr int kSegBytes = 16;                             // bytes of text per thread
@@ -32,6 +36,7 @@ struct ReaderCtr {
   uint32_t max_id;      // largest read id
   uint32_t unsorted;    // rows whose targets do not ascend strictly
   uint32_t shrunk;      // rows that lost duplicates
+  uint32_t long_rows;   // rows out of order with more than 64 targets (sorted as keys, host_reader.inc)
 };
 
 // the 16 bytes of a thread's segment as bit masks: digits, line feeds; `bad` collects the byte checks
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(kTileThreads) void k_text_count(const unsigned char
 // front of the tile (exclusive scans of pass 1's counts).
 __global__ __launch_bounds__(kTileThreads) void k_text_parse(const unsigned char *txt, uint64_t n, const uint64_t *base_tok,
                                                               const uint64_t *base_nl, uint32_t n_targets, uint32_t *tokens,
-                                                              uint64_t *line_first, ReaderCtr *ctr) {
+                                                              uint64_t *line_first, uint32_t *tile_max, ReaderCtr *ctr) {
   __shared__ uint32_t sh[8];
   const uint64_t at = ((uint64_t)blockIdx.x * kTileThreads + threadIdx.x) * kSegBytes;
   uint32_t starts = 0, nls = 0, pnl = 0;
@@ -195,11 +200,104 @@ __global__ __launch_bounds__(kTileThreads) void k_text_parse(const unsigned char
     line_first[l0 + ln + 1] = tk0 + (uint32_t)__popc(starts & ((1u << i) - 1u));
     ++ln;
   }
+  // the largest read id: per tile, then k_max_u32 (an atomic per wavefront on ONE word was 10 of this kernel's 11.6 ms
+  // at 1 GB of text: a million same-address atomics take their turns in L2)
   bad = wave_or(bad);
   max_id = wave_umax(max_id);
   if ((threadIdx.x & 63) == 0) {
     if (bad) atomicOr(&ctr->flags, bad);
-    if (max_id) atomicMax(&ctr->max_id, max_id);
+    sh[4 + (threadIdx.x >> 6)] = max_id;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) tile_max[blockIdx.x] = max(max(sh[4], sh[5]), max(sh[6], sh[7]));
+}
+// *out = max(*out, in[0 .. n)): one workgroup
+__global__ __launch_bounds__(1024) void k_max_u32(const uint32_t *in, uint64_t n, uint32_t *out) {
+  __shared__ uint32_t sh[16];
+  uint32_t m = 0;
+  for (uint64_t i = threadIdx.x; i < n; i += 1024) m = max(m, in[i]);
+  m = wave_umax(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) m = max(m, sh[k]);
+    *out = max(*out, m);
+  }
+}
+
+// Rows of at most 64 targets that do not ascend: sorted by the wavefront that finds them (bitonic network over the
+// lanes, 21 exchanges), duplicates dropped, written back in place; cnt[r] = the new length, flen[r] = 0 (done).  Rows
+// of more than 64 targets keep flen[r] = their length for the key sort of the host side.
+__global__ __launch_bounds__(256) void k_rows_sort_short(const uint64_t *ptr, uint32_t *raw, uint64_t n_ids, uint32_t *flen,
+                                                          uint32_t *cnt, ReaderCtr *ctr) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  uint32_t lost = 0, left = 0;  // (lost: lane 0's count; left: this lane's rows)
+  for (uint64_t r0 = wave * 64; r0 < n_ids; r0 += n_waves * 64) {
+    const uint64_t mine = r0 + lane;
+    const uint32_t fl = mine < n_ids ? flen[mine] : 0u;
+    unsigned long long todo = __ballot(fl != 0u && fl <= 64u);
+    left += fl > 64u;
+    while (todo) {
+      const int k = __ffsll(todo) - 1;
+      todo &= todo - 1;
+      const uint64_t r = r0 + k;
+      const uint32_t len = __shfl(fl, k);
+      const uint64_t b = ptr[r];
+      uint32_t v = lane < len ? raw[b + lane] : 0xffffffffu;  // (target ids are < 2^32 - 1: the padding sorts last)
+#pragma unroll
+      for (uint32_t size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (uint32_t j = size >> 1; j > 0; j >>= 1) {
+          const uint32_t o = __shfl_xor(v, j);
+          const bool up = (lane & size) == 0, low = (lane & j) == 0;
+          v = (low == up) ? min(v, o) : max(v, o);
+        }
+      }
+      const uint32_t left_v = __shfl_up(v, 1);
+      const bool keep = lane < len && (lane == 0 || v != left_v);
+      const unsigned long long km = __ballot(keep);
+      if (keep) raw[b + __popcll(km & ((1ull << lane) - 1ull))] = v;
+      const uint32_t kept = (uint32_t)__popcll(km);
+      if (lane == 0) {
+        cnt[r] = kept;
+        flen[r] = 0u;
+        lost += kept != len;
+      }
+    }
+  }
+  if (lane == 0 && lost) atomicAdd(&ctr->shrunk, lost);
+  if (left) atomicAdd(&ctr->long_rows, left);
+}
+
+// The lanes of a wavefront copy 64 rows together: lane l names row l (len elements from src[so ..] to dst[d0 ..]); element
+// e of the 64 rows laid end to end is copied by lane e mod 64, so consecutive lanes touch consecutive addresses of a row
+// (a thread per row walks 64 rows 64 bytes apart with every load instruction).
+__device__ __forceinline__ void wave_copy_rows(const uint32_t *src, uint64_t so, uint32_t *dst, uint64_t d0, uint32_t len) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t end = len;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(end, o);
+    if (lane >= (uint32_t)o) end += u;
+  }
+  const uint32_t total = __shfl(end, 63);
+  for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+    const uint32_t e = e0 + lane;
+    uint32_t r = 0;  // the row that holds element e: the first lane whose rows end beyond e
+#pragma unroll
+    for (uint32_t step = 32; step > 0; step >>= 1) {
+      const uint32_t pe = __shfl(end, r + step - 1);
+      if (pe <= e) r += step;
+    }
+    r = min(r, 63u);
+    const uint32_t r_end = __shfl(end, r), r_len = __shfl(len, r);
+    const uint64_t r_so = (uint64_t)__shfl((uint32_t)(so >> 32), r) << 32 | (uint32_t)__shfl((uint32_t)so, r);
+    const uint64_t r_d0 = (uint64_t)__shfl((uint32_t)(d0 >> 32), r) << 32 | (uint32_t)__shfl((uint32_t)d0, r);
+    if (e < total) {
+      const uint32_t i = e - (r_end - r_len);
+      dst[r_d0 + i] = src[r_so + i];
+    }
   }
 }
 
@@ -215,18 +313,24 @@ __global__ void k_row_count(const uint32_t *tokens, const uint64_t *line_first, 
     if (rid < n_ids && len) atomicAdd(&cnt[rid], len);
   }
 }
-__global__ void k_row_fill(const uint32_t *tokens, const uint64_t *line_first, uint64_t n_lines, uint64_t n_ids,
-                           const uint64_t *ptr, uint32_t *cur, uint32_t *raw) {
-  for (uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n_lines; l += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t f = line_first[l];
-    const uint32_t len = (uint32_t)(line_first[l + 1] - f - 1);
-    const uint32_t rid = tokens[f];
-    if (rid < n_ids && len) {
-      const uint32_t off = atomicAdd(&cur[rid], len);
-      uint32_t *dst = raw + ptr[rid] + off;
-      const uint32_t *src = tokens + f + 1;
-      for (uint32_t j = 0; j < len; ++j) dst[j] = src[j];
+__global__ __launch_bounds__(256) void k_row_fill(const uint32_t *tokens, const uint64_t *line_first, uint64_t n_lines,
+                                                   uint64_t n_ids, const uint64_t *ptr, uint32_t *cur, uint32_t *raw) {
+  const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t l0 = t0 & ~63ull; l0 < n_lines; l0 += step) {  // (a wavefront's 64 lines together: wave_copy_rows)
+    const uint64_t l = l0 + (threadIdx.x & 63);
+    uint64_t so = 0, d0 = 0;
+    uint32_t len = 0;
+    if (l < n_lines) {
+      const uint64_t f = line_first[l];
+      const uint32_t n = (uint32_t)(line_first[l + 1] - f - 1);
+      const uint32_t rid = tokens[f];
+      if (rid < n_ids && n) {
+        len = n;
+        so = f + 1;
+        d0 = ptr[rid] + atomicAdd(&cur[rid], n);
+      }
     }
+    wave_copy_rows(tokens, so, raw, d0, len);
   }
 }
 // rows whose targets do not ascend strictly (Themisto promises no order): flen[r] = the row's length, 0 for rows in order
@@ -277,13 +381,13 @@ __global__ void k_rows_sorted_back(const uint64_t *keys, const uint32_t *keep, c
   }
   if (lost) atomicAdd(&ctr->shrunk, lost);
 }
-__global__ void k_rows_compact(const uint64_t *ptr, const uint32_t *raw, const uint32_t *cnt, const uint64_t *nptr,
-                               uint64_t n_ids, uint32_t *out) {
-  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_ids; r += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t *src = raw + ptr[r];
-    uint32_t *dst = out + nptr[r];
-    const uint32_t len = cnt[r];
-    for (uint32_t j = 0; j < len; ++j) dst[j] = src[j];
+__global__ __launch_bounds__(256) void k_rows_compact(const uint64_t *ptr, const uint32_t *raw, const uint32_t *cnt,
+                                                      const uint64_t *nptr, uint64_t n_ids, uint32_t *out) {
+  const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r0 = t0 & ~63ull; r0 < n_ids; r0 += step) {
+    const uint64_t r = r0 + (threadIdx.x & 63);
+    const bool in = r < n_ids;
+    wave_copy_rows(raw, in ? ptr[r] : 0, out, in ? nptr[r] : 0, in ? cnt[r] : 0u);
   }
 }
 
@@ -360,15 +464,21 @@ __global__ void k_ec_meta(const uint32_t *head, const uint64_t *eidx, const uint
     tlen[e] = (uint32_t)(ptr[rep + 1] - ptr[rep]);
   }
 }
-__global__ void k_ec_rows(const uint64_t *rptr, const uint32_t *ids, const uint64_t *ptr, const uint32_t *tgt,
-                          const uint64_t *tptr, uint64_t E, uint64_t *counts, uint32_t *out) {
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (uint64_t)gridDim.x * blockDim.x) {
-    counts[e] = rptr[e + 1] - rptr[e];
-    const uint32_t rep = ids[rptr[e]];
-    const uint32_t *src = tgt + ptr[rep];
-    uint32_t *dst = out + tptr[e];
-    const uint32_t len = (uint32_t)(tptr[e + 1] - tptr[e]);
-    for (uint32_t j = 0; j < len; ++j) dst[j] = src[j];
+__global__ __launch_bounds__(256) void k_ec_rows(const uint64_t *rptr, const uint32_t *ids, const uint64_t *ptr,
+                                                 const uint32_t *tgt, const uint64_t *tptr, uint64_t E, uint64_t *counts,
+                                                 uint32_t *out) {
+  const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e0 = t0 & ~63ull; e0 < E; e0 += step) {
+    const uint64_t e = e0 + (threadIdx.x & 63);
+    uint64_t so = 0, d0 = 0;
+    uint32_t len = 0;
+    if (e < E) {
+      counts[e] = rptr[e + 1] - rptr[e];
+      so = ptr[ids[rptr[e]]];
+      d0 = tptr[e];
+      len = (uint32_t)(tptr[e + 1] - d0);
+    }
+    wave_copy_rows(tgt, so, out, d0, len);
   }
 }
 
@@ -378,17 +488,80 @@ struct TextStager {
   static constexpr size_t kChunk = 64u << 20;
   void *buf[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};
+  hipStream_t copy = nullptr;  // the text travels on a stream of its own: the next strand's under this strand's kernels
   void ready() {
     for (int i = 0; i < 2; ++i) {
       if (!buf[i]) MSW_HIP(hipHostMalloc(&buf[i], kChunk, hipHostMallocDefault));
       if (!ev[i]) MSW_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
     }
+    if (!copy) MSW_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
   }
   ~TextStager() {
     for (int i = 0; i < 2; ++i) {
       if (buf[i]) (void)hipHostFree(buf[i]);
       if (ev[i]) (void)hipEventDestroy(ev[i]);
     }
+    if (copy) (void)hipStreamDestroy(copy);
+  }
+};
+
+// Device memory of the reader, kept on the handle between calls.  Two facts of the runtime shape it: hipFree waits for
+// EVERY stream of the device (also the copy stream that carries the next strand's text), and memory given back is
+// scrubbed by the driver before it is handed out again -- ~10 GB of temporaries at cfg3 stalled the allocations of
+// the likelihood build that follows by 0.2 s (tools/reader_probe.py: 0.230 s, 0.021 s after a pause).  So nothing is
+// freed while the handle lives: blocks handed back during a call become reusable from the NEXT call on (no ordering
+// question between the streams of one call), a second read of the same size allocates nothing, and msw_core_trim /
+// msw_core_destroy give the memory back.
+struct ReaderPool {
+  std::mutex mu;
+  std::multimap<size_t, void *> idle;        // reusable blocks by size
+  std::unordered_map<void *, size_t> live;   // blocks handed out (and those handed back during this call)
+  std::vector<void *> returned;
+  size_t bytes = 0;
+  void *take(size_t need) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = idle.lower_bound(need);
+      if (it != idle.end() && it->first <= need + need / 2 + (1u << 20)) {
+        void *p = it->second;
+        live[p] = it->first;
+        idle.erase(it);
+        return p;
+      }
+    }
+    void *p = nullptr;
+    MSW_HIP(hipMalloc(&p, need));
+    std::lock_guard<std::mutex> g(mu);
+    live[p] = need;
+    bytes += need;
+    return p;
+  }
+  void give(void *p) {
+    std::lock_guard<std::mutex> g(mu);
+    returned.push_back(p);
+  }
+  void recycle() {  // between calls: what was handed back may be handed out again
+    std::lock_guard<std::mutex> g(mu);
+    for (void *p : returned) {
+      auto it = live.find(p);
+      if (it == live.end()) continue;
+      idle.emplace(it->second, p);
+      live.erase(it);
+    }
+    returned.clear();
+  }
+  void trim() {  // every idle block back to the device
+    recycle();
+    std::lock_guard<std::mutex> g(mu);
+    for (auto &kv : idle) {
+      (void)hipFree(kv.second);
+      bytes -= kv.first;
+    }
+    idle.clear();
+  }
+  ~ReaderPool() {
+    trim();
+    for (auto &kv : live) (void)hipFree(kv.first);
   }
 };
 

@@ -97,7 +97,7 @@ class _LazyCounts:
         self._aln = aln
 
     def __array__(self, dtype=None, copy=None):
-        a = self._aln.arrays()["ec_counts"]
+        a = self._aln.ec_counts()
         return a.astype(dtype) if dtype is not None else a
 
 

@@ -178,3 +178,21 @@ def test_more_than_one_staging_chunk_and_likelihood_from_device_arrays(core, tmp
     assert (g1, shape1, h1) == (g2, core.shape(), core.layout_hash())
     np.testing.assert_array_equal(m1, m2)
     np.testing.assert_array_equal(logc1, logc2)
+
+
+def test_repeated_reads_reuse_the_handles_memory_and_trim_gives_it_back(core, tmp_path):
+    """The reader keeps its device temporaries on the handle (ReaderPool): a second and third read -- of the same files, of
+    smaller and of larger ones -- and a read after msw_core_trim all give the host reader's arrays."""
+    rng = np.random.default_rng(3)
+    files = {}
+    for name, n in (("mid", 4000), ("small", 300), ("large", 20000)):
+        p = tmp_path / f"{name}.txt"
+        p.write_text("\n".join(_lines(rng, n, 150)) + "\n")
+        files[name] = str(p)
+    host = {k: read_alignment([v], 150) for k, v in files.items()}
+    for name in ("mid", "mid", "small", "large", "mid"):
+        _equal(core.read_alignment([files[name]], 150).arrays(), host[name])
+    core.trim()
+    _equal(core.read_alignment([files["large"]], 150).arrays(), host["large"])
+    both = read_alignment([files["mid"], files["large"]], 150, "union")
+    _equal(core.read_alignment([files["mid"], files["large"]], 150, "union").arrays(), both)

@@ -1,0 +1,41 @@
+"""Developer probe: where the time between msw_alignment_read_device and msw_core_build_likelihood_aln goes.
+usage: python tools/reader_probe.py [reads] [groups] [sleep_s]"""
+import os, sys, time, tempfile, shutil
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from msweep_amd import synth
+from msweep_amd.core import Core
+from msweep_amd.likelihood import from_device_alignment
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+nap = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+tmp = tempfile.mkdtemp(prefix="msweep_probe_", dir=os.environ.get("TMPDIR", "/tmp"))
+try:
+    prob = synth.make_csr_problem(R, G, seed=2)
+    aln = synth.csr_to_targets(prob, shuffle=False)
+    E = len(prob["ec_counts"])
+    rng = np.random.default_rng(11)
+    ec_of = rng.permutation(np.repeat(np.arange(E, dtype=np.int64), prob["ec_counts"].astype(np.int64)))
+    f = [os.path.join(tmp, "r1.txt"), os.path.join(tmp, "r2.txt")]
+    for k, path in enumerate(f):
+        synth.write_themisto(path, ec_of, aln["ec_tptr"], aln["ec_targets"], chunk=1_000_000,
+                             extra=(rng, 0.1, aln["n_targets"]) if k else None)
+    nt = int(aln["n_targets"])
+    core = Core(0)
+    for rep in range(4):
+        t0 = time.perf_counter()
+        al = core.read_alignment(f, nt, "intersection")
+        t1 = time.perf_counter()
+        if nap:
+            time.sleep(nap)
+        t2 = time.perf_counter()
+        lik = from_device_alignment(core, al, aln["target_group"], prob["group_sizes"])
+        t3 = time.perf_counter()
+        res = core.solve(None, np.ones(lik.n_groups))
+        t4 = time.perf_counter()
+        del lik, al
+        t5 = time.perf_counter()
+        print(f"rep {rep}: read {t1 - t0:.3f} build {t3 - t2:.3f} solve {t4 - t3:.3f} del {t5 - t4:.3f}", flush=True)
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)
