@@ -196,3 +196,21 @@ def test_repeated_reads_reuse_the_handles_memory_and_trim_gives_it_back(core, tm
     _equal(core.read_alignment([files["large"]], 150).arrays(), host["large"])
     both = read_alignment([files["mid"], files["large"]], 150, "union")
     _equal(core.read_alignment([files["mid"], files["large"]], 150, "union").arrays(), both)
+
+
+def test_bench_e2e_leg_small():
+    """`bench.py --config e2e` at a small size: both readers run, the device reader's abundances.txt equals the host
+    reader's (asserted inside the leg), the line carries both sets of stages."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "e2e", "--reads", "200000", "--groups", "300"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["unit"] == "reads/s" and line["value"] > 0
+    for key in ("stages_s", "stages_first_pass_s"):
+        assert line[key]["ecs"] == line["host_reader"]["stages_s"]["ecs"] > 0
+        assert line[key]["iters"] == line["host_reader"]["stages_s"]["iters"]

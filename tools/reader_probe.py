@@ -1,5 +1,7 @@
-"""Developer probe: where the time between msw_alignment_read_device and msw_core_build_likelihood_aln goes.
-usage: python tools/reader_probe.py [reads] [groups] [sleep_s]"""
+"""Developer probe: where the time between msw_alignment_read_device and msw_core_build_likelihood_aln goes, and -- with
+a fourth argument `check` -- the device reader against the host reader at that size (inputs beyond 2^32 bytes of
+text per strand: 45 M reads).
+usage: python tools/reader_probe.py [reads] [groups] [sleep_s] [check]"""
 import os, sys, time, tempfile, shutil
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +12,7 @@ from msweep_amd.likelihood import from_device_alignment
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 nap = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+check = len(sys.argv) > 4 and sys.argv[4] == "check"
 tmp = tempfile.mkdtemp(prefix="msweep_probe_", dir=os.environ.get("TMPDIR", "/tmp"))
 try:
     prob = synth.make_csr_problem(R, G, seed=2)
@@ -22,7 +25,22 @@ try:
         synth.write_themisto(path, ec_of, aln["ec_tptr"], aln["ec_targets"], chunk=1_000_000,
                              extra=(rng, 0.1, aln["n_targets"]) if k else None)
     nt = int(aln["n_targets"])
+    print("text bytes per strand:", [os.path.getsize(x) for x in f], flush=True)
     core = Core(0)
+    if check:
+        from msweep_amd.core import read_alignment
+        t0 = time.perf_counter()
+        host = read_alignment(f, nt, "intersection")
+        t1 = time.perf_counter()
+        dev = core.read_alignment(f, nt, "intersection")
+        t2 = time.perf_counter()
+        d = dev.arrays()
+        t3 = time.perf_counter()
+        for k in ("ec_tptr", "ec_targets", "ec_counts", "ec_rptr", "ec_reads"):
+            assert np.array_equal(d[k], host[k]), k
+        print(f"check: host reader {t1 - t0:.2f} s, device reader {t2 - t1:.3f} s (+ {t3 - t2:.2f} s to copy the arrays out); "
+              f"{len(host['ec_counts'])} classes, {len(host['ec_targets'])} hits: equal", flush=True)
+        del host, dev, d
     for rep in range(4):
         t0 = time.perf_counter()
         al = core.read_alignment(f, nt, "intersection")
