@@ -1051,8 +1051,28 @@ int msw_alignment_read_device(msw_handle h, const char *const *paths, size_t n_p
     MSW_HIP(hipStreamSynchronize(h->stream));
     h->reader_pool.recycle();  // (blocks the previous read handed back: nothing of it is in flight any more)
     ReaderCtx cx(h->stream, h->n_cu, &h->text_stage, &h->reader_pool, h->device);
+    bool fits = true;
+    {  // ~5 bytes of device memory per byte of text (measured: 10 GB at cfg3's 2.09 GB, 45 GB at 9.5 GB): a text that
+       // would not fit beside what the device already holds goes to the host reader
+      uint64_t text = 0;
+      for (size_t i = 0; i < n_paths; ++i) {
+        struct stat sb;
+        if (paths[i] && stat(paths[i], &sb) == 0) text += (uint64_t)sb.st_size * (path_is_gzip(paths[i]) ? 8u : 1u);
+      }
+      size_t free_b = 0, total_b = 0;
+      MSW_HIP(hipMemGetInfo(&free_b, &total_b));
+      fits = 6 * text + (1ull << 30) <= (uint64_t)free_b + h->reader_pool.bytes;
+      if (getenv("MSWEEP_READER_FORCE_HOST")) fits = false;  // developer switch (tests): the host reader behind this entry
+    }
     try {
-      read_alignment_device(paths, n_paths, n_targets, merge_mode, cx, *a);
+      if (!fits) throw ReaderFallback{};
+      try {
+        read_alignment_device(paths, n_paths, n_targets, merge_mode, cx, *a);
+      } catch (const HipError &ex) {
+        if (!strstr(ex.what(), "out of memory")) throw;
+        (void)hipGetLastError();
+        throw ReaderFallback{};
+      }
     } catch (const ReaderFallback &) {
       // text the kernels do not judge: the host reader's outcome -- a result or the reference's message -- stands
       msw_alignment_t host = nullptr;

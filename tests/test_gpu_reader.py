@@ -214,3 +214,25 @@ def test_bench_e2e_leg_small():
     for key in ("stages_s", "stages_first_pass_s"):
         assert line[key]["ecs"] == line["host_reader"]["stages_s"]["ecs"] > 0
         assert line[key]["iters"] == line["host_reader"]["stages_s"]["iters"]
+
+
+def test_host_resident_alignment_behind_the_device_entry(core, tmp_path, monkeypatch):
+    """A text that would not fit the device goes to the host reader behind msw_alignment_read_device (forced here by the
+    developer switch); msw_core_build_likelihood_aln then takes the handle's HOST arrays: same likelihood."""
+    rng = np.random.default_rng(21)
+    n_targets, n_groups = 400, 20
+    p = tmp_path / "a.txt"
+    p.write_text("\n".join(_lines(rng, 6000, n_targets)) + "\n")
+    target_group = (np.arange(n_targets) % n_groups).astype(np.uint32)
+    group_sizes = np.bincount(target_group, minlength=n_groups).astype(np.uint64)
+    dev = core.read_alignment([str(p)], n_targets)
+    g1, m1, l1 = core.build_likelihood_aln(dev, target_group, group_sizes)
+    h1 = core.layout_hash()
+    monkeypatch.setenv("MSWEEP_READER_FORCE_HOST", "1")
+    host = core.read_alignment([str(p)], n_targets)
+    monkeypatch.delenv("MSWEEP_READER_FORCE_HOST")
+    _equal(host.arrays(), dev.arrays())
+    g2, m2, l2 = core.build_likelihood_aln(host, target_group, group_sizes)
+    assert (g1, h1) == (g2, core.layout_hash())
+    np.testing.assert_array_equal(l1, l2)
+    np.testing.assert_array_equal(host.ec_counts(), dev.ec_counts())
