@@ -31,6 +31,11 @@ never imports torch (round 5): the barriers around the timed region, the max ove
 abundances are collectives of the library's own RCCL communicator, whose unique id travels from rank 0 to the others
 through a unix socket of their own (class Star).
 
+At N = 1 the cfg3 line also carries `text_to_abundances` (--no-text skips it): the same reads written as two Themisto
+plaintext strands and taken from text to abundances.txt -- the reader on the device (msw_alignment_read_device), the
+likelihood build from its device-resident classes, the solve to --tol 1e-6 -- with the host reader on the same files
+beside it; `--config e2e` is the long form of that leg (Python mirror and gzip pair included).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -87,6 +92,8 @@ def parse():
                     help="cfg3/cfg4 generator: group sizes 1 + Poisson(9) (SURVEY 8d, default) or log-normal up to 400 as "
                          "real groupings have them (thousands of used table slots: the hybrid slot area)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-text", action="store_true",
+                    help="cfg3: skip the text_to_abundances leg (two Themisto strands written and read back: ~40 s)")
     ap.add_argument("--no-extras", "--no-prewarm", dest="no_extras", action="store_true",
                     help="skip the convergence solves and the EM leg that run BEFORE the timed region (and warm "
                          "the clocks: `prewarm` in the line) and the bootstrap leg after it")
@@ -856,6 +863,71 @@ def load_workload(a, core, shard, rank, world):
                        "mirror's table and log-count work")
         return out
 
+    def from_text():
+        """The same reads as two Themisto plaintext strands -> abundances.txt: the reader on the device + the build from
+        its device-resident classes + the solve to --tol 1e-6, beside the host reader on the same files (one pass).
+        The compact form of `bench.py --config e2e`."""
+        import io
+        import shutil
+        import tempfile
+        from msweep_amd.core import Core, read_alignment
+        from msweep_amd.likelihood import from_alignment, from_device_alignment
+        from msweep_amd.sample import PlainSample
+        tmp = tempfile.mkdtemp(prefix="msweep_text_", dir=os.environ.get("TMPDIR", "/tmp"))
+        try:
+            aln = synth.csr_to_targets(prob, shuffle=False)
+            rng = np.random.default_rng(11)
+            ec_of = rng.permutation(np.repeat(np.arange(E, dtype=np.int64), prob["ec_counts"].astype(np.int64)))
+            files, nbytes = [os.path.join(tmp, "reads_1.txt"), os.path.join(tmp, "reads_2.txt")], 0
+            for k, path in enumerate(files):
+                nbytes += synth.write_themisto(path, ec_of, aln["ec_tptr"], aln["ec_targets"], chunk=1_000_000,
+                                               extra=(rng, 0.1, aln["n_targets"]) if k else None)
+            n_targets, target_group, names = int(aln["n_targets"]), aln["target_group"], [f"g{g}" for g in range(G)]
+            del aln, ec_of
+
+            def run(c2, device_reader):
+                t1 = time.perf_counter()
+                if device_reader:
+                    al = c2.read_alignment(files, n_targets, "intersection")
+                    t2 = time.perf_counter()
+                    lk = from_device_alignment(c2, al, target_group, prob["group_sizes"])
+                    n_reads, n_aligned, n_ecs = al.n_reads, al.n_aligned, al.n_ecs
+                else:
+                    al = read_alignment(files, n_targets, "intersection")
+                    t2 = time.perf_counter()
+                    lk = from_alignment(c2, al["ec_tptr"], al["ec_targets"], target_group, prob["group_sizes"], al["ec_counts"],
+                                        download_log_counts=False)
+                    n_reads, n_aligned, n_ecs = al["n_reads"], len(al["ec_reads"]), len(al["ec_counts"])
+                t3 = time.perf_counter()
+                r = c2.solve(None, np.ones(lk.n_groups))
+                t4 = time.perf_counter()
+                out = io.StringIO()
+                smp = PlainSample(n_reads, n_aligned)
+                smp.store_abundances(r["theta"])
+                smp.write_abundances(names, out)
+                with open(os.path.join(tmp, "abundances.txt"), "w") as f:
+                    f.write(out.getvalue())
+                t5 = time.perf_counter()
+                return {"read_collapse_s": t2 - t1, "build_likelihood_s": t3 - t2, "solve_s": t4 - t3,
+                        "write_abundances_s": t5 - t4, "total_s": t5 - t1, "iters": int(r["iters"]), "ecs": int(n_ecs)}, out.getvalue()
+
+            with Core(core.device) as c2:
+                c2.set_pack_schedule(False)   # one solve: as the drivers
+                host, text_host = run(c2, False)
+                passes = [run(c2, True) for _ in range(3)]
+            best = min((x[0] for x in passes), key=lambda d: d["total_s"])
+            return {"seconds": best["total_s"], "reads_per_sec": a.reads / best["total_s"], "stages_s": best,
+                    "first_pass_s": passes[0][0], "host_reader": host, "text_bytes": nbytes,
+                    "same_abundances_txt": all(x[1] == text_host for x in passes),
+                    "what": "the workload's reads as two Themisto plaintext strands (--themisto-mode intersection) -> "
+                            "msw_alignment_read_device (text to HBM, parse / merge / hash / sort / classes as kernels) -> "
+                            "msw_core_build_likelihood_aln (classes read in device memory) -> msw_core_solve(--tol 1e-6) -> "
+                            "abundances.txt; best of three passes on one handle, first_pass_s = the first of them; "
+                            "host_reader = one pass of msw_alignment_read + msw_core_build_likelihood on the same files "
+                            "(page cache warm for both); `bench.py --config e2e` is the long form"}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
     if a.group_sizes == "diverse":
         return dict(E=E, G=G, nnz=nnz, logc=lik.log_counts(), w=prob["ec_counts"].astype(np.uint32), cpu=cpu, reads=a.reads,
                     first_theta=first_theta,
@@ -864,7 +936,7 @@ def load_workload(a, core, shard, rank, world):
                          f"{int(prob['group_sizes'].max())} here; thousands of used lookup-table slots -> index records + hybrid "
                          "slot area): synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB, fixed iteration count")
     return dict(E=E, G=G, nnz=nnz, logc=lik.log_counts(), w=prob["ec_counts"].astype(np.uint32), cpu=cpu, reads=a.reads,
-                first_theta=first_theta,
+                first_theta=first_theta, from_text=from_text if a.config == "cfg3" and not shard else None,
                 setup_s={"generate": t_gen, "set_csr": t_up},
                 desc="cfg3: synthetic 10M reads x 5k groups, CSR-of-ECs likelihood, RCG-VB (--algorithm rcggpu), "
                      "fixed iteration count" if a.config == "cfg3" else
@@ -1250,6 +1322,12 @@ def main():
                 line["time_to_first_theta"] = wl["first_theta"]()
             except Exception as ex:  # reporting only
                 line["time_to_first_theta"] = {"ms": None, "what": f"failed: {ex}"}
+        if wl.get("from_text") is not None and n_gpus == 1 and not a.no_extras and not a.no_text:
+            log("text -> abundances ...")
+            try:
+                line["text_to_abundances"] = wl["from_text"]()
+            except Exception as ex:  # reporting only
+                line["text_to_abundances"] = {"seconds": None, "what": f"failed: {ex}"}
         if em is not None:
             line["em_algorithm"] = em
         if em_float is not None:

@@ -236,3 +236,21 @@ def test_host_resident_alignment_behind_the_device_entry(core, tmp_path, monkeyp
     assert (g1, h1) == (g2, core.layout_hash())
     np.testing.assert_array_equal(l1, l2)
     np.testing.assert_array_equal(host.ec_counts(), dev.ec_counts())
+
+
+def test_default_bench_line_carries_text_to_abundances():
+    """The default (cfg3) line at a small size: `text_to_abundances` = the reads as Themisto text through the device
+    reader, the host reader beside it, the same abundances.txt."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "200000", "--groups", "300", "--steps", "5",
+                          "--warmup", "2", "--no-cpu-baseline", "--bootstrap-per-rank", "0"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    t = line["text_to_abundances"]
+    assert t["same_abundances_txt"] is True and t["seconds"] > 0
+    assert t["stages_s"]["ecs"] == t["host_reader"]["ecs"] > 0 and t["stages_s"]["iters"] == t["host_reader"]["iters"]

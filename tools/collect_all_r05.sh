@@ -17,9 +17,9 @@ case "${1:-1}" in
   MSWEEP_DENSE_COMPRESS=0 bash tools/collect_profiles.sh r05_cfg2_dense --config cfg2 > gpurun_out/r05_cfg2_dense.log 2>&1; echo "cfg2 dense rc=$?"
   ;;
 *)
-  MSWEEP_BUILD_TIMING=1 python3 bench.py --config cfg3 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r05_setup_cfg3.json 2> gpurun_out/r05_setup_cfg3.txt; echo "setup cfg3 rc=$?"
-  MSWEEP_BUILD_TIMING=1 python3 bench.py --config cfg5 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r05_setup_cfg5.json 2> gpurun_out/r05_setup_cfg5.txt; echo "setup cfg5 rc=$?"
+  MSWEEP_BUILD_TIMING=1 python3 bench.py --config cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-text > gpurun_out/r05_setup_cfg3.json 2> gpurun_out/r05_setup_cfg3.txt; echo "setup cfg3 rc=$?"
+  MSWEEP_BUILD_TIMING=1 python3 bench.py --config cfg5 --steps 5 --warmup 2 --no-cpu-baseline --no-text > gpurun_out/r05_setup_cfg5.json 2> gpurun_out/r05_setup_cfg5.txt; echo "setup cfg5 rc=$?"
   python3 tools/small_input_timing.py 100000 1000000 > gpurun_out/r05_small_inputs.txt 2>&1; echo "small rc=$?"
-  python3 bench.py --config e2e --no-cpu-baseline > gpurun_out/r05_e2e_bench_line.json 2> gpurun_out/r05_e2e.err; echo "e2e rc=$?"
+  python3 bench.py --config e2e --no-cpu-baseline --no-text > gpurun_out/r05_e2e_bench_line.json 2> gpurun_out/r05_e2e.err; echo "e2e rc=$?"
   ;;
 esac
