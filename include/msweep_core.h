@@ -314,6 +314,9 @@ void msw_alignment_destroy(msw_alignment_t a);
  * (msw_alignment_last_error / msw_last_error). */
 int msw_alignment_read_device(msw_handle h, const char *const *paths, size_t n_paths, size_t n_targets, int merge_mode,
                               msw_alignment_t *out);
+/* 1: the handle's arrays are device-resident (msw_alignment_read_device served the text with its kernels); 0: host
+ * arrays (msw_alignment_read, or the host parser behind the device entry). */
+int msw_alignment_on_device(msw_alignment_t a);
 /* msw_alignment_read_device keeps its device temporaries (~5 bytes per byte of text) on the handle between calls: a
  * repeated read allocates nothing, and nothing is freed in front of the likelihood build (memory given back is scrubbed
  * before it is handed out again: 0.2 s at 10 M reads).  msw_core_trim gives them back; msw_core_destroy does too. */

@@ -25,7 +25,7 @@ EXPORTS = [
     "msw_core_set_dense_logl", "msw_core_set_csr", "msw_core_build_likelihood",
     "msw_core_get_dense_logl", "msw_core_layout_hash", "msw_core_shape", "msw_alignment_read",
     "msw_alignment_shape", "msw_alignment_export", "msw_alignment_view", "msw_alignment_destroy", "msw_alignment_last_error",
-    "msw_alignment_read_device", "msw_core_build_likelihood_aln", "msw_core_trim", "msw_core_solve", "msw_core_prepare", "msw_core_run",
+    "msw_alignment_read_device", "msw_core_build_likelihood_aln", "msw_core_trim", "msw_alignment_on_device", "msw_core_solve", "msw_core_prepare", "msw_core_run",
     "msw_core_gamma",
     "msw_core_trace", "msw_core_set_trace_theta", "msw_core_bootstrap",
     "msw_core_resample_counts", "msw_core_set_profiling", "msw_core_last_timing",
@@ -156,6 +156,7 @@ def load_library():
     L.msw_alignment_export.argtypes = [vp, vp, vp, vp, vp, vp]
     L.msw_alignment_destroy.argtypes = [vp]
     L.msw_core_trim.argtypes = [vp]
+    L.msw_alignment_on_device.argtypes = [vp]
     L.msw_alignment_read_device.argtypes = [vp, C.POINTER(C.c_char_p), sz, sz, C.c_int, C.POINTER(vp)]
     L.msw_core_build_likelihood_aln.argtypes = [vp, vp, vp, sz, vp, sz, C.c_double, C.c_double, C.c_double, sz,
                                                 C.POINTER(sz), vp, vp]
@@ -220,6 +221,7 @@ class DeviceAlignment:
         self.n_ecs, self.n_reads, self.n_hits, self.n_aligned = ne.value, nr.value, nh.value, na.value
         self._arrays = None
         self._counts = None
+        self.on_device = bool(L.msw_alignment_on_device(h))   # False: the host parser took the text (its word is final)
 
     def ec_counts(self):
         """reads per class (uint64): the one array the drivers need on the host -- 8 bytes per class leave the device"""

@@ -67,6 +67,7 @@ def test_device_reader_equals_host_reader(core, tmp_path, mode, n_strands, flavo
         paths.append(str(p))
     host = read_alignment(paths, n_targets, mode)
     dev = core.read_alignment(paths, n_targets, mode)
+    assert dev.on_device   # served by the kernels, not by the host parser behind the entry
     assert (dev.n_ecs, dev.n_hits, dev.n_aligned, dev.n_reads) == (len(host["ec_counts"]), len(host["ec_targets"]),
                                                                   len(host["ec_reads"]), host["n_reads"])
     _equal(dev.arrays(), host)
@@ -91,8 +92,9 @@ def test_text_shapes_the_parser_takes(core, tmp_path):
         p = tmp_path / f"{name}.txt"
         p.write_bytes(text.encode())
         host = read_alignment([str(p)], n_targets)
-        dev = core.read_alignment([str(p)], n_targets).arrays()
-        _equal(dev, host)
+        dev = core.read_alignment([str(p)], n_targets)
+        assert dev.on_device, name
+        _equal(dev.arrays(), host)
 
 
 def test_empty_and_unaligned_files(core, tmp_path):
@@ -105,8 +107,9 @@ def test_empty_and_unaligned_files(core, tmp_path):
     for paths, mode in (([e], "intersection"), ([u], "intersection"), ([a, u], "intersection"), ([a, u], "union"),
                         ([a, e], "union"), ([e, a], "union"), ([a, e], "intersection")):
         host = read_alignment([str(x) for x in paths], 5, mode)
-        dev = core.read_alignment([str(x) for x in paths], 5, mode).arrays()
-        _equal(dev, host)
+        dev = core.read_alignment([str(x) for x in paths], 5, mode)
+        assert dev.on_device
+        _equal(dev.arrays(), host)
 
 
 def test_text_the_kernels_do_not_judge_goes_to_the_host_parser(core, tmp_path):
@@ -131,7 +134,9 @@ def test_text_the_kernels_do_not_judge_goes_to_the_host_parser(core, tmp_path):
     # accepted by the host parser although the kernels hand it over: leading zeros beyond ten digits
     zeros = tmp_path / "zeros.txt"
     zeros.write_text("0 00000000003 1\n1 2\n")
-    _equal(core.read_alignment([str(zeros)], 10).arrays(), read_alignment([str(zeros)], 10))
+    z = core.read_alignment([str(zeros)], 10)
+    assert not z.on_device
+    _equal(z.arrays(), read_alignment([str(zeros)], 10))
     with pytest.raises(MswError, match="themisto-mode"):
         core.read_alignment([str(good)], 10, "both")
 
@@ -144,7 +149,9 @@ def test_gzip_input(core, tmp_path):
     gz = tmp_path / "p.txt.gz"
     with gzip.open(gz, "wt") as f:
         f.write("\n".join(lines) + "\n")
-    _equal(core.read_alignment([str(gz)], 97).arrays(), read_alignment([str(plain)], 97))
+    dev = core.read_alignment([str(gz)], 97)   # (inflated on the host, parsed on the device)
+    assert dev.on_device
+    _equal(dev.arrays(), read_alignment([str(plain)], 97))
 
 
 def test_more_than_one_staging_chunk_and_likelihood_from_device_arrays(core, tmp_path):
@@ -168,6 +175,7 @@ def test_more_than_one_staging_chunk_and_likelihood_from_device_arrays(core, tmp
         paths.append(str(p))
     host = read_alignment(paths, n_targets, "intersection")
     aln = core.read_alignment(paths, n_targets, "intersection")
+    assert aln.on_device
     _equal(aln.arrays(), host)
     target_group = (np.arange(n_targets) % n_groups).astype(np.uint32)
     group_sizes = np.bincount(target_group, minlength=n_groups).astype(np.uint64)
@@ -231,6 +239,7 @@ def test_host_resident_alignment_behind_the_device_entry(core, tmp_path, monkeyp
     monkeypatch.setenv("MSWEEP_READER_FORCE_HOST", "1")
     host = core.read_alignment([str(p)], n_targets)
     monkeypatch.delenv("MSWEEP_READER_FORCE_HOST")
+    assert dev.on_device and not host.on_device
     _equal(host.arrays(), dev.arrays())
     g2, m2, l2 = core.build_likelihood_aln(host, target_group, group_sizes)
     assert (g1, h1) == (g2, core.layout_hash())
@@ -254,3 +263,48 @@ def test_default_bench_line_carries_text_to_abundances():
     t = line["text_to_abundances"]
     assert t["same_abundances_txt"] is True and t["seconds"] > 0
     assert t["stages_s"]["ecs"] == t["host_reader"]["ecs"] > 0 and t["stages_s"]["iters"] == t["host_reader"]["iters"]
+
+
+def test_fuzz_mutated_text(core, tmp_path):
+    """Random byte-level damage to small files: the device entry and the host reader end the same way -- the same five
+    arrays, or the same error message (the kernels hand anything they do not judge to the host parser; what they DO take
+    they must parse as the host does)."""
+    rng = np.random.default_rng(2024)
+    palette = [b" ", b"  ", b"\n", b"\r\n", b"\r", b"\t", b"x", b"-", b"+", b",", b"0", b"7", b"99", b"4294967295", b"4294967296",
+               b"00000000000", b"\n\n", b" \n", b"\x00", b"12345678901"]
+    n_targets = 64
+    n_ok = n_err = 0
+    served = {True: 0, False: 0}   # texts the kernels took / handed to the host parser (and it accepted)
+    p = tmp_path / "f.txt"
+    for case in range(3000):
+        # (one case in ten spans several 4 KB tiles of the text kernels)
+        lines = _lines(rng, int(rng.integers(200, 700)) if case % 10 == 0 else int(rng.integers(1, 40)), n_targets, dup_lines=bool(rng.integers(0, 2)), shuffle=bool(rng.integers(0, 2)))
+        text = bytearray(("\n".join(lines) + ("\n" if rng.random() < 0.8 else "")).encode())
+        for _ in range(int(rng.integers(0, 4))):
+            at = int(rng.integers(0, len(text) + 1))
+            what = int(rng.integers(0, 3))
+            if what == 0:
+                text[at:at] = palette[int(rng.integers(0, len(palette)))]
+            elif what == 1 and len(text):
+                del text[min(at, len(text) - 1)]
+            elif len(text):
+                text[min(at, len(text) - 1)] = palette[int(rng.integers(0, len(palette)))][0]
+        p.write_bytes(bytes(text))
+        results = []
+        def on_device_entry():
+            al = core.read_alignment([str(p)], n_targets)
+            served[al.on_device] += 1
+            return al.arrays()
+        for fn in (lambda: read_alignment([str(p)], n_targets), on_device_entry):
+            try:
+                results.append(("ok", fn()))
+            except MswError as ex:
+                results.append(("err", str(ex)))
+        assert results[0][0] == results[1][0], (case, bytes(text), results[0], results[1])
+        if results[0][0] == "ok":
+            _equal(results[1][1], results[0][1])
+            n_ok += 1
+        else:
+            assert results[0][1] == results[1][1], (case, bytes(text))
+            n_err += 1
+    assert n_ok > 300 and n_err > 300 and served[True] > 300, (n_ok, n_err, served)
