@@ -1061,7 +1061,14 @@ int msw_alignment_read_device(msw_handle h, const char *const *paths, size_t n_p
       }
       size_t free_b = 0, total_b = 0;
       MSW_HIP(hipMemGetInfo(&free_b, &total_b));
-      fits = 6 * text + (1ull << 30) <= (uint64_t)free_b + h->reader_pool.bytes;
+      // (what earlier reads left idle on the handle counts as room; when it would be needed as FRESH memory -- a text of
+      // another size class -- it goes back to the device first)
+      const uint64_t need = 6 * text + (1ull << 30);
+      if (need > (uint64_t)free_b && h->reader_pool.idle_bytes()) {
+        h->reader_pool.trim();
+        MSW_HIP(hipMemGetInfo(&free_b, &total_b));
+      }
+      fits = need <= (uint64_t)free_b + h->reader_pool.idle_bytes();
       if (getenv("MSWEEP_READER_FORCE_HOST")) fits = false;  // developer switch (tests): the host reader behind this entry
     }
     try {

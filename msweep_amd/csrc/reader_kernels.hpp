@@ -15,6 +15,8 @@
 #pragma once
 #include "common.hpp"
 
+#include <cstdlib>
+
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -483,15 +485,21 @@ __global__ __launch_bounds__(256) void k_ec_rows(const uint64_t *rptr, const uin
 }
 
 // ---- host: pinned staging of the text on its way to the device (host_reader.inc) ------------------------------------------
-// two pinned staging buffers + their events: owned by the handle (pinning 2 x 64 MB costs ~20 ms: once per handle)
+// two pinned staging buffers + their events: owned by the handle (pinning costs ~0.4 ms per MB, once per handle: 2 x 32 MB)
 struct TextStager {
-  static constexpr size_t kChunk = 64u << 20;
+  // MSWEEP_READER_CHUNK_MB (developer switch): bytes per staging buffer; pinning them is the first call's fixed cost
+  size_t chunk = 0;
   void *buf[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipStream_t copy = nullptr;  // the text travels on a stream of its own: the next strand's under this strand's kernels
   void ready() {
+    if (!chunk) {
+      const char *e = getenv("MSWEEP_READER_CHUNK_MB");
+      const long mb = e ? atol(e) : 0;
+      chunk = (size_t)(mb >= 1 && mb <= 1024 ? mb : 32) << 20;  // (profiles/r05_reader_chunk_ab.txt: 16-256 MB steady alike, pinning 0.4 ms per MB)
+    }
     for (int i = 0; i < 2; ++i) {
-      if (!buf[i]) MSW_HIP(hipHostMalloc(&buf[i], kChunk, hipHostMallocDefault));
+      if (!buf[i]) MSW_HIP(hipHostMalloc(&buf[i], chunk, hipHostMallocDefault));
       if (!ev[i]) MSW_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
     }
     if (!copy) MSW_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
@@ -549,6 +557,12 @@ struct ReaderPool {
       live.erase(it);
     }
     returned.clear();
+  }
+  size_t idle_bytes() {
+    std::lock_guard<std::mutex> g(mu);
+    size_t b = 0;
+    for (auto &kv : idle) b += kv.first;
+    return b;
   }
   void trim() {  // every idle block back to the device
     recycle();

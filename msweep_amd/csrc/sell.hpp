@@ -61,7 +61,7 @@ constexpr uint32_t kSentinels = 64;  // one sentinel group per lane: padding nev
 #define MSW_REG_CELLS 16
 #endif
 constexpr int kRowsPerLane = MSW_REG_CELLS;
-static_assert(kRowsPerLane == 16 || kRowsPerLane == 8, "slices of at most 16 or 8 rows");
+static_assert(kRowsPerLane == 16 || kRowsPerLane == 12 || kRowsPerLane == 8, "slices of at most 16, 12 or 8 rows");
 constexpr int kSliceClasses = 7;
 constexpr uint32_t kMaxLgm = kSliceClasses - 1;  // class c: 2^(kMaxLgm - c) lanes per EC
 struct SliceClasses {

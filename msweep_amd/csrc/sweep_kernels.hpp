@@ -492,9 +492,11 @@ __global__ __launch_bounds__(pass_threads_A<ENC>()) void k_passA(const Scalars *
         case 2: fixed(b, std::integral_constant<int, 2>{}, std::false_type{}); break;
         case 4: fixed(b, std::integral_constant<int, 4>{}, std::false_type{}); break;
         case 6: fixed(b, std::integral_constant<int, 6>{}, std::false_type{}); break;
-#if MSW_REG_CELLS == 16
+#if MSW_REG_CELLS >= 12
         case 8: fixed(b, std::integral_constant<int, 8>{}, std::false_type{}); break;
         case 10: fixed(b, std::integral_constant<int, 10>{}, std::false_type{}); break;
+#endif
+#if MSW_REG_CELLS == 16
         case 12: fixed(b, std::integral_constant<int, 12>{}, std::false_type{}); break;
         case 14: fixed(b, std::integral_constant<int, 14>{}, std::false_type{}); break;
 #endif

@@ -13,17 +13,29 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 nap = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 check = len(sys.argv) > 4 and sys.argv[4] == "check"
-tmp = tempfile.mkdtemp(prefix="msweep_probe_", dir=os.environ.get("TMPDIR", "/tmp"))
+# MSWEEP_PROBE_DIR: keep the generated strands there (several runs of the probe -- e.g. over MSWEEP_READER_CHUNK_MB -- in
+# one GPU job without generating the text again)
+keep = os.environ.get("MSWEEP_PROBE_DIR")
+tmp = keep or tempfile.mkdtemp(prefix="msweep_probe_", dir=os.environ.get("TMPDIR", "/tmp"))
+os.makedirs(tmp, exist_ok=True)
 try:
-    prob = synth.make_csr_problem(R, G, seed=2)
-    aln = synth.csr_to_targets(prob, shuffle=False)
-    E = len(prob["ec_counts"])
-    rng = np.random.default_rng(11)
-    ec_of = rng.permutation(np.repeat(np.arange(E, dtype=np.int64), prob["ec_counts"].astype(np.int64)))
     f = [os.path.join(tmp, "r1.txt"), os.path.join(tmp, "r2.txt")]
-    for k, path in enumerate(f):
-        synth.write_themisto(path, ec_of, aln["ec_tptr"], aln["ec_targets"], chunk=1_000_000,
-                             extra=(rng, 0.1, aln["n_targets"]) if k else None)
+    meta = os.path.join(tmp, f"meta_{R}_{G}.npz")
+    if keep and os.path.exists(meta):
+        m = np.load(meta)
+        aln = {"n_targets": int(m["n_targets"]), "target_group": m["target_group"]}
+        prob = {"group_sizes": m["group_sizes"]}
+    else:
+        prob = synth.make_csr_problem(R, G, seed=2)
+        aln = synth.csr_to_targets(prob, shuffle=False)
+        E = len(prob["ec_counts"])
+        rng = np.random.default_rng(11)
+        ec_of = rng.permutation(np.repeat(np.arange(E, dtype=np.int64), prob["ec_counts"].astype(np.int64)))
+        for k, path in enumerate(f):
+            synth.write_themisto(path, ec_of, aln["ec_tptr"], aln["ec_targets"], chunk=1_000_000,
+                                 extra=(rng, 0.1, aln["n_targets"]) if k else None)
+        if keep:
+            np.savez(meta, n_targets=aln["n_targets"], target_group=aln["target_group"], group_sizes=prob["group_sizes"])
     nt = int(aln["n_targets"])
     print("text bytes per strand:", [os.path.getsize(x) for x in f], flush=True)
     core = Core(0)
@@ -56,4 +68,5 @@ try:
         t5 = time.perf_counter()
         print(f"rep {rep}: read {t1 - t0:.3f} build {t3 - t2:.3f} solve {t4 - t3:.3f} del {t5 - t4:.3f}", flush=True)
 finally:
-    shutil.rmtree(tmp, ignore_errors=True)
+    if not keep:
+        shutil.rmtree(tmp, ignore_errors=True)
