@@ -308,3 +308,37 @@ def test_fuzz_mutated_text(core, tmp_path):
             assert results[0][1] == results[1][1], (case, bytes(text))
             n_err += 1
     assert n_ok > 300 and n_err > 300 and served[True] > 300, (n_ok, n_err, served)
+
+
+@pytest.mark.parametrize("mode,n_strands", [("intersection", 1), ("intersection", 2), ("union", 2)])
+def test_device_reader_against_the_python_mirror_of_the_reference(core, tmp_path, mode, n_strands):
+    """The device reader held directly against msweep_amd/alignment.py -- the line-by-line mirror of
+    include/mSWEEP_alignment.hpp:54-215 -- not only against the host reader: classes in ascending order of the
+    reference's hash, their reads, counts and target sets."""
+    from msweep_amd.alignment import Alignment, ec_hash
+    rng = np.random.default_rng(70 + n_strands + len(mode))
+    n_targets, n_reads = 37, 700
+    paths = []
+    for s in range(n_strands):
+        p = tmp_path / f"strand_{s}.txt"
+        p.write_text("\n".join(_lines(rng, n_reads, n_targets, dup_lines=(s == 0))) + "\n")
+        paths.append(str(p))
+    ref = Alignment(n_targets)
+    streams = [open(p) for p in paths]
+    ref.read(mode, streams)
+    for s in streams:
+        s.close()
+    ref._reads = {r: t for r, t in ref._reads.items() if r < ref.n_queries}   # ids below the last strand's line count (:148)
+    ref.collapse()
+    dev = core.read_alignment(paths, n_targets, mode)
+    assert dev.on_device
+    got = dev.arrays()
+    assert got["n_reads"] == ref.n_queries
+    np.testing.assert_array_equal(got["ec_counts"], ref.ec_counts)
+    np.testing.assert_array_equal(got["ec_tptr"], ref.ec_tptr)
+    np.testing.assert_array_equal(got["ec_targets"], ref.ec_targets)
+    rp = got["ec_rptr"].astype(int)
+    assert [got["ec_reads"][rp[i]:rp[i + 1]].tolist() for i in range(len(rp) - 1)] == ref.ec_read_ids
+    tp = got["ec_tptr"].astype(int)
+    hashes = [ec_hash(got["ec_targets"][tp[i]:tp[i + 1]].tolist()) for i in range(len(tp) - 1)]
+    assert hashes == sorted(hashes) and len(set(hashes)) == len(hashes)
