@@ -394,43 +394,100 @@ __global__ __launch_bounds__(256) void k_rows_compact(const uint64_t *ptr, const
 }
 
 // ---- paired-end merge (include/mSWEEP_alignment.hpp:123-133): intersection / union of the two strands' rows ----------
-// WRITE = false: len[i] = length of read i's merged row; true: the row written at optr[i]
-template <bool WRITE>
-__global__ void k_merge_rows(const uint64_t *aptr, const uint32_t *atgt, uint64_t na, const uint64_t *bptr,
-                             const uint32_t *btgt, uint64_t nb, uint64_t n, int intersect, uint32_t *len,
-                             const uint64_t *optr, uint32_t *out) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    uint64_t a = 0, ae = 0, b = 0, be = 0;
-    if (i < na) a = aptr[i], ae = aptr[i + 1];
-    if (i < nb) b = bptr[i], be = bptr[i + 1];
-    uint32_t *dst = WRITE ? out + optr[i] : nullptr;
-    uint32_t k = 0;
-    while (a < ae && b < be) {
-      const uint32_t x = atgt[a], y = btgt[b];
+// WRITE = false: len[i] = length of read i's merged row; true: the row written at optr[i].
+// One merge loop per read -- but a lane walking its own two rows in memory touches, with its 63 neighbours, 64 cache lines
+// per load.  A wavefront therefore stages the rows of its 64 reads in LDS (wave_copy_rows: whole lines), every lane merges
+// its read there, and the merged rows -- one contiguous range of the output -- go back in whole lines.  64 reads whose rows
+// exceed the staging area (kMergeCap targets per strand) merge in memory.
+constexpr int kMergeCap = 1280;
+constexpr int kMergeThreads = 128;
+template <bool WRITE, class GetA, class GetB, class Put>
+__device__ __forceinline__ uint32_t merge_one(uint32_t la, uint32_t lb, bool intersect, GetA geta, GetB getb, Put put) {
+  uint32_t a = 0, b = 0, k = 0;
+  if (la && lb) {
+    uint32_t x = geta(0), y = getb(0);
+    for (;;) {
       if (x == y) {
-        if (WRITE) dst[k] = x;
+        if (WRITE) put(k, x);
         ++k, ++a, ++b;
+        if (a == la || b == lb) break;
+        x = geta(a), y = getb(b);
       } else if (x < y) {
         if (!intersect) {
-          if (WRITE) dst[k] = x;
+          if (WRITE) put(k, x);
           ++k;
         }
-        ++a;
+        if (++a == la) break;
+        x = geta(a);
       } else {
         if (!intersect) {
-          if (WRITE) dst[k] = y;
+          if (WRITE) put(k, y);
           ++k;
         }
-        ++b;
+        if (++b == lb) break;
+        y = getb(b);
       }
     }
-    if (!intersect) {
-      for (; a < ae; ++a, ++k)
-        if (WRITE) dst[k] = atgt[a];
-      for (; b < be; ++b, ++k)
-        if (WRITE) dst[k] = btgt[b];
+  }
+  if (!intersect) {
+    for (; a < la; ++a, ++k)
+      if (WRITE) put(k, geta(a));
+    for (; b < lb; ++b, ++k)
+      if (WRITE) put(k, getb(b));
+  }
+  return k;
+}
+template <bool WRITE>
+__global__ __launch_bounds__(kMergeThreads) void k_merge_rows(const uint64_t *aptr, const uint32_t *atgt, uint64_t na,
+                                                              const uint64_t *bptr, const uint32_t *btgt, uint64_t nb,
+                                                              uint64_t n, int intersect, uint32_t *len, const uint64_t *optr,
+                                                              uint32_t *out) {
+  __shared__ uint32_t sh[kMergeThreads / 64][(WRITE ? 4 : 2) * kMergeCap];
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t *sa = sh[threadIdx.x >> 6], *sb = sa + kMergeCap, *so = sa + 2 * kMergeCap;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t i0 = wave * 64; i0 < n; i0 += n_waves * 64) {
+    const uint64_t i = i0 + lane;
+    uint64_t a0 = 0, b0 = 0;
+    uint32_t la = 0, lb = 0;
+    if (i < n && i < na) a0 = aptr[i], la = (uint32_t)(aptr[i + 1] - a0);
+    if (i < n && i < nb) b0 = bptr[i], lb = (uint32_t)(bptr[i + 1] - b0);
+    uint32_t ea = la, eb = lb;  // inclusive prefix sums over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t ua = __shfl_up(ea, o), ub = __shfl_up(eb, o);
+      if (lane >= (uint32_t)o) ea += ua, eb += ub;
     }
-    if (!WRITE) len[i] = k;
+    const uint32_t ta = __shfl(ea, 63), tb = __shfl(eb, 63);
+    uint32_t k;
+    if (ta <= (uint32_t)kMergeCap && tb <= (uint32_t)kMergeCap) {  // (wave-uniform)
+      const uint32_t oa = ea - la, ob = eb - lb;
+      wave_copy_rows(atgt, a0, sa, oa, la);
+      wave_copy_rows(btgt, b0, sb, ob, lb);
+      // (the rows a lane merges were written by other lanes of its wavefront)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const uint64_t o_first = WRITE ? optr[i0] : 0;
+      const uint32_t oo = WRITE && i < n ? (uint32_t)(optr[i] - o_first) : 0u;
+      k = merge_one<WRITE>(la, lb, intersect != 0, [&](uint32_t j) { return sa[oa + j]; }, [&](uint32_t j) { return sb[ob + j]; },
+                           [&](uint32_t j, uint32_t v) { so[oo + j] = v; });
+      if (WRITE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint64_t i1 = i0 + 64 < n ? i0 + 64 : n;
+        const uint32_t total = (uint32_t)(optr[i1] - o_first);
+        for (uint32_t e = lane; e < total; e += 64) out[o_first + e] = so[e];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the staging area is written again in the next round)
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      uint32_t *dst = WRITE && i < n ? out + optr[i] : nullptr;
+      k = merge_one<WRITE>(la, lb, intersect != 0, [&](uint32_t j) { return atgt[a0 + j]; }, [&](uint32_t j) { return btgt[b0 + j]; },
+                           [&](uint32_t j, uint32_t v) { dst[j] = v; });
+    }
+    if (!WRITE && i < n) len[i] = k;
   }
 }
 

@@ -342,3 +342,28 @@ def test_device_reader_against_the_python_mirror_of_the_reference(core, tmp_path
     tp = got["ec_tptr"].astype(int)
     hashes = [ec_hash(got["ec_targets"][tp[i]:tp[i + 1]].tolist()) for i in range(len(tp) - 1)]
     assert hashes == sorted(hashes) and len(set(hashes)) == len(hashes)
+
+
+@pytest.mark.parametrize("mode", ["intersection", "union"])
+def test_merge_of_rows_beyond_the_staging_area(core, tmp_path, mode):
+    """Paired-end merge: wavefronts whose 64 reads fit the LDS staging area (kMergeCap targets per strand) beside
+    wavefronts whose rows do not (reads of ~2000 targets: merged in memory), in one input."""
+    rng = np.random.default_rng(31 + len(mode))
+    n_targets, n_reads = 3000, 1000
+    paths = []
+    for s in range(2):
+        lines = []
+        for r in range(n_reads):
+            if r % 97 == 5:
+                t = rng.choice(n_targets, int(rng.integers(1500, 2500)), replace=False)
+            elif r % 13 == 0:
+                t = rng.choice(n_targets, int(rng.integers(20, 60)), replace=False)
+            else:
+                t = rng.choice(n_targets, int(rng.integers(0, 9)), replace=False)
+            lines.append(f"{r}" + "".join(f" {int(x)}" for x in t))
+        p = tmp_path / f"s{s}.txt"
+        p.write_text("\n".join(lines) + "\n")
+        paths.append(str(p))
+    dev = core.read_alignment(paths, n_targets, mode)
+    assert dev.on_device
+    _equal(dev.arrays(), read_alignment(paths, n_targets, mode))
