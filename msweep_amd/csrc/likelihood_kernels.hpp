@@ -144,15 +144,23 @@ __device__ __forceinline__ void sort16(uint32_t (&v)[16]) {
   }
 }
 
-// append `id` to a list for every lane with `want` set: one atomic per wavefront
-__device__ __forceinline__ void wave_append(bool want, uint32_t id, uint32_t *list, uint32_t *counter) {
+// append `id` to a list for every lane with `want` set, at *at (wave-uniform: the wavefront's own range of the list,
+// reserved with ONE atomic per wavefront and kernel -- an atomic per round, 146 k of them on one word at cfg3, queued in
+// L2 for as long as the rest of the kernel took)
+__device__ __forceinline__ void wave_append_at(bool want, uint32_t id, uint32_t *list, uint32_t &at) {
   const unsigned long long m = __ballot(want);
   if (m == 0) return;
-  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+  const int lane = threadIdx.x & 63;
+  if (want) list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = id;
+  at += (uint32_t)__popcll(m);
+}
+// the wavefront's range of a list: `mine` = entries this LANE will append over the whole kernel
+__device__ __forceinline__ uint32_t wave_reserve(uint32_t mine, uint32_t *counter) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
   uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-  base = (uint32_t)__shfl((int)base, leader, 64);
-  if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = id;
+  if ((threadIdx.x & 63) == 0 && mine) base = atomicAdd(counter, mine);
+  return (uint32_t)__shfl((int)base, 0, 64);
 }
 
 template <bool EMIT>
@@ -162,6 +170,21 @@ __global__ __launch_bounds__(256) void k_ec_groups_thread(const uint64_t *tptr, 
                                                          uint32_t *out_cnt, uint32_t *mid_ids, uint32_t *long_ids,
                                                          uint32_t *ctr) {
   const uint32_t stride = gridDim.x * blockDim.x;
+  [[maybe_unused]] uint32_t at_mid = 0, at_long = 0;
+  if (!EMIT) {  // the lengths of the wavefront's ECs once more, up front: where its entries of the two lists go
+    uint32_t n_mid = 0, n_long = 0;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < E; i0 += stride) {
+      const uint32_t i = i0 + threadIdx.x;
+      if (i < E) {
+        const uint64_t b = tptr[i], e = tptr[i + 1];
+        const uint64_t n64 = (e < b || e > ntot) ? 0 : e - b;
+        n_mid += n64 > kEcThreadMax && n64 <= kEcWaveMax;
+        n_long += n64 > kEcWaveMax;
+      }
+    }
+    at_mid = wave_reserve(n_mid, &ctr[kCtrMid]);
+    at_long = wave_reserve(n_long, &ctr[kCtrLong]);
+  }
   // (every lane of a wavefront runs the same number of rounds: the list appends are wave operations)
   for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < E; i0 += stride) {
     const uint32_t i = i0 + threadIdx.x;
@@ -172,8 +195,8 @@ __global__ __launch_bounds__(256) void k_ec_groups_thread(const uint64_t *tptr, 
     const uint64_t n64 = broken ? 0 : e - b;
     if (!EMIT) {
       if (broken) atomicOr(&ctr[kCtrBad], kBadTptr);
-      wave_append(in && n64 > kEcThreadMax && n64 <= kEcWaveMax, i, mid_ids, &ctr[kCtrMid]);
-      wave_append(in && n64 > kEcWaveMax, i, long_ids, &ctr[kCtrLong]);
+      wave_append_at(in && n64 > kEcThreadMax && n64 <= kEcWaveMax, i, mid_ids, at_mid);
+      wave_append_at(in && n64 > kEcWaveMax, i, long_ids, at_long);
       if (in && n64 == 0) nd[i] = 0;
     }
     if (!in || n64 == 0 || n64 > kEcThreadMax) continue;
