@@ -543,30 +543,41 @@ __global__ __launch_bounds__(256) void k_ec_rows(const uint64_t *rptr, const uin
 }
 
 // ---- host: pinned staging of the text on its way to the device (host_reader.inc) ------------------------------------------
-// two pinned staging buffers + their events: owned by the handle (pinning costs ~0.4 ms per MB, once per handle: 2 x 32 MB)
+// Every reader thread streams its own interleaved share of the file -- blocks k, k + T, k + 2 T, ... -- through two
+// pinned sub-buffers of its own: pread, hipMemcpyAsync, the next block into the other sub-buffer while this one
+// travels.  No meeting point between the threads (a gang that filled ONE staging chunk together and was started per
+// chunk paid ~0.3 ms of thread start-up per 32 MB).  Owned by the handle: pinning costs ~0.4 ms per MB, once.
 struct TextStager {
-  // MSWEEP_READER_CHUNK_MB (developer switch): bytes per staging buffer; pinning them is the first call's fixed cost
-  size_t chunk = 0;
-  void *buf[2] = {nullptr, nullptr};
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  hipStream_t copy = nullptr;  // the text travels on a stream of its own: the next strand's under this strand's kernels
-  void ready() {
-    if (!chunk) {
-      const char *e = getenv("MSWEEP_READER_CHUNK_MB");
+  size_t block = 0, threads = 0;   // bytes per sub-buffer (MSWEEP_READER_BLOCK_MB, developer switch), threads it is laid out for
+  void *pinned = nullptr;          // 2 * threads * block bytes
+  std::vector<hipEvent_t> ev;      // [2 * threads]: the copy that last read a sub-buffer
+  hipStream_t copy = nullptr;      // the text travels on a stream of its own: the next strand's under this strand's kernels
+  void ready(size_t T) {
+    if (!block) {
+      const char *e = getenv("MSWEEP_READER_BLOCK_MB");
       const long mb = e ? atol(e) : 0;
-      chunk = (size_t)(mb >= 1 && mb <= 1024 ? mb : 32) << 20;  // (profiles/r05_reader_chunk_ab.txt: 16-256 MB steady alike, pinning 0.4 ms per MB)
+      block = (size_t)(mb >= 1 && mb <= 256 ? mb : 4) << 20;  // (1-2 MB: the fixed cost per copy shows; 4-8 MB alike)
     }
-    for (int i = 0; i < 2; ++i) {
-      if (!buf[i]) MSW_HIP(hipHostMalloc(&buf[i], chunk, hipHostMallocDefault));
-      if (!ev[i]) MSW_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    if (T > threads) {
+      release();
+      MSW_HIP(hipHostMalloc(&pinned, 2 * T * block, hipHostMallocDefault));
+      ev.assign(2 * T, nullptr);
+      for (auto &e : ev) MSW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      threads = T;
     }
     if (!copy) MSW_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
   }
+  char *sub(size_t thread, int slot) const { return static_cast<char *>(pinned) + (2 * thread + slot) * block; }
+  void release() {
+    if (pinned) (void)hipHostFree(pinned);
+    for (auto e : ev)
+      if (e) (void)hipEventDestroy(e);
+    pinned = nullptr;
+    ev.clear();
+    threads = 0;
+  }
   ~TextStager() {
-    for (int i = 0; i < 2; ++i) {
-      if (buf[i]) (void)hipHostFree(buf[i]);
-      if (ev[i]) (void)hipEventDestroy(ev[i]);
-    }
+    release();
     if (copy) (void)hipStreamDestroy(copy);
   }
 };
