@@ -143,6 +143,42 @@ class DeviceLikelihood {
     mask_.assign(mask.begin(), mask.end());
     built_ = true;
   }
+  // The same from the Themisto plaintext files themselves, ON THE DEVICE: the reader as kernels
+  // (msw_alignment_read_device: text -> equivalence classes in device memory) and the build from its resident arrays
+  // (msw_core_build_likelihood_aln) -- Alignment::read + collapse + ConstructAdaptiveLikelihood
+  // (src/mSWEEP.cpp:324-346) without the pseudoalignment crossing PCIe twice.  Afterwards ec_counts() holds the reads
+  // per class (totals, bootstrap weights) and n_reads() / n_aligned() what Alignment::n_reads() and the sum of the
+  // counts are.  Text the kernels do not judge goes through the host parser: the reference's messages.
+  void build_from_files(const std::vector<std::string> &paths, bool union_mode, const std::vector<uint32_t> &target_group,
+                        const std::vector<uint64_t> &group_sizes, double q, double e, size_t min_hits, double zero_inflation) {
+    std::vector<const char *> c;
+    for (const auto &p : paths) c.push_back(p.c_str());
+    msw_alignment_t aln = nullptr;
+    if (msw_alignment_read_device(h_, c.data(), c.size(), target_group.size(), union_mode ? MSW_MERGE_UNION : MSW_MERGE_INTERSECTION,
+                                  &aln))
+      throw std::runtime_error(msw_alignment_last_error());
+    struct Guard {
+      msw_alignment_t a;
+      ~Guard() { msw_alignment_destroy(a); }
+    } guard{aln};
+    size_t E = 0, hits = 0;
+    msw_alignment_shape(aln, &E, &n_reads_, &hits, &n_aligned_);
+    if (E == 0) throw std::runtime_error("no read aligned against the reference");
+    ec_counts_.assign(E, 0);
+    if (msw_alignment_export(aln, nullptr, nullptr, ec_counts_.data(), nullptr, nullptr))
+      throw std::runtime_error("msw_alignment_export failed");
+    const size_t G = group_sizes.size();
+    std::vector<uint8_t> mask(G, 0);
+    logc_.assign(E, 0.0);
+    size_t kept = 0;
+    check(h_, msw_core_build_likelihood_aln(h_, aln, target_group.data(), target_group.size(), group_sizes.data(), G, q, e,
+                                            zero_inflation, min_hits, &kept, mask.data(), logc_.data()));
+    mask_.assign(mask.begin(), mask.end());
+    built_ = true;
+  }
+  const std::vector<uint64_t> &ec_counts() const { return ec_counts_; }   // reads per class (build_from_files)
+  size_t n_reads() const { return n_reads_; }
+  size_t n_aligned() const { return n_aligned_; }
   const std::vector<double> &log_counts() const { return logc_; }          // Likelihood::log_counts()
   const std::vector<bool> &groups_considered() const { return mask_; }     // Likelihood::groups_considered()
   bool built_on_device() const { return built_; }
@@ -160,6 +196,8 @@ class DeviceLikelihood {
  private:
   msw_handle h_ = nullptr;
   std::vector<double> logc_;
+  std::vector<uint64_t> ec_counts_;
+  size_t n_reads_ = 0, n_aligned_ = 0;
   std::vector<bool> mask_;
   bool built_ = false;
 };

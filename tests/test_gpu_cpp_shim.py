@@ -109,6 +109,40 @@ def test_device_likelihood_build_and_accessors(device_likelihood_binary, gpu_cor
     np.testing.assert_array_equal(np.array(out["theta"].split(), float), res["theta"])
 
 
+@pytest.mark.parametrize("mode", ["intersection", "union"])
+def test_device_likelihood_from_themisto_files(device_likelihood_binary, gpu_core, tmp_path, mode):
+    """msw::DeviceLikelihood::build_from_files -- the reader on the device + the build from its resident classes, the C++
+    face of Alignment::read + collapse + ConstructAdaptiveLikelihood -- against the Python mirror of the same entry
+    points on the same two strands."""
+    from msweep_amd import synth
+    from msweep_amd.likelihood import from_device_alignment
+    p = synth.make_csr_problem(4000, 15, seed=62, max_other=3, theta_support=9)
+    aln = synth.csr_to_targets(p)
+    E = len(p["ec_counts"])
+    rng = np.random.default_rng(5)
+    ec_of = rng.permutation(np.repeat(np.arange(E, dtype=np.int64), p["ec_counts"].astype(np.int64)))
+    files = [str(tmp_path / "r1.txt"), str(tmp_path / "r2.txt")]
+    for k, path in enumerate(files):
+        synth.write_themisto(path, ec_of, aln["ec_tptr"], aln["ec_targets"], chunk=1000,
+                             extra=(rng, 0.1, aln["n_targets"]) if k else None)
+    txt = f"{aln['n_targets']} 15\n" + " ".join(str(int(x)) for x in aln["target_group"]) + "\n" + \
+          " ".join(str(int(x)) for x in p["group_sizes"]) + "\n"
+    r = subprocess.run([device_likelihood_binary, "files", "1" if mode == "union" else "0", "1"] + files, input=txt,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(line.split(" ", 1) for line in r.stdout.strip().splitlines())
+    dev = gpu_core.read_alignment(files, int(aln["n_targets"]), mode)
+    lik = from_device_alignment(gpu_core, dev, aln["target_group"], p["group_sizes"], min_hits=1, download_log_counts=True)
+    res = gpu_core.solve(None, np.ones(lik.n_groups))
+    assert (int(out["n_groups"]), int(out["n_ecs"]), int(out["n_reads"]), int(out["n_aligned"])) == \
+           (lik.n_groups, dev.n_ecs, dev.n_reads, dev.n_aligned)
+    np.testing.assert_array_equal(np.array(out["mask"].split(), int).astype(bool), lik.groups_considered())
+    np.testing.assert_array_equal(np.array(out["counts"].split(), np.uint64), dev.ec_counts())
+    np.testing.assert_array_equal(np.array(out["logc"].split(), float), lik.log_counts())
+    assert int(out["iters"]) == res["iters"]
+    np.testing.assert_array_equal(np.array(out["theta"].split(), float), res["theta"])
+
+
 def test_reference_calls_keep_the_likelihood_resident_over_the_bootstrap_loop(reference_calls_binary, gpu_core, tmp_path):
     """src/mSWEEP.cpp:402,507: the same `ll_mat` goes to rcg_optl() 1 + --iters times.  Through the verbatim call
     expressions: ONE upload for the estimate and 20 replicates (the shim keeps the matrix resident, keyed by address,
