@@ -5,7 +5,6 @@ log_mat(), log_counts(), groups_considered()) but owns a device-resident CSR-of-
 dense) matrix inside a `Core` handle instead of a seamat::DenseMatrix.
 """
 import numpy as np
-from scipy.special import gammaln
 
 from .core import Core, MswError
 
@@ -21,6 +20,7 @@ def bb_params(group_sizes, q=0.65, e=0.01):
 
 
 def _lbeta(x, y):
+    from scipy.special import gammaln   # (imported where it is used: the drivers build on the device and never need it)
     return gammaln(x) + gammaln(y) - gammaln(x + y)
 
 
@@ -29,6 +29,7 @@ def precalc_lls(group_sizes, q=0.65, e=0.01, zero_inflation=0.01):
     T[g][k] = ldbb_scaled(k, n_g, alpha_g, beta_g) + log1p(-zi) for 1 <= k <= n_g.  Entries
     k > n_g are never indexed (the reference leaves lgamma-of-negative garbage there); they are
     filled with log(zi)."""
+    from scipy.special import gammaln
     sizes = np.asarray(group_sizes, np.int64)
     G, mx = len(sizes), int(sizes.max())
     alpha, beta = bb_params(sizes, q, e)
