@@ -13,7 +13,7 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 nap = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 check = len(sys.argv) > 4 and sys.argv[4] == "check"
-# MSWEEP_PROBE_DIR: keep the generated strands there (several runs of the probe -- e.g. over MSWEEP_READER_CHUNK_MB -- in
+# MSWEEP_PROBE_DIR: keep the generated strands there (several runs of the probe -- e.g. over MSWEEP_READER_BLOCK_MB -- in
 # one GPU job without generating the text again)
 keep = os.environ.get("MSWEEP_PROBE_DIR")
 tmp = keep or tempfile.mkdtemp(prefix="msweep_probe_", dir=os.environ.get("TMPDIR", "/tmp"))
