@@ -44,6 +44,17 @@ try:
         d = dev.arrays()
         for k in ("ec_tptr", "ec_targets", "ec_counts", "ec_rptr", "ec_reads"):
             assert np.array_equal(d[k], host[k]), k
+        from msweep_amd.likelihood import from_device_alignment
+        G = 100
+        tg = (np.arange(NT) * G // NT).astype(np.uint32)   # contiguous targets share a group: ~10 groups per read
+        sizes = np.bincount(tg, minlength=G).astype(np.uint64)
+        for rep in range(2):
+            t4 = time.perf_counter()
+            lik = from_device_alignment(core, dev, tg, sizes)
+            t5 = time.perf_counter()
+            res = core.solve(None, np.ones(lik.n_groups))
+            t6 = time.perf_counter()
+        print(f"{mode}: build {t5 - t4:.3f} s, solve {t6 - t5:.3f} s ({res['iters']} iterations, nnz {core.shape()[2]})", flush=True)
         print(f"{mode}: host reader {t1 - t0:.3f} s, device reader {t3 - t2:.3f} s; {dev.n_ecs} classes, {dev.n_hits} hits: equal", flush=True)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
