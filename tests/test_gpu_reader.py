@@ -269,14 +269,17 @@ def test_fuzz_mutated_text(core, tmp_path):
     """Random byte-level damage to small files: the device entry and the host reader end the same way -- the same five
     arrays, or the same error message (the kernels hand anything they do not judge to the host parser; what they DO take
     they must parse as the host does)."""
-    rng = np.random.default_rng(2024)
+    import os
+    # (MSWEEP_READER_FUZZ_SEED / _CASES: longer campaigns with other seeds, tools/README.md)
+    rng = np.random.default_rng(int(os.environ.get("MSWEEP_READER_FUZZ_SEED", "2024")))
+    n_cases = int(os.environ.get("MSWEEP_READER_FUZZ_CASES", "3000"))
     palette = [b" ", b"  ", b"\n", b"\r\n", b"\r", b"\t", b"x", b"-", b"+", b",", b"0", b"7", b"99", b"4294967295", b"4294967296",
                b"00000000000", b"\n\n", b" \n", b"\x00", b"12345678901"]
     n_targets = 64
     n_ok = n_err = 0
     served = {True: 0, False: 0}   # texts the kernels took / handed to the host parser (and it accepted)
     p = tmp_path / "f.txt"
-    for case in range(3000):
+    for case in range(n_cases):
         # (one case in ten spans several 4 KB tiles of the text kernels)
         lines = _lines(rng, int(rng.integers(200, 700)) if case % 10 == 0 else int(rng.integers(1, 40)), n_targets, dup_lines=bool(rng.integers(0, 2)), shuffle=bool(rng.integers(0, 2)))
         text = bytearray(("\n".join(lines) + ("\n" if rng.random() < 0.8 else "")).encode())
